@@ -1,0 +1,181 @@
+"""ctypes mirror of include/i2lqr.h and the loader of libi2lqr_hip.so.
+
+The product path has NO CPU fallback: `load_library()` raises if the HIP extension has not been
+built, and every solver call raises if no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_N = 12
+MAX_M = 4
+MAX_HORIZON = 64
+OBS_WORDS = 6
+
+F64, F32 = 0, 1
+LAYOUT_PROBLEM_MAJOR, LAYOUT_BATCH_MINOR = 0, 1
+SYS_BICYCLE4, SYS_BICYCLE6, SYS_QUAD12 = 0, 1, 2
+SYSTEM_DIMS = {SYS_BICYCLE4: (4, 2), SYS_BICYCLE6: (6, 2), SYS_QUAD12: (12, 4)}
+SYSTEM_NAMES = {"bicycle4": SYS_BICYCLE4, "bicycle6": SYS_BICYCLE6, "quad12": SYS_QUAD12}
+
+ST_RUNNING, ST_CONVERGED, ST_MAX_ITER, ST_LAMB_OVERFLOW, ST_NONFINITE = 0, 1, 2, 3, 4
+STATUS_NAMES = {
+    ST_RUNNING: "running",
+    ST_CONVERGED: "converged",
+    ST_MAX_ITER: "max_iter",
+    ST_LAMB_OVERFLOW: "lamb_overflow",
+    ST_NONFINITE: "nonfinite",
+}
+
+
+class I2lqrConfig(C.Structure):
+    """`i2lqr_config` (include/i2lqr.h).  Field order and types must match the header."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("n", C.c_int32),
+        ("m", C.c_int32),
+        ("N", C.c_int32),
+        ("dtype", C.c_int32),
+        ("layout", C.c_int32),
+        ("system_id", C.c_int32),
+        ("max_iter", C.c_int32),
+        ("dt", C.c_double),
+        ("eps", C.c_double),
+        ("lamb_factor", C.c_double),
+        ("max_lamb", C.c_double),
+        ("ctrl_q1", C.c_double),
+        ("ctrl_q2", C.c_double),
+        ("obs_q1", C.c_double),
+        ("obs_q2", C.c_double),
+        ("safety_margin", C.c_double),
+        ("u_max", C.c_double * MAX_M),
+        ("xtarget", C.c_double * MAX_N),
+        ("Q", C.c_double * (MAX_N * MAX_N)),
+        ("Qt", C.c_double * (MAX_N * MAX_N)),
+        ("R", C.c_double * (MAX_M * MAX_M)),
+        ("sys_par", C.c_double * 8),
+    ]
+
+    # -- convenience -----------------------------------------------------------------------
+    def set_matrix(self, name: str, mat) -> None:
+        mat = np.asarray(mat, dtype=np.float64)
+        ld = MAX_M if name == "R" else MAX_N
+        buf = np.zeros((ld, ld))
+        buf[: mat.shape[0], : mat.shape[1]] = mat
+        getattr(self, name)[:] = buf.ravel().tolist()
+
+    def get_matrix(self, name: str) -> np.ndarray:
+        ld, d = (MAX_M, self.m) if name == "R" else (MAX_N, self.n)
+        return np.array(getattr(self, name)[:]).reshape(ld, ld)[:d, :d].copy()
+
+    def copy(self) -> "I2lqrConfig":
+        out = I2lqrConfig()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(I2lqrConfig))
+        return out
+
+    @property
+    def np_dtype(self):
+        return np.float64 if self.dtype == F64 else np.float32
+
+
+def default_config(system="bicycle4", num_horizon=6, dtype="f64", dt=1.0,
+                   layout=LAYOUT_PROBLEM_MAJOR) -> I2lqrConfig:
+    """Reference defaults (iLqrParam utils/base.py:243-271, KineticBicycleParam :16) for a system.
+
+    bicycle4 reproduces the reference exactly; bicycle6 / quad12 are build-defined and keep the
+    same barrier / regularisation constants with their own terminal weights and input boxes.
+    """
+    sid = SYSTEM_NAMES[system] if isinstance(system, str) else int(system)
+    n, m = SYSTEM_DIMS[sid]
+    cfg = I2lqrConfig()
+    cfg.struct_size = C.sizeof(I2lqrConfig)
+    cfg.n, cfg.m, cfg.N = n, m, int(num_horizon)
+    cfg.dtype = {"f64": F64, "f32": F32}[dtype] if isinstance(dtype, str) else int(dtype)
+    cfg.layout = layout
+    cfg.system_id = sid
+    cfg.max_iter = 150
+    cfg.dt = float(dt)
+    cfg.eps = 1e-2
+    cfg.lamb_factor = 10.0
+    cfg.max_lamb = 1000.0
+    cfg.ctrl_q1 = cfg.ctrl_q2 = 1.0
+    cfg.obs_q1 = cfg.obs_q2 = 2.74
+    cfg.safety_margin = 0.0
+    if sid == SYS_BICYCLE4:
+        # a_max = 2.0, delta_max = pi/2 clipped/barriered at round(pi/2, 2) = 1.57
+        # (utils/base.py:16, control/iterative_ilqr.py:38-39, control/ilqr_helper.py:96-99)
+        cfg.u_max[:] = [2.0, round(np.pi / 2, 2), 0.0, 0.0]
+        cfg.set_matrix("Qt", 2 * np.diag([1.0, 1.0, 20.0, 0.02]))
+    elif sid == SYS_BICYCLE6:
+        cfg.u_max[:] = [1.0, 0.5, 0.0, 0.0]  # jerk, steering-rate box
+        cfg.set_matrix("Qt", 2 * np.diag([1.0, 1.0, 20.0, 0.02, 1.0, 1.0]))
+    else:
+        cfg.u_max[:] = [2.0, 2.0, 2.0, 2.0]  # thrust deviation box [N] around hover
+        cfg.set_matrix("Qt", 2 * np.diag([10.0] * 3 + [5.0] * 3 + [1.0] * 3 + [0.5] * 3))
+        # mass [kg], g, arm [m], Ix, Iy, Iz [kg m^2], ctau [m]
+        cfg.sys_par[:] = [1.0, 9.81, 0.2, 0.01, 0.01, 0.02, 0.05, 0.0]
+    return cfg
+
+
+# -- library loading ---------------------------------------------------------------------------
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_NAME = "libi2lqr_hip.so"
+LIB_PATH = _PKG_DIR / "csrc" / LIB_NAME
+
+# name -> (restype, argtypes); the exports include/i2lqr.h declares.
+_P = C.c_void_p
+EXPORTS = {
+    "i2lqr_version": (C.c_int, []),
+    "i2lqr_last_error": (C.c_char_p, []),
+    "i2lqr_config_default": (C.c_int, [C.POINTER(I2lqrConfig), C.c_int, C.c_int]),
+    "i2lqr_create": (C.c_int, [C.POINTER(I2lqrConfig), C.POINTER(_P)]),
+    "i2lqr_destroy": (C.c_int, [_P]),
+    "i2lqr_rollout": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "i2lqr_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_iterate": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                _P]),
+    "i2lqr_solve": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_relax_cost": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "i2lqr_argmin_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen libi2lqr_hip.so and bind every export.  Raises if the extension is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` (or `make -C {_PKG_DIR / 'csrc'}`). There is no "
+            "CPU fallback for the solver."
+        )
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It
+    # must be the first one in the process so that this library binds to the SAME runtime and
+    # shares torch's streams and allocations; loading /opt/rocm's copy first would give the
+    # process two runtimes.
+    import torch  # noqa: F401
+    lib = C.CDLL(str(p))
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if an export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    ver = lib.i2lqr_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"{p}: ABI version {ver}, Python mirror expects {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,470 @@
+// C-ABI of libi2lqr_hip.so (include/i2lqr.h): argument validation, typed device configs and
+// kernel dispatch.  No exception crosses the boundary; every entry point returns an int code and
+// records a thread-local message for i2lqr_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/i2lqr.h"
+#include "i2lqr_wave.hpp"
+
+using namespace i2lqr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(I2LQR_ERR_LAUNCH, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+template <class T, int n, int m> DevCfg<T, n, m> make_dev_cfg(const i2lqr_config& h) {
+  DevCfg<T, n, m> d;
+  std::memset(&d, 0, sizeof(d));
+  d.N = h.N;
+  d.max_iter = h.max_iter;
+  d.dt = (T)h.dt;
+  d.eps = (T)h.eps;
+  d.lamb_factor = (T)h.lamb_factor;
+  d.max_lamb = (T)h.max_lamb;
+  d.ctrl_q1 = (T)h.ctrl_q1;
+  d.ctrl_q2 = (T)h.ctrl_q2;
+  d.obs_q1 = (T)h.obs_q1;
+  d.obs_q2 = (T)h.obs_q2;
+  d.safety_margin = (T)h.safety_margin;
+  bool hasQ = false, hasR = false;
+  for (int a = 0; a < m; a++) d.u_max[a] = (T)h.u_max[a];
+  for (int i = 0; i < n; i++) d.xtarget[i] = (T)h.xtarget[i];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      d.Q[i * n + j] = (T)h.Q[i * I2LQR_MAX_N + j];
+      d.Qt[i * n + j] = (T)h.Qt[i * I2LQR_MAX_N + j];
+      hasQ |= h.Q[i * I2LQR_MAX_N + j] != 0.0;
+    }
+  for (int a = 0; a < m; a++)
+    for (int b = 0; b < m; b++) {
+      d.R[a * m + b] = (T)h.R[a * I2LQR_MAX_M + b];
+      hasR |= h.R[a * I2LQR_MAX_M + b] != 0.0;
+    }
+  for (int q = 0; q < 8; q++) d.sys_par[q] = (T)h.sys_par[q];
+  d.flags = (hasQ ? FLAG_HAS_Q : 0) | (hasR ? FLAG_HAS_R : 0);
+  return d;
+}
+
+}  // namespace
+
+struct i2lqr_handle {
+  i2lqr_config cfg;
+  int lanes;        // lanes of a wavefront that cooperate on one problem
+  size_t lds_bytes; // dynamic LDS per workgroup (one wavefront)
+  int device;
+};
+
+namespace {
+
+// One launcher per (dtype, system); LANES fixed at 64 = one problem per wavefront.
+template <class T, class Sys> struct Launch {
+  static constexpr int n = Sys::n, m = Sys::m, LANES = 64;
+  using Cfg = DevCfg<T, n, m>;
+
+  static size_t lds_bytes(int N) { return (size_t)Layout<Sys>(N).total * sizeof(T) * (64 / LANES); }
+  static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
+
+  static int prepare(i2lqr_handle* h) {
+    h->lanes = LANES;
+    h->lds_bytes = lds_bytes(h->cfg.N);
+    if (h->lds_bytes > 160 * 1024)
+      return fail(I2LQR_ERR_UNSUPPORTED, "horizon %d needs %zu B of LDS per wavefront (> 160 KiB)",
+                  h->cfg.N, h->lds_bytes);
+    if (h->lds_bytes > 64 * 1024) {
+      const int bytes = (int)h->lds_bytes;
+      HIP_TRY(hipFuncSetAttribute((const void*)k_iterate<T, Sys, LANES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_backward<T, Sys, LANES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_forward<T, Sys, LANES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_rollout<T, Sys, LANES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    return I2LQR_OK;
+  }
+
+  static int iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
+                     const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                     int32_t* iters, int32_t* status, hipStream_t s) {
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    IterArgs<T> a;
+    a.B = B;
+    a.n_iters = n_iters;
+    a.early_exit = early_exit;
+    a.X = (T*)X;
+    a.U = (T*)U;
+    a.x_term = (const T*)x_term;
+    a.lamb = (T*)lamb;
+    a.obs = (const T*)obs;
+    a.cost = (T*)cost;
+    a.K = (T*)K;
+    a.k = (T*)k;
+    a.iters = iters;
+    a.status = status;
+    hipLaunchKernelGGL((k_iterate<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, a);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
+                     hipStream_t s) {
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    hipLaunchKernelGGL((k_rollout<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
+                       (T*)X, (T*)U, (const T*)x_term, (T*)cost);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                      const void* lamb, const void* obs, void* K, void* k, hipStream_t s) {
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    hipLaunchKernelGGL((k_backward<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
+                       (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb, (const T*)obs,
+                       (T*)K, (T*)k);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                     const void* K, const void* k, void* Xn, void* Un, void* cost_new,
+                     hipStream_t s) {
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    hipLaunchKernelGGL((k_forward<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
+                       (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
+                       (T*)Xn, (T*)Un, (T*)cost_new);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+};
+
+// dispatch over (dtype, system)
+#define I2LQR_DISPATCH(h, CALL)                                                               \
+  do {                                                                                        \
+    const int sid_ = (h)->cfg.system_id;                                                      \
+    if ((h)->cfg.dtype == I2LQR_F64) {                                                        \
+      if (sid_ == I2LQR_SYS_BICYCLE4) return Launch<double, Bicycle4<double>>::CALL;          \
+      if (sid_ == I2LQR_SYS_BICYCLE6) return Launch<double, Bicycle6<double>>::CALL;          \
+      if (sid_ == I2LQR_SYS_QUAD12) return Launch<double, Quad12<double>>::CALL;              \
+    } else {                                                                                  \
+      if (sid_ == I2LQR_SYS_BICYCLE4) return Launch<float, Bicycle4<float>>::CALL;            \
+      if (sid_ == I2LQR_SYS_BICYCLE6) return Launch<float, Bicycle6<float>>::CALL;            \
+      if (sid_ == I2LQR_SYS_QUAD12) return Launch<float, Quad12<float>>::CALL;                \
+    }                                                                                         \
+    return fail(I2LQR_ERR_UNSUPPORTED, "system %d / dtype %d not built", sid_,               \
+                (h)->cfg.dtype);                                                              \
+  } while (0)
+
+int prepare_dispatch(i2lqr_handle* h) { I2LQR_DISPATCH(h, prepare(h)); }
+
+int check_common(const i2lqr_handle* h, int64_t B) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
+  if (B > (int64_t)0x7fffffff) return fail(I2LQR_ERR_INVALID, "batch %lld too large", (long long)B);
+  return I2LQR_OK;
+}
+
+// ---- arg-min kernels (flat, first index wins ties) -------------------------------------------
+template <class T> struct MinPair { T v; int64_t i; };
+
+template <class T> __device__ __forceinline__ bool better(T v, int64_t i, T bv, int64_t bi) {
+  // NaN never wins; ties resolve to the lower index (Python list.index(min(list)))
+  if (v != v) return false;
+  if (bi < 0) return true;
+  return v < bv || (v == bv && i < bi);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_argmin_partial(int64_t B, const T* cost,
+                                                        MinPair<T>* part) {
+  __shared__ T sv[256];
+  __shared__ int64_t si[256];
+  T bv = T(0);
+  int64_t bi = -1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
+    const T v = cost[i];
+    if (better(v, i, bv, bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const T ov = sv[threadIdx.x + s];
+      const int64_t oi = si[threadIdx.x + s];
+      if (oi >= 0 && better(ov, oi, sv[threadIdx.x], si[threadIdx.x])) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[blockIdx.x].v = sv[0]; part[blockIdx.x].i = si[0]; }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_argmin_final(int nparts, const MinPair<T>* part,
+                                                      int64_t* best_idx, T* best_cost) {
+  __shared__ T sv[256];
+  __shared__ int64_t si[256];
+  T bv = T(0);
+  int64_t bi = -1;
+  for (int p = threadIdx.x; p < nparts; p += 256) {
+    const T v = part[p].v;
+    const int64_t i = part[p].i;
+    if (i >= 0 && better(v, i, bv, bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const T ov = sv[threadIdx.x + s];
+      const int64_t oi = si[threadIdx.x + s];
+      if (oi >= 0 && better(ov, oi, sv[threadIdx.x], si[threadIdx.x])) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *best_idx = si[0];
+    *best_cost = si[0] >= 0 ? sv[0] : (T)INFINITY;
+  }
+}
+
+constexpr int kArgminBlocks = 256;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int i2lqr_version(void) { return I2LQR_ABI_VERSION; }
+
+const char* i2lqr_last_error(void) { return g_err; }
+
+int i2lqr_config_default(i2lqr_config* cfg, int system_id, int num_horizon) {
+  if (!cfg) return fail(I2LQR_ERR_INVALID, "null cfg");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = (int32_t)sizeof(*cfg);
+  cfg->N = num_horizon;
+  cfg->dtype = I2LQR_F64;
+  cfg->layout = I2LQR_LAYOUT_PROBLEM_MAJOR;
+  cfg->system_id = system_id;
+  cfg->max_iter = 150;
+  cfg->dt = 1.0;
+  cfg->eps = 1e-2;
+  cfg->lamb_factor = 10.0;
+  cfg->max_lamb = 1000.0;
+  cfg->ctrl_q1 = cfg->ctrl_q2 = 1.0;
+  cfg->obs_q1 = cfg->obs_q2 = 2.74;
+  cfg->safety_margin = 0.0;
+  auto diag = [&](double* M, int i, double v) { M[i * I2LQR_MAX_N + i] = v; };
+  switch (system_id) {
+    case I2LQR_SYS_BICYCLE4: {
+      cfg->n = 4;
+      cfg->m = 2;
+      cfg->u_max[0] = 2.0;
+      cfg->u_max[1] = 1.57; /* round(pi/2, 2) */
+      const double qt[4] = {2.0, 2.0, 40.0, 0.04};
+      for (int i = 0; i < 4; i++) diag(cfg->Qt, i, qt[i]);
+      break;
+    }
+    case I2LQR_SYS_BICYCLE6: {
+      cfg->n = 6;
+      cfg->m = 2;
+      cfg->u_max[0] = 1.0;
+      cfg->u_max[1] = 0.5;
+      const double qt[6] = {2.0, 2.0, 40.0, 0.04, 2.0, 2.0};
+      for (int i = 0; i < 6; i++) diag(cfg->Qt, i, qt[i]);
+      break;
+    }
+    case I2LQR_SYS_QUAD12: {
+      cfg->n = 12;
+      cfg->m = 4;
+      for (int a = 0; a < 4; a++) cfg->u_max[a] = 2.0;
+      const double qt[4] = {20.0, 10.0, 2.0, 1.0};
+      for (int i = 0; i < 12; i++) diag(cfg->Qt, i, qt[i / 3]);
+      const double sp[8] = {1.0, 9.81, 0.2, 0.01, 0.01, 0.02, 0.05, 0.0};
+      for (int q = 0; q < 8; q++) cfg->sys_par[q] = sp[q];
+      break;
+    }
+    default:
+      return fail(I2LQR_ERR_INVALID, "unknown system_id %d", system_id);
+  }
+  return I2LQR_OK;
+}
+
+int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
+  if (!cfg || !out) return fail(I2LQR_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(i2lqr_config))
+    return fail(I2LQR_ERR_INVALID, "config struct_size %d, library expects %zu", cfg->struct_size,
+                sizeof(i2lqr_config));
+  int n = 0, m = 0;
+  switch (cfg->system_id) {
+    case I2LQR_SYS_BICYCLE4: n = 4; m = 2; break;
+    case I2LQR_SYS_BICYCLE6: n = 6; m = 2; break;
+    case I2LQR_SYS_QUAD12: n = 12; m = 4; break;
+    default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
+  }
+  if (cfg->n != n || cfg->m != m)
+    return fail(I2LQR_ERR_INVALID, "system %d has n=%d m=%d, config says n=%d m=%d", cfg->system_id,
+                n, m, cfg->n, cfg->m);
+  if (cfg->N < 1 || cfg->N > I2LQR_MAX_HORIZON)
+    return fail(I2LQR_ERR_INVALID, "horizon %d outside [1, %d]", cfg->N, I2LQR_MAX_HORIZON);
+  if (cfg->dtype != I2LQR_F64 && cfg->dtype != I2LQR_F32)
+    return fail(I2LQR_ERR_INVALID, "unknown dtype %d", cfg->dtype);
+  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return fail(I2LQR_ERR_UNSUPPORTED, "layout %d is not built (problem-major only)", cfg->layout);
+  if (!(cfg->dt > 0) || !(cfg->lamb_factor > 1) || cfg->max_iter < 0)
+    return fail(I2LQR_ERR_INVALID, "need dt > 0, lamb_factor > 1, max_iter >= 0");
+  for (int a = 0; a < m; a++)
+    if (!(cfg->u_max[a] > 0)) return fail(I2LQR_ERR_INVALID, "u_max[%d] must be > 0", a);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(I2LQR_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");
+  i2lqr_handle* h = new (std::nothrow) i2lqr_handle;
+  if (!h) return fail(I2LQR_ERR_LAUNCH, "out of host memory");
+  h->cfg = *cfg;
+  HIP_TRY(hipGetDevice(&h->device));
+  const int rc = prepare_dispatch(h);
+  if (rc != I2LQR_OK) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  g_err[0] = 0;
+  return I2LQR_OK;
+}
+
+int i2lqr_destroy(i2lqr_handle* h) {
+  delete h;
+  return I2LQR_OK;
+}
+
+int i2lqr_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
+                  void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
+  I2LQR_DISPATCH(h, rollout(h, B, X, U, x_term, cost, (hipStream_t)stream));
+}
+
+int i2lqr_backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                   const void* lamb, const void* obs, void* K, void* k, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !lamb || !K || !k) return fail(I2LQR_ERR_INVALID, "null buffer");
+  I2LQR_DISPATCH(h, backward(h, B, X, U, x_term, lamb, obs, K, k, (hipStream_t)stream));
+}
+
+int i2lqr_forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                  const void* K, const void* k, void* X_new, void* U_new, void* cost_new,
+                  void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !K || !k || !X_new || !U_new || !cost_new)
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  I2LQR_DISPATCH(h, forward(h, B, X, U, x_term, K, k, X_new, U_new, cost_new,
+                            (hipStream_t)stream));
+}
+
+int i2lqr_iterate(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
+                  const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                  int32_t* iters, int32_t* status, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (n_iters < 0) return fail(I2LQR_ERR_INVALID, "negative n_iters");
+  if (B == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !lamb || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
+  if ((K == nullptr) != (k == nullptr))
+    return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
+  I2LQR_DISPATCH(h, iterate(h, B, n_iters, 0, X, U, x_term, lamb, obs, cost, K, k, iters, status,
+                            (hipStream_t)stream));
+}
+
+int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* lamb,
+                const void* obs, void* cost, void* K, void* k, int32_t* iters, int32_t* status,
+                void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !lamb || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
+  if ((K == nullptr) != (k == nullptr))
+    return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
+  I2LQR_DISPATCH(h, iterate(h, B, h->cfg.max_iter, 1, X, U, x_term, lamb, obs, cost, K, k, iters,
+                            status, (hipStream_t)stream));
+}
+
+int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_term,
+                     const int32_t* qfun, int32_t outer_iter, int32_t max_relax_iter,
+                     void* cost_it, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B == 0) return I2LQR_OK;
+  if (!X || !x_term || !qfun || !cost_it) return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (outer_iter < 0 || max_relax_iter < 1)
+    return fail(I2LQR_ERR_INVALID, "need outer_iter >= 0 and max_relax_iter >= 1");
+  const unsigned grid = (unsigned)((B + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_relax_cost<double>), dim3(grid), dim3(256), 0, s, B, h->cfg.n, h->cfg.N,
+                       (const double*)X, (const double*)x_term, qfun, outer_iter, max_relax_iter,
+                       (double*)cost_it);
+  else
+    hipLaunchKernelGGL((k_relax_cost<float>), dim3(grid), dim3(256), 0, s, B, h->cfg.n, h->cfg.N,
+                       (const float*)X, (const float*)x_term, qfun, outer_iter, max_relax_iter,
+                       (float*)cost_it);
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int64_t i2lqr_argmin_workspace_bytes(int64_t B) {
+  (void)B;
+  return (int64_t)kArgminBlocks * 16;
+}
+
+int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
+                 void* best_cost, void* workspace, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (!cost_it || !best_idx || !best_cost || !workspace)
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t want = (B + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > kArgminBlocks ? kArgminBlocks : want));
+  if (h->cfg.dtype == I2LQR_F64) {
+    auto* part = (MinPair<double>*)workspace;
+    hipLaunchKernelGGL((k_argmin_partial<double>), dim3(blocks), dim3(256), 0, s, B,
+                       (const double*)cost_it, part);
+    hipLaunchKernelGGL((k_argmin_final<double>), dim3(1), dim3(256), 0, s, blocks, part, best_idx,
+                       (double*)best_cost);
+  } else {
+    auto* part = (MinPair<float>*)workspace;
+    hipLaunchKernelGGL((k_argmin_partial<float>), dim3(blocks), dim3(256), 0, s, B,
+                       (const float*)cost_it, part);
+    hipLaunchKernelGGL((k_argmin_final<float>), dim3(1), dim3(256), 0, s, blocks, part, best_idx,
+                       (float*)best_cost);
+  }
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+}  // extern "C"

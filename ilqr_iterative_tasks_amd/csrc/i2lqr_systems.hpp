@@ -1,0 +1,270 @@
+// Plant models of the batched iLQR solver, device side (gfx950).
+//
+// Each system provides, for state dimension n and input dimension m:
+//   step()     x_{t+1} = f(x_t, u_t)
+//   trig()     the transcendental values the Jacobians need at the evaluation state
+//              (computed once per horizon step, in parallel over t, and cached in LDS)
+//   jac_var()  the NVAR state/input-dependent entries of F = [A | B]  (n x (n+m), row-major)
+//   var_idx()  flat index into F of varying entry v
+//   jac_const() value of a non-varying entry of F (identity / dt pattern)
+//
+// Reference: systems/kinetic_bicycle.py:10-52 (kinetic_bicycle, get_A_matrix, get_B_matrix).
+// The reference evaluates the Jacobians of step t with v, theta of x_{t+1} and accel of u_t
+// (control/iterative_ilqr.py:92-99); `xe` below is that evaluation state for every system.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace i2lqr {
+
+template <class T> __device__ __forceinline__ T t_sin(T x);
+template <> __device__ __forceinline__ double t_sin<double>(double x) { return sin(x); }
+template <> __device__ __forceinline__ float t_sin<float>(float x) { return sinf(x); }
+template <class T> __device__ __forceinline__ T t_cos(T x);
+template <> __device__ __forceinline__ double t_cos<double>(double x) { return cos(x); }
+template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf(x); }
+template <class T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <class T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+template <class T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+// The library is built with -ffp-contract=off so that one source expression rounds the same way
+// in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
+// the dot products of the Riccati step ask for the fused multiply-add explicitly.
+template <class T> __device__ __forceinline__ T t_fma(T a, T b, T c);
+template <> __device__ __forceinline__ double t_fma<double>(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+template <> __device__ __forceinline__ float t_fma<float>(float a, float b, float c) {
+  return __builtin_fmaf(a, b, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bicycle4: the reference plant.  x = [x, y, v, theta], u = [accel, delta].
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Bicycle4 {
+  static constexpr int n = 4, m = 2, NTRIG = 2, NVAR = 6;
+  static constexpr int system_id = 0;
+
+  // kinetic_bicycle(): systems/kinetic_bicycle.py:10-27
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    const T dt = c.dt;
+    const T w = x[2] * dt + (u[0] * dt * dt) / T(2);
+    xn[0] = x[0] + t_cos(x[3]) * w;
+    xn[1] = x[1] + t_sin(x[3]) * w;
+    xn[2] = x[2] + u[0] * dt;
+    xn[3] = x[3] + u[1] * dt;
+  }
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    tr[0] = t_cos(xe[3]);
+    tr[1] = t_sin(xe[3]);
+  }
+  // get_A_matrix / get_B_matrix: systems/kinetic_bicycle.py:30-52
+  template <class Cfg>
+  static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&u)[m],
+                                                 const T (&tr)[NTRIG], T (&v)[NVAR]) {
+    const T dt = c.dt;
+    const T w = xe[2] * dt + (u[0] * dt * dt) / T(2);
+    v[0] = tr[0] * dt;             // A[0][2]
+    v[1] = -w * tr[1];             // A[0][3]
+    v[2] = tr[1] * dt;             // A[1][2]
+    v[3] = w * tr[0];              // A[1][3]
+    v[4] = dt * dt * tr[0] / T(2); // B[0][0]
+    v[5] = dt * dt * tr[1] / T(2); // B[1][0]
+  }
+  static __device__ __forceinline__ int var_idx(int v) {
+    constexpr int W = n + m;
+    const int idx[NVAR] = {0 * W + 2, 0 * W + 3, 1 * W + 2, 1 * W + 3, 0 * W + n, 1 * W + n};
+    int r = idx[0];
+#pragma unroll
+    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
+    return r;
+  }
+  template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
+    if (j < n) return (i == j) ? T(1) : T(0);
+    return ((i == 2 && j == n) || (i == 3 && j == n + 1)) ? c.dt : T(0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// bicycle6 (build-defined): bicycle4 with actuator states.  x = [x, y, v, theta, a, delta],
+// u = [jerk, steering rate].
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Bicycle6 {
+  static constexpr int n = 6, m = 2, NTRIG = 2, NVAR = 6;
+  static constexpr int system_id = 1;
+
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    const T dt = c.dt;
+    const T w = x[2] * dt + (x[4] * dt * dt) / T(2);
+    xn[0] = x[0] + t_cos(x[3]) * w;
+    xn[1] = x[1] + t_sin(x[3]) * w;
+    xn[2] = x[2] + x[4] * dt;
+    xn[3] = x[3] + x[5] * dt;
+    xn[4] = x[4] + u[0] * dt;
+    xn[5] = x[5] + u[1] * dt;
+  }
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    tr[0] = t_cos(xe[3]);
+    tr[1] = t_sin(xe[3]);
+  }
+  template <class Cfg>
+  static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&)[m],
+                                                 const T (&tr)[NTRIG], T (&v)[NVAR]) {
+    const T dt = c.dt;
+    const T w = xe[2] * dt + (xe[4] * dt * dt) / T(2);
+    v[0] = tr[0] * dt;             // A[0][2]
+    v[1] = -w * tr[1];             // A[0][3]
+    v[2] = dt * dt * tr[0] / T(2); // A[0][4]
+    v[3] = tr[1] * dt;             // A[1][2]
+    v[4] = w * tr[0];              // A[1][3]
+    v[5] = dt * dt * tr[1] / T(2); // A[1][4]
+  }
+  static __device__ __forceinline__ int var_idx(int v) {
+    constexpr int W = n + m;
+    const int idx[NVAR] = {0 * W + 2, 0 * W + 3, 0 * W + 4, 1 * W + 2, 1 * W + 3, 1 * W + 4};
+    int r = idx[0];
+#pragma unroll
+    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
+    return r;
+  }
+  template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
+    if (j < n) {
+      if (i == j) return T(1);
+      return ((i == 2 && j == 4) || (i == 3 && j == 5)) ? c.dt : T(0);
+    }
+    return ((i == 4 && j == n) || (i == 5 && j == n + 1)) ? c.dt : T(0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// quad12 (build-defined): rigid-body quadrotor, explicit Euler.
+// x = [p(3), phi, theta, psi, v(3), p, q, r], u = rotor thrust deviations from hover.
+// sys_par = {mass, g, arm, Ix, Iy, Iz, ctau}.
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Quad12 {
+  static constexpr int n = 12, m = 4, NTRIG = 6;
+  // 25 state-dependent entries of A and the 3 x 4 thrust-direction entries of B
+  static constexpr int NVAR = 37;
+  static constexpr int system_id = 2;
+
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    const T mass = c.sys_par[0], g = c.sys_par[1], arm = c.sys_par[2];
+    const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5], ct = c.sys_par[6];
+    const T sph = t_sin(x[3]), cph = t_cos(x[3]), sth = t_sin(x[4]), cth = t_cos(x[4]);
+    const T sps = t_sin(x[5]), cps = t_cos(x[5]);
+    const T tth = sth / cth;
+    const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
+    const T p = x[9], q = x[10], r = x[11], dt = c.dt;
+    T f[n];
+    f[0] = x[6];
+    f[1] = x[7];
+    f[2] = x[8];
+    f[3] = p + q * sph * tth + r * cph * tth;
+    f[4] = q * cph - r * sph;
+    f[5] = (q * sph + r * cph) / cth;
+    f[6] = (Tt / mass) * (cph * sth * cps + sph * sps);
+    f[7] = (Tt / mass) * (cph * sth * sps - sph * cps);
+    f[8] = (Tt / mass) * (cph * cth) - g;
+    f[9] = ((Iy - Iz) / Ix) * q * r + arm * (u[1] - u[3]) / Ix;
+    f[10] = ((Iz - Ix) / Iy) * p * r + arm * (u[2] - u[0]) / Iy;
+    f[11] = ((Ix - Iy) / Iz) * p * q + ct * (u[0] - u[1] + u[2] - u[3]) / Iz;
+#pragma unroll
+    for (int i = 0; i < n; i++) xn[i] = x[i] + dt * f[i];
+  }
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    tr[0] = t_sin(xe[3]);
+    tr[1] = t_cos(xe[3]);
+    tr[2] = t_sin(xe[4]);
+    tr[3] = t_cos(xe[4]);
+    tr[4] = t_sin(xe[5]);
+    tr[5] = t_cos(xe[5]);
+  }
+  template <class Cfg>
+  static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&u)[m],
+                                                 const T (&tr)[NTRIG], T (&v)[NVAR]) {
+    const T mass = c.sys_par[0], g = c.sys_par[1];
+    const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
+    const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
+    const T tth = sth / cth, sec2 = T(1) / (cth * cth);
+    const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
+    const T Tm = Tt / mass, dt = c.dt;
+    const T p = xe[9], q = xe[10], r = xe[11];
+    // A = I + dt * dF/dx
+    v[0] = T(1) + dt * ((q * cph - r * sph) * tth);       // [3][3]
+    v[1] = dt * ((q * sph + r * cph) * sec2);             // [3][4]
+    v[2] = dt * (sph * tth);                              // [3][10]
+    v[3] = dt * (cph * tth);                              // [3][11]
+    v[4] = dt * (-q * sph - r * cph);                     // [4][3]
+    v[5] = dt * cph;                                      // [4][10]
+    v[6] = dt * (-sph);                                   // [4][11]
+    v[7] = dt * ((q * cph - r * sph) / cth);              // [5][3]
+    v[8] = dt * ((q * sph + r * cph) * sth * sec2);       // [5][4]
+    v[9] = dt * (sph / cth);                              // [5][10]
+    v[10] = dt * (cph / cth);                             // [5][11]
+    v[11] = dt * (Tm * (-sph * sth * cps + cph * sps));   // [6][3]
+    v[12] = dt * (Tm * (cph * cth * cps));                // [6][4]
+    v[13] = dt * (Tm * (-cph * sth * sps + sph * cps));   // [6][5]
+    v[14] = dt * (Tm * (-sph * sth * sps - cph * cps));   // [7][3]
+    v[15] = dt * (Tm * (cph * cth * sps));                // [7][4]
+    v[16] = dt * (Tm * (cph * sth * cps + sph * sps));    // [7][5]
+    v[17] = dt * (Tm * (-sph * cth));                     // [8][3]
+    v[18] = dt * (Tm * (-cph * sth));                     // [8][4]
+    v[19] = dt * (((Iy - Iz) / Ix) * r);                  // [9][10]
+    v[20] = dt * (((Iy - Iz) / Ix) * q);                  // [9][11]
+    v[21] = dt * (((Iz - Ix) / Iy) * r);                  // [10][9]
+    v[22] = dt * (((Iz - Ix) / Iy) * p);                  // [10][11]
+    v[23] = dt * (((Ix - Iy) / Iz) * q);                  // [11][9]
+    v[24] = dt * (((Ix - Iy) / Iz) * p);                  // [11][10]
+    // B rows 6..8: dt * a{x,y,z} for each of the 4 inputs
+    const T ax = dt * ((cph * sth * cps + sph * sps) / mass);
+    const T ay = dt * ((cph * sth * sps - sph * cps) / mass);
+    const T az = dt * ((cph * cth) / mass);
+#pragma unroll
+    for (int j = 0; j < m; j++) {
+      v[25 + j] = ax;
+      v[29 + j] = ay;
+      v[33 + j] = az;
+    }
+  }
+  static __device__ __forceinline__ int var_idx(int v) {
+    constexpr int W = n + m;
+    const int idx[NVAR] = {
+        3 * W + 3,  3 * W + 4,  3 * W + 10, 3 * W + 11, 4 * W + 3,  4 * W + 10, 4 * W + 11,
+        5 * W + 3,  5 * W + 4,  5 * W + 10, 5 * W + 11, 6 * W + 3,  6 * W + 4,  6 * W + 5,
+        7 * W + 3,  7 * W + 4,  7 * W + 5,  8 * W + 3,  8 * W + 4,  9 * W + 10, 9 * W + 11,
+        10 * W + 9, 10 * W + 11, 11 * W + 9, 11 * W + 10,
+        6 * W + n + 0, 6 * W + n + 1, 6 * W + n + 2, 6 * W + n + 3,
+        7 * W + n + 0, 7 * W + n + 1, 7 * W + n + 2, 7 * W + n + 3,
+        8 * W + n + 0, 8 * W + n + 1, 8 * W + n + 2, 8 * W + n + 3};
+    int r = idx[0];
+#pragma unroll
+    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
+    return r;
+  }
+  template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
+    const T dt = c.dt;
+    if (j < n) {
+      if (i == j) return T(1);
+      if (i < 3 && j == i + 6) return dt; // d pos / d vel
+      if (i == 3 && j == 9) return dt;    // d phi / d p
+      return T(0);
+    }
+    const int a = j - n;
+    const T arm = c.sys_par[2], Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
+    const T ct = c.sys_par[6];
+    if (i == 9) return (a == 1) ? dt * arm / Ix : (a == 3) ? -dt * arm / Ix : T(0);
+    if (i == 10) return (a == 2) ? dt * arm / Iy : (a == 0) ? -dt * arm / Iy : T(0);
+    if (i == 11) return ((a & 1) == 0) ? dt * ct / Iz : -dt * ct / Iz;
+    return T(0);
+  }
+};
+
+}  // namespace i2lqr

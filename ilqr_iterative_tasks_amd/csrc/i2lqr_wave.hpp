@@ -1,0 +1,692 @@
+// Wave-cooperative iLQR kernels for gfx950 (MI355X): LANES lanes of one 64-wide wavefront own one
+// iLQR problem (LANES = 64: one problem per wavefront).  The whole problem state — trajectory,
+// gains, per-step transcendental cache, the small A/B/Q blocks of the Riccati step — lives in
+// that wave's slice of LDS; HBM is touched once on entry and once on exit with time-contiguous,
+// coalesced records.  No MFMA: every contraction is n <= 12 wide.
+//
+// Workgroup = one wavefront (64 threads): there is no s_barrier anywhere; lanes of a wave
+// synchronise their LDS traffic with wave_sync() (compiler-level fence, the hardware executes a
+// wave's DS instructions in order).
+//
+// Reference being replaced (paths relative to the reference root):
+//   ilqr()          control/iterative_ilqr.py:7-85
+//   backward_pass() control/iterative_ilqr.py:88-130  (+ control/ilqr_helper.py:9-150)
+//   forward_pass()  control/iterative_ilqr.py:133-160
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "i2lqr_systems.hpp"
+
+namespace i2lqr {
+
+enum : int { FLAG_HAS_Q = 1, FLAG_HAS_R = 2 };
+
+// Device copy of i2lqr_config, typed and sized for one system; passed by value as a kernel
+// argument (kernarg segment: uniform, served by the scalar cache).
+template <class T, int n, int m> struct DevCfg {
+  int N, max_iter, flags, pad_;
+  T dt, eps, lamb_factor, max_lamb;
+  T ctrl_q1, ctrl_q2, obs_q1, obs_q2, safety_margin;
+  T u_max[m];
+  T xtarget[n];
+  T Q[n * n], Qt[n * n], R[m * m];
+  T sys_par[8];
+};
+
+template <class T> struct IterArgs {
+  int64_t B;
+  int n_iters;    // iterations to run (iterate) / max iterations (solve)
+  int early_exit; // 1: reference exits (solve); 0: fixed count (iterate)
+  T* X;           // [B][n][N+1] in/out (X[:, :, 0] = x0 on entry)
+  T* U;           // [B][m][N]   in/out
+  const T* x_term; // [B][n]
+  T* lamb;        // [B] in/out
+  const T* obs;   // [B][6] or null
+  T* cost;        // [B] out
+  T* K;           // [B][m][n][N] out or null
+  T* k;           // [B][m][N] out or null
+  int32_t* iters;  // [B] out or null
+  int32_t* status; // [B] out or null
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a[i] for a lane-dependent i without sending the array to scratch
+template <class T, int L> __device__ __forceinline__ T pick(const T (&a)[L], int i) {
+  T v = a[0];
+#pragma unroll
+  for (int q = 1; q < L; q++) v = (i == q) ? a[q] : v;
+  return v;
+}
+
+template <class T> __device__ __forceinline__ T clip(T v, T lo, T hi) {
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// LDS layout of one problem, in words of T.  Trajectories and gains are TIME-major in LDS
+// (X[t][n], U[t][m], Kk[t][m][n+1] with k as the last column) so one horizon step touches one
+// contiguous span; the HBM records are component-major with time contiguous (the reference's
+// NumPy layout) and are transposed on the way in/out.
+template <class Sys> struct Layout {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
+  int N;
+  int X0, X1, U0, U1, Kk, trg, lu, luu, ob, Va, F, T1, H, g, total;
+  __host__ __device__ explicit Layout(int N_) : N(N_) {
+    int o = 0;
+    X0 = o; o += n * (N + 1);
+    X1 = o; o += n * (N + 1);
+    U0 = o; o += m * N;
+    U1 = o; o += m * N;
+    Kk = o; o += m * (n + 1) * N;
+    trg = o; o += NT * N;
+    lu = o; o += m * N;
+    luu = o; o += m * N;
+    ob = o; o += 5 * (N + 1);
+    Va = o; o += n * (n + 1);
+    F = o; o += n * W;
+    T1 = o; o += W * (n + 1);
+    H = o; o += W * W;
+    g = o; o += W;
+    total = (o + 1) & ~1;  // keep every problem slice 16-byte aligned for fp64
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The per-problem worker.  All LANES lanes of a problem execute every method together.
+// ---------------------------------------------------------------------------------------------
+template <class T, class Sys, int LANES> struct Worker {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
+  using Cfg = DevCfg<T, n, m>;
+  const Cfg& c;
+  const Layout<Sys> L;
+  T* const S;   // this problem's LDS slice
+  const int sl; // lane index inside the problem's lane group
+  const int N;
+
+  __device__ Worker(const Cfg& c_, T* smem, int lane)
+      : c(c_), L(c_.N), S(smem + (lane / LANES) * Layout<Sys>(c_.N).total), sl(lane % LANES),
+        N(c_.N) {}
+
+  // d^T M d with NumPy's association (d.T @ M) @ d: control/iterative_ilqr.py:43-48, :151-159
+  template <int D> __device__ __forceinline__ T quad_form(const T* M, const T (&d)[D]) const {
+    T acc = T(0);
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+      T col = T(0);
+#pragma unroll
+      for (int i = 0; i < D; i++) col += d[i] * M[i * D + j];
+      acc += col * d[j];
+    }
+    return acc;
+  }
+
+  __device__ __forceinline__ T stage_cost(const T (&x)[n], const T* ref, const T (&u)[m]) const {
+    T l = T(0);
+    if (c.flags & FLAG_HAS_Q) {
+      T d[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) d[i] = x[i] - ref[i];
+      l += quad_form<n>(c.Q, d);
+    }
+    if (c.flags & FLAG_HAS_R) l += quad_form<m>(c.R, u);
+    return l;
+  }
+
+  __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
+    T d[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) d[i] = x[i] - xT[i];
+    return quad_form<n>(c.Qt, d);
+  }
+
+  // -- HBM <-> LDS ---------------------------------------------------------------------------
+  // record [comp][len] (time contiguous) <-> LDS [t][comp]; global side coalesced
+  __device__ __forceinline__ void load_rec(const T* g, int ldsoff, int comps, int len) const {
+    for (int e = sl; e < comps * len; e += LANES) {
+      const int cc = e / len, t = e - cc * len;
+      S[ldsoff + t * comps + cc] = g[e];
+    }
+  }
+  __device__ __forceinline__ void store_rec(T* g, int ldsoff, int comps, int len) const {
+    for (int e = sl; e < comps * len; e += LANES) {
+      const int cc = e / len, t = e - cc * len;
+      g[e] = S[ldsoff + t * comps + cc];
+    }
+  }
+  // gains: global K[m][n][N], k[m][N]  <->  LDS Kk[t][m][n+1]
+  __device__ __forceinline__ void store_gains(T* gK, T* gk) const {
+    for (int e = sl; e < m * n * N; e += LANES) {
+      const int a = e / (n * N), r = e - a * (n * N), j = r / N, t = r - j * N;
+      gK[e] = S[L.Kk + (t * m + a) * (n + 1) + j];
+    }
+    for (int e = sl; e < m * N; e += LANES) {
+      const int a = e / N, t = e - a * N;
+      gk[e] = S[L.Kk + (t * m + a) * (n + 1) + n];
+    }
+  }
+  __device__ __forceinline__ void load_gains(const T* gK, const T* gk) const {
+    for (int e = sl; e < m * n * N; e += LANES) {
+      const int a = e / (n * N), r = e - a * (n * N), j = r / N, t = r - j * N;
+      S[L.Kk + (t * m + a) * (n + 1) + j] = gK[e];
+    }
+    for (int e = sl; e < m * N; e += LANES) {
+      const int a = e / N, t = e - a * N;
+      S[L.Kk + (t * m + a) * (n + 1) + n] = gk[e];
+    }
+  }
+
+  // -- nominal rollout + cost: control/iterative_ilqr.py:32-48 -------------------------------
+  // Every lane of the problem runs the (serial) recursion redundantly; lanes < n / < m publish.
+  __device__ __forceinline__ T rollout(int Xo, int Uo, const T (&xT)[n]) const {
+    T x[n], u[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[Xo + i];
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = clip(S[Uo + t * m + a], -c.u_max[a], c.u_max[a]);
+      if (sl < m) S[Uo + t * m + sl] = pick<T, m>(u, sl);
+      Sys::step(c, x, u, xn);
+      if (sl < n) S[Xo + (t + 1) * n + sl] = pick<T, n>(xn, sl);
+      cost = cost + stage_cost(x, c.xtarget, u);
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    cost = cost + terminal_cost(x, xT);
+    wave_sync();
+    return cost;
+  }
+
+  // -- per-step caches, parallel over t: trig of x_{t+1}, input barrier of u_t, obstacle barrier
+  //    of x_t (t = 0..N; index N is the terminal term of get_cost_final) -----------------------
+  __device__ __forceinline__ void prep(int Xo, int Uo, const T (&ob)[6]) const {
+    for (int t = sl; t <= N; t += LANES) {
+      if (t < N) {
+        T xe[n], tr[NT];
+#pragma unroll
+        for (int i = 0; i < n; i++) xe[i] = S[Xo + (t + 1) * n + i];
+        Sys::trig(xe, tr);
+#pragma unroll
+        for (int q = 0; q < NT; q++) S[L.trg + t * NT + q] = tr[q];
+        // add_control_constraint(): control/ilqr_helper.py:83-103, one symmetric box per input
+        T u[m];
+#pragma unroll
+        for (int a = 0; a < m; a++) u[a] = S[Uo + t * m + a];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+          const T e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
+          const T e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+          T lu = T(0);
+          if (c.flags & FLAG_HAS_R) {
+#pragma unroll
+            for (int b = 0; b < m; b++) lu += T(2) * c.R[a * m + b] * u[b];
+          }
+          lu += c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo;
+          const T luu = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
+                        c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+          S[L.lu + t * m + a] = lu;
+          S[L.luu + t * m + a] = luu;
+        }
+      }
+      // obstacle barrier: control/ilqr_helper.py:32-51 (stage) / :121-147 (terminal, index N)
+      T o0 = T(0), o1 = T(0), o2 = T(0), o3 = T(0), o4 = T(0);
+      if (ob[5] >= T(0)) {
+        const T px = S[Xo + t * n + 0], py = S[Xo + t * n + 1];
+        const int opt = (int)ob[5];
+        T dz = px - ob[0], dy = py - ob[1];
+        if (opt == 1) dy = py - (ob[1] + T(t) * ob[4]);
+        if (opt == 2) dz = px - (ob[0] - T(t) * ob[4]);
+        const T pa = T(1) / (ob[2] * ob[2]), pb = T(1) / (ob[3] * ob[3]);
+        const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
+        const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
+        const T e = t_exp(c.obs_q2 * h);
+        const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+        o0 = c1 * hd0;
+        o1 = c1 * hd1;
+        o2 = c2 * (hd0 * hd0);
+        o3 = c2 * (hd0 * hd1);
+        o4 = c2 * (hd1 * hd1);
+      }
+      S[L.ob + t * 5 + 0] = o0;
+      S[L.ob + t * 5 + 1] = o1;
+      S[L.ob + t * 5 + 2] = o2;
+      S[L.ob + t * 5 + 3] = o3;
+      S[L.ob + t * 5 + 4] = o4;
+    }
+    wave_sync();
+  }
+
+  // Regularised inverse of Q_uu: control/iterative_ilqr.py:118-123.  m == 2 follows the
+  // reference's NON-symmetric eig (unit-norm eigenvectors, not orthogonalised) in closed form;
+  // m > 2 runs cyclic Jacobi on the symmetrised matrix (no reference counterpart).
+  __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
+                                              T (&inv)[m * m]) const {
+    if constexpr (m == 2) {
+      const T a = Quu[0], b = Quu[1], cc = Quu[2], d = Quu[3];
+      const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
+      T disc = hd * hd + b * cc;
+      disc = disc < T(0) ? T(0) : disc;
+      const T s = t_sqrt(disc);
+      T l1 = (mean >= T(0)) ? mean + s : mean - s;
+      T l2 = (l1 != T(0)) ? (a * d - b * cc) / l1 : T(0);
+      if (s == T(0)) { l1 = mean; l2 = mean; }
+      const T w[2] = {l1, l2};
+      T V[4];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const T lo = w[1 - e];
+        const T c0x = a - lo, c0y = cc, c1x = b, c1y = d - lo;
+        const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
+        const bool first = n0 >= n1;
+        T vx = first ? c0x : c1x, vy = first ? c0y : c1y, nn = first ? n0 : n1;
+        if (nn == T(0)) { vx = (e == 0) ? T(1) : T(0); vy = (e == 0) ? T(0) : T(1); nn = T(1); }
+        const T r = T(1) / t_sqrt(nn);
+        V[0 * 2 + e] = vx * r;
+        V[1 * 2 + e] = vy * r;
+      }
+      T wr[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) wr[e] = T(1) / ((w[e] < T(0) ? T(0) : w[e]) + lamb);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          inv[i * 2 + j] = V[i * 2 + 0] * wr[0] * V[j * 2 + 0] + V[i * 2 + 1] * wr[1] * V[j * 2 + 1];
+    } else {
+      T Sm[m * m], V[m * m];
+#pragma unroll
+      for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+          Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
+          V[i * m + j] = (i == j) ? T(1) : T(0);
+        }
+      for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+        for (int p = 0; p < m - 1; p++)
+#pragma unroll
+          for (int q = p + 1; q < m; q++) {
+            const T apq = Sm[p * m + q];
+            const T app = Sm[p * m + p], aqq = Sm[q * m + q];
+            // rotation angle; apq == 0 gives the identity rotation
+            const T tau = (aqq - app) / (T(2) * apq);
+            T tt = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
+            tt = (apq == T(0)) ? T(0) : tt;
+            const T cs = T(1) / t_sqrt(T(1) + tt * tt), sn = tt * cs;
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T skp = Sm[k * m + p], skq = Sm[k * m + q];
+              Sm[k * m + p] = cs * skp - sn * skq;
+              Sm[k * m + q] = sn * skp + cs * skq;
+            }
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T spk = Sm[p * m + k], sqk = Sm[q * m + k];
+              Sm[p * m + k] = cs * spk - sn * sqk;
+              Sm[q * m + k] = sn * spk + cs * sqk;
+            }
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T vkp = V[k * m + p], vkq = V[k * m + q];
+              V[k * m + p] = cs * vkp - sn * vkq;
+              V[k * m + q] = sn * vkp + cs * vkq;
+            }
+          }
+      }
+      T wr[m];
+#pragma unroll
+      for (int e = 0; e < m; e++) {
+        const T we = Sm[e * m + e];
+        wr[e] = T(1) / ((we < T(0) ? T(0) : we) + lamb);
+      }
+#pragma unroll
+      for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+          T acc = T(0);
+#pragma unroll
+          for (int e = 0; e < m; e++) acc += V[i * m + e] * wr[e] * V[j * m + e];
+          inv[i * m + j] = acc;
+        }
+    }
+  }
+
+  // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
+  // Needs prep() on the same trajectory.  Leaves the gains in LDS (Kk).
+  __device__ __forceinline__ void backward(int Xo, int Uo, const T (&xT)[n], T lamb) const {
+    // constant pattern of F = [A | B]; the state-dependent entries are refreshed every step
+    for (int e = sl; e < n * W; e += LANES) S[L.F + e] = Sys::jac_const(c, e / W, e % W);
+    // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150
+    for (int e = sl; e < n * (n + 1); e += LANES) {
+      const int i = e / (n + 1), j = e - i * (n + 1);
+      T v;
+      if (j < n) {
+        v = T(2) * c.Qt[i * n + j];
+        if (i < 2 && j < 2) v += S[L.ob + N * 5 + 2 + i + j];
+      } else {
+        v = T(0);
+#pragma unroll
+        for (int r = 0; r < n; r++) v += T(2) * c.Qt[i * n + r] * (S[Xo + N * n + r] - xT[r]);
+        if (i < 2) v += S[L.ob + N * 5 + i];
+      }
+      S[L.Va + e] = v;
+    }
+    wave_sync();
+
+    // lanes that own a varying Jacobian entry
+    constexpr int VPASS = (Sys::NVAR + LANES - 1) / LANES;
+    int var_at[VPASS];
+#pragma unroll
+    for (int r = 0; r < VPASS; r++) var_at[r] = Sys::var_idx(sl + r * LANES);
+
+    for (int t = N - 1; t >= 0; t--) {
+      // P0: refresh F at (x_{t+1}, u_t): control/iterative_ilqr.py:92-99
+      {
+        T xe[n], u[m], tr[NT], jv[Sys::NVAR];
+#pragma unroll
+        for (int i = 0; i < n; i++) xe[i] = S[Xo + (t + 1) * n + i];
+#pragma unroll
+        for (int a = 0; a < m; a++) u[a] = S[Uo + t * m + a];
+#pragma unroll
+        for (int q = 0; q < NT; q++) tr[q] = S[L.trg + t * NT + q];
+        Sys::jac_var(c, xe, u, tr, jv);
+#pragma unroll
+        for (int r = 0; r < VPASS; r++) {
+          const int v = sl + r * LANES;
+          if (v < Sys::NVAR) S[L.F + var_at[r]] = pick<T, Sys::NVAR>(jv, v);
+        }
+      }
+      wave_sync();
+      // P1: T1 = F^T [Vxx | Vx]   ((n+m) x (n+1)); f.T @ V of control/iterative_ilqr.py:112-116
+      for (int e = sl; e < W * (n + 1); e += LANES) {
+        const int a = e / (n + 1), j = e - a * (n + 1);
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < n; i++)
+          acc = t_fma(S[L.F + i * W + a], S[L.Va + i * (n + 1) + j], acc);
+        S[L.T1 + e] = acc;
+      }
+      wave_sync();
+      // P2: H = L + T1[:, :n] F  ((n+m) x (n+m): Qxx | . ; Qux | Quu),  g = l + T1[:, n]
+      for (int e = sl; e < W * W; e += LANES) {
+        const int a = e / W, b = e - a * W;
+        if (a < n && b >= n) continue;  // Qxu is never used by the reference
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < n; i++)
+          acc = t_fma(S[L.T1 + a * (n + 1) + i], S[L.F + i * W + b], acc);
+        T l = T(0);
+        if (a < n) {  // l_xx = 2Q (+ obstacle block): control/ilqr_helper.py:30, :51
+          if (c.flags & FLAG_HAS_Q) l = T(2) * c.Q[a * n + b];
+          if (a < 2 && b < 2) l += S[L.ob + t * 5 + 2 + a + b];
+        } else if (b >= n) {  // l_uu = 2R + barrier: control/ilqr_helper.py:28
+          if (c.flags & FLAG_HAS_R) l = T(2) * c.R[(a - n) * m + (b - n)];
+          if (a == b) l += S[L.luu + t * m + (a - n)];
+        }
+        S[L.H + e] = l + acc;
+      }
+      for (int a = sl; a < W; a += LANES) {
+        T l;
+        if (a < n) {  // l_x = 2Q dX[:, t] (+ obstacle): control/ilqr_helper.py:29, :50
+          l = T(0);
+          if (c.flags & FLAG_HAS_Q) {
+#pragma unroll
+            for (int r = 0; r < n; r++)
+              l += T(2) * c.Q[a * n + r] * (S[Xo + t * n + r] - c.xtarget[r]);
+          }
+          if (a < 2) l += S[L.ob + t * 5 + a];
+        } else {
+          l = S[L.lu + t * m + (a - n)];
+        }
+        S[L.g + a] = l + S[L.T1 + a * (n + 1) + n];
+      }
+      wave_sync();
+      // P3: gains [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
+      T Quu[m * m], Qinv[m * m];
+#pragma unroll
+      for (int a = 0; a < m; a++)
+#pragma unroll
+        for (int b = 0; b < m; b++) Quu[a * m + b] = S[L.H + (n + a) * W + (n + b)];
+      quu_inverse(Quu, lamb, Qinv);
+      for (int e = sl; e < m * (n + 1); e += LANES) {
+        const int a = e / (n + 1), j = e - a * (n + 1);
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) {
+          const T gq = (j < n) ? S[L.H + (n + b) * W + j] : S[L.g + n + b];
+          acc = t_fma(pick<T, m * m>(Qinv, a * m + b), gq, acc);
+        }
+        S[L.Kk + t * m * (n + 1) + e] = -acc;
+      }
+      wave_sync();
+      // P4: value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
+      //     [Vxx | Vx] = [Qxx | Qx] - (K^T Quu) [K | k]
+      for (int e = sl; e < n * (n + 1); e += LANES) {
+        const int i = e / (n + 1), j = e - i * (n + 1);
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) {
+          T ktq = T(0);
+#pragma unroll
+          for (int a = 0; a < m; a++)
+            ktq = t_fma(S[L.Kk + (t * m + a) * (n + 1) + i], Quu[a * m + b], ktq);
+          acc = t_fma(ktq, S[L.Kk + (t * m + b) * (n + 1) + j], acc);
+        }
+        const T qv = (j < n) ? S[L.H + i * W + j] : S[L.g + i];
+        S[L.Va + e] = qv - acc;
+      }
+      wave_sync();
+    }
+  }
+
+  // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
+  // (Xo, Uo) nominal -> (Xn, Un) candidate; returns cost_new (stage cost measured to x_terminal).
+  __device__ __forceinline__ T forward(int Xo, int Uo, int Xn, int Un, const T (&xT)[n]) const {
+    T x[n], u[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[Xo + i];
+    if (sl < n) S[Xn + sl] = pick<T, n>(x, sl);
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        const T* kk = S + L.Kk + (t * m + a) * (n + 1);
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < n; j++) acc = t_fma(kk[j], x[j] - S[Xo + t * n + j], acc);
+        u[a] = clip(S[Uo + t * m + a] + kk[n] + acc, -c.u_max[a], c.u_max[a]);
+      }
+      if (sl < m) S[Un + t * m + sl] = pick<T, m>(u, sl);
+      Sys::step(c, x, u, xn);
+      if (sl < n) S[Xn + (t + 1) * n + sl] = pick<T, n>(xn, sl);
+      cost = cost + stage_cost(x, xT, u);
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    cost = cost + terminal_cost(x, xT);
+    wave_sync();
+    return cost;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Kernels.  Grid: ceil(B / (64 / LANES)) workgroups of one wavefront each.
+// ---------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ bool t_isfinite(T v) {
+  return (v - v) == T(0);
+}
+
+template <class T, class Sys, int LANES>
+__global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> c,
+                                                const IterArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
+  if (prob >= a.B) return;
+  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  const int N = c.N;
+  const auto& L = w.L;
+  T* S = w.S;
+
+  // entry: x0, U, x_term, lamb, obs  (HBM -> LDS/registers, coalesced along the record)
+  const T* gX = a.X + prob * (int64_t)(n * (N + 1));
+  if (w.sl < n) S[L.X0 + w.sl] = gX[w.sl * (N + 1)];
+  w.load_rec(a.U + prob * (int64_t)(m * N), L.U0, m, N);
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[prob];
+  wave_sync();
+
+  int cur = 0;  // which of the two trajectory buffers holds the nominal
+  int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
+  T cost_ret = T(0);
+  for (it = 0; it < a.n_iters;) {
+    const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
+    const int Xn = cur ? L.X0 : L.X1, Un = cur ? L.U0 : L.U1;
+    const T cost = w.rollout(Xo, Uo, xT);
+    w.prep(Xo, Uo, ob);
+    w.backward(Xo, Uo, xT, lamb);
+    const T cost_new = w.forward(Xo, Uo, Xn, Un, xT);
+    it++;
+    cost_ret = cost;
+    // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
+    if (cost_new < cost) {
+      cur ^= 1;
+      lamb /= c.lamb_factor;
+      cost_ret = cost_new;
+      if (t_abs((cost_new - cost) / cost) < c.eps) {
+        if (a.early_exit) { status = 1; break; }
+        if (status == 0) status = 1;
+      }
+    } else {
+      lamb *= c.lamb_factor;
+      if (lamb > c.max_lamb) {
+        if (a.early_exit) { status = 3; break; }
+        if (status == 0) status = 3;
+      }
+    }
+  }
+  if (!t_isfinite(cost_ret)) status = 4;
+
+  // exit: X, U, gains, scalars (LDS -> HBM)
+  const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
+  w.store_rec(a.X + prob * (int64_t)(n * (N + 1)), Xo, n, N + 1);
+  w.store_rec(a.U + prob * (int64_t)(m * N), Uo, m, N);
+  if (a.K) w.store_gains(a.K + prob * (int64_t)(m * n * N), a.k + prob * (int64_t)(m * N));
+  if (w.sl == 0) {
+    a.lamb[prob] = lamb;
+    a.cost[prob] = cost_ret;
+    if (a.iters) a.iters[prob] = it;
+    if (a.status) a.status[prob] = status;
+  }
+}
+
+// rollout only: control/iterative_ilqr.py:32-48
+template <class T, class Sys, int LANES>
+__global__ __launch_bounds__(64) void k_rollout(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                T* X, T* U, const T* x_term, T* cost) {
+  constexpr int n = Sys::n, m = Sys::m;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
+  if (prob >= B) return;
+  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  const int N = c.N;
+  const T* gX = X + prob * (int64_t)(n * (N + 1));
+  if (w.sl < n) w.S[w.L.X0 + w.sl] = gX[w.sl * (N + 1)];
+  w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  T xT[n];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
+  wave_sync();
+  const T cst = w.rollout(w.L.X0, w.L.U0, xT);
+  w.store_rec(X + prob * (int64_t)(n * (N + 1)), w.L.X0, n, N + 1);
+  w.store_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  if (w.sl == 0) cost[prob] = cst;
+}
+
+// backward only: control/iterative_ilqr.py:88-130
+template <class T, class Sys, int LANES>
+__global__ __launch_bounds__(64) void k_backward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                 const T* X, const T* U, const T* x_term,
+                                                 const T* lamb, const T* obs, T* K, T* k) {
+  constexpr int n = Sys::n, m = Sys::m;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
+  if (prob >= B) return;
+  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  const int N = c.N;
+  w.load_rec(X + prob * (int64_t)(n * (N + 1)), w.L.X0, n, N + 1);
+  w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = obs ? obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  wave_sync();
+  w.prep(w.L.X0, w.L.U0, ob);
+  w.backward(w.L.X0, w.L.U0, xT, lamb[prob]);
+  w.store_gains(K + prob * (int64_t)(m * n * N), k + prob * (int64_t)(m * N));
+}
+
+// forward only: control/iterative_ilqr.py:133-160
+template <class T, class Sys, int LANES>
+__global__ __launch_bounds__(64) void k_forward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                const T* X, const T* U, const T* x_term,
+                                                const T* K, const T* k, T* Xn, T* Un,
+                                                T* cost_new) {
+  constexpr int n = Sys::n, m = Sys::m;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
+  if (prob >= B) return;
+  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  const int N = c.N;
+  w.load_rec(X + prob * (int64_t)(n * (N + 1)), w.L.X0, n, N + 1);
+  w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  w.load_gains(K + prob * (int64_t)(m * n * N), k + prob * (int64_t)(m * N));
+  T xT[n];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
+  wave_sync();
+  const T cst = w.forward(w.L.X0, w.L.U0, w.L.X1, w.L.U1, xT);
+  w.store_rec(Xn + prob * (int64_t)(n * (N + 1)), w.L.X1, n, N + 1);
+  w.store_rec(Un + prob * (int64_t)(m * N), w.L.U1, m, N);
+  if (w.sl == 0) cost_new[prob] = cst;
+}
+
+// relaxed terminal cost: utils/base.py:427-437.  One lane per candidate.
+template <class T>
+__global__ void k_relax_cost(int64_t B, int n, int N, const T* X, const T* x_term,
+                             const int32_t* qfun, int outer_iter, int max_relax_iter,
+                             T* cost_it) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* Xb = X + b * (int64_t)(n * (N + 1));
+  double ss = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double d = (double)Xb[i * (N + 1) + N] - (double)x_term[b * n + i];
+    ss += d * d;
+  }
+  const double nrm = sqrt(ss);
+  double scale = 1.0;
+  for (int q = 0; q < outer_iter; q++) scale *= 10.0;
+  double out = INFINITY;
+  for (int i = 1; i <= max_relax_iter; i++) {
+    if (nrm <= 80.0 * i / scale) { out = (double)qfun[b] + N + 100 * i; break; }
+    if (nrm > 80.0 * max_relax_iter / scale) break;
+  }
+  cost_it[b] = (T)out;
+}
+
+}  // namespace i2lqr

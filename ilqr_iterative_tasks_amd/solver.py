@@ -1,0 +1,189 @@
+"""BatchedILQR — Python host of the C-ABI (include/i2lqr.h) over PyTorch-ROCm device tensors.
+
+PyTorch is plumbing only: it owns the HBM allocations and the HIP stream; every arithmetic step
+runs in the hand-written HIP kernels of libi2lqr_hip.so.  There is no CPU path: constructing a
+solver without a visible HIP device, or without the built extension, raises.
+
+Tensor layout (problem-major, time contiguous — the reference's NumPy layout with a leading batch
+axis; control/iterative_ilqr.py:109-110, utils/base.py:405-409):
+    X[B, n, N+1]   U[B, m, N]   K[B, m, n, N]   k[B, m, N]   x_term[B, n]   lamb[B]   obs[B, 6]
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import I2lqrConfig, OBS_WORDS
+
+
+class I2lqrError(RuntimeError):
+    """Non-zero return code of the C-ABI.  A RuntimeError, so the reference's
+    `try: calc_input() except RuntimeError` (utils/base.py:146-155) semantics still hold."""
+
+
+class BatchedILQR:
+    def __init__(self, cfg: I2lqrConfig, device: str | torch.device = "cuda:0"):
+        self._handle = None  # set first so __del__ is safe if loading fails
+        self.lib = _abi.load_library()
+        if not torch.cuda.is_available():
+            raise I2lqrError("no HIP device visible: BatchedILQR has no CPU fallback")
+        self.device = torch.device(device)
+        self.cfg = cfg.copy()
+        self.n, self.m, self.N = cfg.n, cfg.m, cfg.N
+        self.dtype = torch.float64 if cfg.dtype == _abi.F64 else torch.float32
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_create(C.byref(self.cfg), C.byref(handle)))
+        self._handle = handle
+        self._argmin_ws = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise I2lqrError(f"i2lqr error {rc}: {self.lib.i2lqr_last_error().decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None:
+            self.lib.i2lqr_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t: torch.Tensor | None, shape, dtype=None, name="tensor") -> C.c_void_p:
+        if t is None:
+            return C.c_void_p(None)
+        dtype = self.dtype if dtype is None else dtype
+        if t.device != self.device and not (t.device.type == self.device.type and
+                                            (t.device.index or 0) == (self.device.index or 0)):
+            raise ValueError(f"{name}: expected device {self.device}, got {t.device}")
+        if t.dtype != dtype:
+            raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: must be contiguous")
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, *shape, dtype=None) -> torch.Tensor:
+        return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,
+                           device=self.device)
+
+    def alloc(self, B: int, want_gains: bool = True) -> dict:
+        """Zero-initialised buffer set for B problems (U = 0, lamb = 1: utils/base.py:393, :405)."""
+        n, m, N = self.n, self.m, self.N
+        z = lambda *s, dtype=None: torch.zeros(*s, dtype=self.dtype if dtype is None else dtype,
+                                               device=self.device)
+        buf = dict(X=z(B, n, N + 1), U=z(B, m, N), x_term=z(B, n), lamb=z(B) + 1, cost=z(B),
+                   iters=z(B, dtype=torch.int32), status=z(B, dtype=torch.int32), obs=None)
+        buf["K"] = z(B, m, n, N) if want_gains else None
+        buf["k"] = z(B, m, N) if want_gains else None
+        return buf
+
+    # -- the path ---------------------------------------------------------------------------
+    def rollout(self, X, U, x_term, cost=None):
+        """control/iterative_ilqr.py:32-48.  X[:, :, 0] = x0; U is clipped in place."""
+        B, n, m, N = X.shape[0], self.n, self.m, self.N
+        cost = self.empty(B) if cost is None else cost
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_rollout(
+                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
+                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
+                self._ptr(cost, (B,), name="cost"), self._stream()))
+        return cost
+
+    def backward(self, X, U, x_term, lamb, obs=None, K=None, k=None):
+        """control/iterative_ilqr.py:88-130.  Returns (k[B,m,N], K[B,m,n,N])."""
+        B, n, m, N = X.shape[0], self.n, self.m, self.N
+        K = self.empty(B, m, n, N) if K is None else K
+        k = self.empty(B, m, N) if k is None else k
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_backward(
+                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
+                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
+                self._ptr(lamb, (B,), name="lamb"), self._ptr(obs, (B, OBS_WORDS), name="obs"),
+                self._ptr(K, (B, m, n, N), name="K"), self._ptr(k, (B, m, N), name="k"),
+                self._stream()))
+        return k, K
+
+    def forward(self, X, U, x_term, K, k, X_new=None, U_new=None, cost_new=None):
+        """control/iterative_ilqr.py:133-160.  Returns (X_new, U_new, cost_new)."""
+        B, n, m, N = X.shape[0], self.n, self.m, self.N
+        X_new = self.empty(B, n, N + 1) if X_new is None else X_new
+        U_new = self.empty(B, m, N) if U_new is None else U_new
+        cost_new = self.empty(B) if cost_new is None else cost_new
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_forward(
+                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
+                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
+                self._ptr(K, (B, m, n, N), name="K"), self._ptr(k, (B, m, N), name="k"),
+                self._ptr(X_new, (B, n, N + 1), name="X_new"),
+                self._ptr(U_new, (B, m, N), name="U_new"),
+                self._ptr(cost_new, (B,), name="cost_new"), self._stream()))
+        return X_new, U_new, cost_new
+
+    def _iter_args(self, buf, B):
+        n, m, N = self.n, self.m, self.N
+        return (self._ptr(buf["X"], (B, n, N + 1), name="X"),
+                self._ptr(buf["U"], (B, m, N), name="U"),
+                self._ptr(buf["x_term"], (B, n), name="x_term"),
+                self._ptr(buf["lamb"], (B,), name="lamb"),
+                self._ptr(buf.get("obs"), (B, OBS_WORDS), name="obs"),
+                self._ptr(buf["cost"], (B,), name="cost"),
+                self._ptr(buf.get("K"), (B, m, n, N), name="K"),
+                self._ptr(buf.get("k"), (B, m, N), name="k"),
+                self._ptr(buf.get("iters"), (B,), torch.int32, name="iters"),
+                self._ptr(buf.get("status"), (B,), torch.int32, name="status"))
+
+    def iterate(self, buf: dict, n_iters: int) -> dict:
+        """`n_iters` fused iLQR iterations per problem without early exits (the throughput unit);
+        in place on buf['X'], buf['U'], buf['lamb'].  control/iterative_ilqr.py:29-84."""
+        B = buf["X"].shape[0]
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_iterate(self._handle, B, int(n_iters),
+                                               *self._iter_args(buf, B), self._stream()))
+        return buf
+
+    def solve(self, buf: dict) -> dict:
+        """ilqr() to termination for every problem (control/iterative_ilqr.py:7-85), in place."""
+        B = buf["X"].shape[0]
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_solve(self._handle, B, *self._iter_args(buf, B),
+                                             self._stream()))
+        return buf
+
+    def relax_cost(self, X, x_term, qfun, outer_iter: int, max_relax_iter: int = 55,
+                   cost_it=None):
+        """utils/base.py:427-437 for every candidate."""
+        B, n, N = X.shape[0], self.n, self.N
+        cost_it = self.empty(B) if cost_it is None else cost_it
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_relax_cost(
+                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
+                self._ptr(x_term, (B, n), name="x_term"),
+                self._ptr(qfun, (B,), torch.int32, name="qfun"), int(outer_iter),
+                int(max_relax_iter), self._ptr(cost_it, (B,), name="cost_it"), self._stream()))
+        return cost_it
+
+    def argmin(self, cost_it):
+        """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1])."""
+        B = cost_it.shape[0]
+        if self._argmin_ws is None:
+            self._argmin_ws = torch.empty(int(self.lib.i2lqr_argmin_workspace_bytes(B)),
+                                          dtype=torch.uint8, device=self.device)
+        idx = self.empty(1, dtype=torch.int64)
+        val = self.empty(1)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_argmin(
+                self._handle, B, self._ptr(cost_it, (B,), name="cost_it"),
+                C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()),
+                C.c_void_p(self._argmin_ws.data_ptr()), self._stream()))
+        return idx, val

@@ -1,0 +1,193 @@
+/*
+ * i2lqr.h — C-ABI of the MI355X-native batched iLQR solver (libi2lqr_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of HybridRobotics/ilqr-iterative-tasks:
+ * the reference has no FFI layer, its seam is the plain Python call
+ *     uvar, xvar, lamb = ilqr(ilqr_param, num_horizon, xtarget, timestep, obstacle,
+ *                             system_param, x_terminal, dX, uvar, xvar, lamb)
+ * at iterative_ilqr/utils/base.py:414-426 inside iLqr.calc_input() (:371-479).  Every entry point
+ * below names the reference function (file:line, relative to the reference root) it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an int:
+ *    0 = ok, <0 = error (message via i2lqr_last_error(), thread-local).  Numerical outcomes
+ *    (converged / diverged / non-finite) are per-problem status words, never error codes.
+ *  - All data pointers are DEVICE pointers (HBM) owned by the caller; the library never allocates
+ *    user-visible memory.  `stream` is a hipStream_t passed as void*; launches are asynchronous.
+ *  - `real` below is double (cfg.dtype == I2LQR_F64) or float (I2LQR_F32); all buffers of one
+ *    handle use that one type.  The config struct itself is always double.
+ *  - Layout I2LQR_LAYOUT_PROBLEM_MAJOR (default): one problem's record is contiguous and inside
+ *    it TIME is the fastest axis, exactly as the reference's NumPy arrays
+ *    (xvar[n, N+1], uvar[m, N], K[m, n, N], k[m, N]; control/iterative_ilqr.py:109-110,
+ *    utils/base.py:405-409):
+ *        X[B][n][N+1]  U[B][m][N]  K[B][m][n][N]  k[B][m][N]  x_term[B][n]  obs[B][6]
+ *    Layout I2LQR_LAYOUT_BATCH_MINOR: the batch index is the fastest axis
+ *        X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  obs[6][B]
+ *    (one problem per lane; used by the throughput kernels).
+ *  - obs record = {x, y, width, height, spd, moving_option}; moving_option 0 = static,
+ *    1 = moving up (+y), 2 = moving left (-x) (utils/base.py:23-34, control/ilqr_helper.py:34-43);
+ *    moving_option < 0 disables the obstacle for that problem (the reference's `obstacle is None`).
+ *    A NULL obs pointer disables it for the whole batch.
+ */
+#ifndef I2LQR_H
+#define I2LQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2LQR_ABI_VERSION 1
+#define I2LQR_MAX_N 12
+#define I2LQR_MAX_M 4
+#define I2LQR_MAX_HORIZON 64
+#define I2LQR_OBS_WORDS 6
+
+/* cfg.dtype */
+enum { I2LQR_F64 = 0, I2LQR_F32 = 1 };
+/* cfg.layout */
+enum { I2LQR_LAYOUT_PROBLEM_MAJOR = 0, I2LQR_LAYOUT_BATCH_MINOR = 1 };
+/* cfg.system_id: the plant model (reference: systems/kinetic_bicycle.py:10-52 for BICYCLE4) */
+enum {
+  I2LQR_SYS_BICYCLE4 = 0, /* reference plant: [x,y,v,theta], [accel,delta]            n=4  m=2 */
+  I2LQR_SYS_BICYCLE6 = 1, /* build-defined: bicycle4 + actuator states [a,delta],
+                             inputs [jerk, steer rate]                                 n=6  m=2 */
+  I2LQR_SYS_QUAD12 = 2    /* build-defined: rigid-body quadrotor, explicit Euler       n=12 m=4 */
+};
+/* return codes */
+enum {
+  I2LQR_OK = 0,
+  I2LQR_ERR_INVALID = -1,     /* bad argument / config */
+  I2LQR_ERR_UNSUPPORTED = -2, /* shape / system / layout combination not built */
+  I2LQR_ERR_LAUNCH = -3,      /* HIP launch or runtime failure */
+  I2LQR_ERR_NODEVICE = -4     /* no HIP device visible */
+};
+/* per-problem status word written by i2lqr_iterate / i2lqr_solve */
+enum {
+  I2LQR_ST_RUNNING = 0,       /* fixed-count iterate finished without a termination event */
+  I2LQR_ST_CONVERGED = 1,     /* |dcost/cost| < eps on an accepted step (iterative_ilqr.py:78-80) */
+  I2LQR_ST_MAX_ITER = 2,      /* max_ilqr_iter reached (iterative_ilqr.py:29) */
+  I2LQR_ST_LAMB_OVERFLOW = 3, /* lamb > max_lamb after a rejected step (iterative_ilqr.py:83-84) */
+  I2LQR_ST_NONFINITE = 4      /* returned cost is NaN/Inf */
+};
+
+/*
+ * Host-side POD configuration.  Mirrors the parameter bundles the reference reads on the path:
+ * iLqrParam (utils/base.py:242-302), KineticBicycleParam (utils/base.py:15-20) and the constants
+ * in utils/constants_kinetic_bicycle.py:1-6.  Matrices are row-major with leading dimension
+ * I2LQR_MAX_N (Q, Qt) / I2LQR_MAX_M (R); only the top-left n x n / m x m block is read.
+ */
+typedef struct i2lqr_config {
+  int32_t struct_size; /* = sizeof(i2lqr_config); guards against ABI drift */
+  int32_t n, m, N;     /* X_DIM, U_DIM, num_horizon */
+  int32_t dtype;       /* I2LQR_F64 | I2LQR_F32 */
+  int32_t layout;      /* I2LQR_LAYOUT_* */
+  int32_t system_id;   /* I2LQR_SYS_* */
+  int32_t max_iter;    /* iLqrParam.max_ilqr_iter (150) */
+  double dt;           /* timestep */
+  double eps;          /* iLqrParam.eps (1e-2) */
+  double lamb_factor;  /* iLqrParam.lamb_factor (10) */
+  double max_lamb;     /* iLqrParam.max_lamb (1000) */
+  double ctrl_q1, ctrl_q2; /* iLqrParam.tuning_ctrl_q1/q2 (1, 1) */
+  double obs_q1, obs_q2;   /* iLqrParam.tuning_obs_q1/q2 (2.74, 2.74) */
+  double safety_margin;    /* iLqrParam.safety_margin (0) */
+  double u_max[I2LQR_MAX_M]; /* symmetric input box; bicycle4: {a_max, round(delta_max, 2)}
+                                (control/iterative_ilqr.py:33-40, control/ilqr_helper.py:90-100) */
+  double xtarget[I2LQR_MAX_N]; /* tracking target of the stage cost (utils/base.py:374: zeros) */
+  double Q[I2LQR_MAX_N * I2LQR_MAX_N];  /* iLqrParam.matrix_Q */
+  double Qt[I2LQR_MAX_N * I2LQR_MAX_N]; /* iLqrParam.matrix_Qterminal */
+  double R[I2LQR_MAX_M * I2LQR_MAX_M];  /* iLqrParam.matrix_R */
+  double sys_par[8]; /* plant constants; QUAD12: {mass, g, arm, Ix, Iy, Iz, ctau, 0}; else unused */
+} i2lqr_config;
+
+typedef struct i2lqr_handle i2lqr_handle;
+
+/* ABI version of the loaded library (== I2LQR_ABI_VERSION of the header it was built from). */
+int i2lqr_version(void);
+
+/* Last error message of the calling thread ("" if none).  Never NULL. */
+const char* i2lqr_last_error(void);
+
+/* Fill *cfg with the reference defaults for `system_id` (utils/base.py:243-271, :16) at the
+ * system's native n, m and the given horizon; dtype f64, problem-major layout.  Host only. */
+int i2lqr_config_default(i2lqr_config* cfg, int system_id, int num_horizon);
+
+/* Validate the config, upload it to the device and size internal state.  No user-visible memory
+ * is allocated.  One handle per stream; a handle is not thread-safe. */
+int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
+int i2lqr_destroy(i2lqr_handle* h);
+
+/*
+ * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.
+ * In: X[.,:,0] = x0, U.  Out: U clipped in place, X[.,:,1..N], cost[B] (stage cost to xtarget +
+ * terminal cost to x_term; barrier terms are NOT part of the cost, as in the reference).
+ */
+int i2lqr_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
+                  void* stream);
+
+/*
+ * Backward pass: dynamics Jacobians, cost quadratisation, Riccati gain recursion — replaces
+ * backward_pass() control/iterative_ilqr.py:88-130 with its callees get_A_matrix/get_B_matrix
+ * (systems/kinetic_bicycle.py:30-52), get_cost_derivation (control/ilqr_helper.py:9-56),
+ * add_control_constraint (:83-103), repelling_cost_function (:59-64), get_cost_final (:106-150).
+ * In: X, U (a rolled-out nominal trajectory), x_term, lamb[B], obs (or NULL).
+ * Out: K[B][m][n][N], k[B][m][N].
+ */
+int i2lqr_backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                   const void* lamb, const void* obs, void* K, void* k, void* stream);
+
+/*
+ * Forward pass: closed-loop full-step rollout with input clipping and cost — replaces
+ * forward_pass() control/iterative_ilqr.py:133-160.
+ * Out: X_new, U_new, cost_new[B] (stage cost measured to x_term, as the reference does).
+ */
+int i2lqr_forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                  const void* K, const void* k, void* X_new, void* U_new, void* cost_new,
+                  void* stream);
+
+/*
+ * Fused fixed-count iteration — `n_iters` passes of the loop body control/iterative_ilqr.py:29-84
+ * (rollout+cost, backward, forward, accept/reject with the lamb schedule) per problem, WITHOUT the
+ * two early exits (:78-80, :83-84): every problem executes exactly n_iters iterations.  This is
+ * the unit of the throughput metric.  In/out: X (X[.,:,0] = x0 on entry), U, lamb.  Out: cost[B]
+ * (cost of the returned trajectory), K, k of the last iteration (may be NULL to skip the stores),
+ * iters[B] (int32, = n_iters), status[B] (int32).
+ */
+int i2lqr_iterate(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
+                  const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                  int32_t* iters, int32_t* status, void* stream);
+
+/*
+ * Solve to termination — replaces ilqr() control/iterative_ilqr.py:7-85 for B problems at once:
+ * up to cfg.max_iter iterations with both early exits.  Same buffers as i2lqr_iterate; iters[B]
+ * is the number of executed iterations, status[B] the exit reason.
+ */
+int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* lamb,
+                const void* obs, void* cost, void* K, void* k, int32_t* iters, int32_t* status,
+                void* stream);
+
+/*
+ * Relaxed terminal cost of each candidate — replaces utils/base.py:427-437:
+ * smallest i in [1, max_relax_iter] with ||x_N - x_term||_2 <= 80 i / 10^outer_iter gives
+ * cost_it = qfun + N + 100 i; a norm above 80 max_relax_iter / 10^outer_iter (or NaN) gives +inf.
+ * qfun[B] is int32 (cost-to-go in steps, utils/base.py:346); cost_it[B] is `real`.
+ */
+int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_term,
+                     const int32_t* qfun, int32_t outer_iter, int32_t max_relax_iter,
+                     void* cost_it, void* stream);
+
+/*
+ * Flat arg-min over cost_it[B] with first-index tie-break (the reduction the all-gather feeds;
+ * utils/base.py:462-465 applies it per lap, see the Python host for the list-of-lists form).
+ * Out (device): best_idx[1] (int64), best_cost[1] (`real`).  `workspace` must hold
+ * i2lqr_argmin_workspace_bytes(B) bytes.
+ */
+int64_t i2lqr_argmin_workspace_bytes(int64_t B);
+int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
+                 void* best_cost, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2LQR_H */

@@ -1,0 +1,52 @@
+"""Shared helpers of the test-suite (the only place, with bench.py's cpu_baseline leg and
+__graft_entry__.smoke(), that touches oracle/)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def rel_err(a, b, floor=1e-300):
+    """max |a-b| / max |b|  (array-level relative error: entries that are round-off noise next to
+    the array's scale, e.g. K[0,1,t] ~ 1e-17, are compared absolutely)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+def batch_rel_err(a, b, floor=1e-300):
+    """rel_err per leading-axis entry (scale = max |b| of that entry, at least `floor`), max over
+    the batch."""
+    a = np.asarray(a, dtype=np.float64).reshape(len(a), -1)
+    b = np.asarray(b, dtype=np.float64).reshape(len(b), -1)
+    if a.shape[0] == 0:
+        return 0.0
+    scale = np.maximum(np.abs(b).max(axis=1), floor)
+    return float((np.abs(a - b).max(axis=1) / scale).max())
+
+
+def to_dev(solver, arr, dtype=None):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(arr))
+    if t.dtype in (torch.float64, torch.float32):
+        t = t.to(solver.dtype if dtype is None else dtype)
+    return t.to(solver.device).contiguous()
+
+
+def dev_batch(solver, host: dict, want_gains=True):
+    """Host problem dict (workloads.make_batch / golden) -> device buffer dict for the solver."""
+    B = host["X"].shape[0]
+    buf = solver.alloc(B, want_gains=want_gains)
+    for key in ("X", "U", "x_term", "lamb"):
+        buf[key].copy_(to_dev(solver, host[key]))
+    if host.get("obs") is not None:
+        buf["obs"] = to_dev(solver, host["obs"])
+    return buf
+
+
+def problems_from_calls(g, N, n=4, m=2):
+    """Golden ilqr() call records (x0, x_term, lamb_in, obs) -> problem-major host batch."""
+    B = len(g["x0"])
+    X = np.zeros((B, n, N + 1))
+    X[:, :, 0] = g["x0"]
+    return dict(X=X, U=np.zeros((B, m, N)), x_term=np.array(g["x_term"], float),
+                lamb=np.array(g["lamb_in"], float), obs=np.array(g["obs"], float))
