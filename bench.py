@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — batched iLQR iterations/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic problems that is already resident
+in HBM: `iters` fused iLQR iterations per problem (i2lqr_iterate: rollout + cost, backward Riccati
+pass with dynamics Jacobians and cost quadratisation, forward rollout, accept/reject), the relaxed
+terminal cost of every candidate, the all-gather of those costs across ranks (N > 1; RCCL over
+xGMI) and the arg-min.  Default workload = BASELINE.json configs[1]: batch 1024 per GPU,
+kinematic bicycle n=6 m=2 N=20, fp64.  Weak scaling: every rank owns its own `batch` problems.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_iterate) against the HBM
+peak with the ALGORITHMIC bytes of SURVEY.md §8(d) (4968 B per iteration per problem at
+n=6, m=2, N=20, fp64); `cpu_baseline` times the CPU oracle (a port, oracle/ilqr_oracle.c) on the
+host cores of the same box on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2",
+                    help="config2 (default: B=1024 fp64), config3 (B=65536 fp32), config4, config5")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload's)")
+    ap.add_argument("--dtype", default=None, choices=[None, "f64", "f32"])
+    ap.add_argument("--iters", type=int, default=10, help="fused iLQR iterations per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+def make_step_buffers(solver, host, n_sets, torch):
+    """n_sets independent copies of the in/out state (X, U, lamb) + shared read-only inputs and
+    shared outputs, all resident in HBM before the timed region starts."""
+    dev, dt = solver.device, solver.dtype
+    B = host["X"].shape[0]
+    shared = dict(
+        x_term=torch.as_tensor(host["x_term"]).to(dev, dt).contiguous(),
+        obs=torch.as_tensor(host["obs"]).to(dev, dt).contiguous(),
+        cost=torch.zeros(B, dtype=dt, device=dev),
+        K=torch.zeros(B, solver.m, solver.n, solver.N, dtype=dt, device=dev),
+        k=torch.zeros(B, solver.m, solver.N, dtype=dt, device=dev),
+        iters=torch.zeros(B, dtype=torch.int32, device=dev),
+        status=torch.zeros(B, dtype=torch.int32, device=dev),
+    )
+    X0 = torch.as_tensor(host["X"]).to(dev, dt).contiguous()
+    U0 = torch.as_tensor(host["U"]).to(dev, dt).contiguous()
+    l0 = torch.as_tensor(host["lamb"]).to(dev, dt).contiguous()
+    sets = []
+    for _ in range(n_sets):
+        buf = dict(shared)
+        buf.update(X=X0.clone(), U=U0.clone(), lamb=l0.clone())
+        sets.append(buf)
+    return sets
+
+
+def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True):
+    """Time `steps` steps; returns dict(seconds, kernel_ms_avg, iterations)."""
+    import torch.distributed as dist
+    from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+    solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
+    host = workloads.make_batch(cfg, B, offset=rank * B)
+    sets = make_step_buffers(solver, host, steps + warmup, torch)
+    qfun = torch.zeros(B, dtype=torch.int32, device=solver.device)
+    cost_it = torch.zeros(B, dtype=solver.dtype, device=solver.device)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+    def step(buf, i_timed=None):
+        if i_timed is not None:
+            ev0[i_timed].record()
+        solver.iterate(buf, args.iters)
+        if i_timed is not None:
+            ev1[i_timed].record()
+        if with_tail:
+            solver.relax_cost(buf["X"], buf["x_term"], qfun, 0, 55, cost_it)
+            cost_all = dist_mod.allgather_costs(cost_it)
+            solver.argmin(cost_all)
+
+    for i in range(warmup):
+        step(sets[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(sets[warmup + i], i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device=solver.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
+    # every problem executes exactly `iters` iterations (no early exit): check on the last set
+    assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
+    solver.close()
+    return dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps)
+
+
+def cpu_baseline(cfg, B, iters, budget_s):
+    """The CPU oracle (port of the reference algorithm, oracle/ilqr_oracle.c) on the host cores of
+    this box, same synthetic workload, same fixed iteration count, bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ilqr_iterative_tasks_amd import workloads
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    host = workloads.make_batch(cfg, min(B, 4096))
+
+    def run(sl):
+        orc.ilqr_batch(cfg, host["X"][sl], host["U"][sl], host["x_term"][sl], host["lamb"][sl],
+                       host["obs"][sl], max_iter=iters, early_exit=False, want_gains=True)
+
+    # calibrate on one thread
+    n_cal = 32
+    t0 = time.perf_counter()
+    run(slice(0, n_cal))
+    per_problem = (time.perf_counter() - t0) / n_cal
+    # all cores: ctypes releases the GIL during the C call; every thread sweeps its own slice
+    # `reps` times so that the whole sample is about `budget_s` seconds of wall time
+    n_per = max(8, len(host["X"]) // cores)
+    reps = max(1, int(budget_s / (n_per * per_problem)))
+    slices = [slice(i * n_per, (i + 1) * n_per) for i in range(cores)]
+
+    def worker(sl):
+        for _ in range(reps):
+            run(sl)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(worker, slices))
+    dt = time.perf_counter() - t0
+    total = n_per * cores * reps
+    t0 = time.perf_counter()
+    run(slices[0])
+    one_thread = n_per * iters / (time.perf_counter() - t0)
+    return dict(value=total * iters / dt, unit="iLQR iterations/s", cores=cores, kind="port",
+                sample=f"{n_per * cores} problems x {iters} iterations x {reps} sweeps of the "
+                       f"bench workload on {cores} threads ({dt:.1f} s wall)",
+                value_1thread=one_thread)
+
+
+def main():
+    args = parse_args()
+    import torch
+    from ilqr_iterative_tasks_amd import dist as dist_mod, workloads
+
+    rank, world, local = dist_mod.init_from_env("nccl")
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    wl = workloads.CONFIGS[args.workload]
+    cfg = workloads.config_for(args.workload, args.dtype)
+    B = args.batch or wl["batch"]
+    dtype = "f64" if cfg.dtype == 0 else "f32"
+
+    res = run_gpu(args, cfg, B, rank, world, torch, dist_mod, args.steps, args.warmup)
+    value = res["iterations"] / res["seconds"]
+    alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
+    achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
+
+    traffic = None
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if tf.exists():
+        try:
+            rec = json.loads(tf.read_text()).get(f"{args.workload}:{dtype}:B{B}:it{args.iters}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"
+        else f"batched iLQR iterations/s ({wl['system']}, N={wl['N']})",
+        "value": value,
+        "unit": "iLQR iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": res["seconds"] / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}] ({args.workload}): "
+                               f"{wl['system']} n={cfg.n} m={cfg.m} N={cfg.N} dt={cfg.dt}",
+                   "batch_per_gpu": B, "global_batch": B * world,
+                   "iterations_per_step": args.iters,
+                   "step": "i2lqr_iterate + relax_cost + all-gather(costs) + argmin",
+                   "parallelism": f"batch-sharded x{world}, one all-gather of terminal costs"},
+        "roofline": {"bound": "hbm", "kernel": "k_iterate", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_iteration": alg_bytes,
+                     "kernel_ms_avg": res["kernel_ms"]},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, B, args.iters, args.cpu_seconds)
+    if world == 1 and not args.no_extra:
+        # secondary single-GPU workloads (not the headline): large batches of the same problem
+        extra = {}
+        for name, eb, edt in (("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32")):
+            ecfg = workloads.config_for(args.workload, edt)
+            r = run_gpu(args, ecfg, eb, 0, 1, torch, dist_mod, 6, 2, with_tail=False)
+            eb_bytes = workloads.algorithmic_bytes_per_iteration(ecfg)
+            extra[name] = {"iterations_per_s": r["iterations"] / r["seconds"],
+                           "kernel_ms": r["kernel_ms"],
+                           "achieved_GBs": eb_bytes * eb * args.iters / (r["kernel_ms"] * 1e-3) / 1e9}
+        out["extra"] = extra
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

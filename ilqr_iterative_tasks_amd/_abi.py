@@ -137,6 +137,8 @@ EXPORTS = {
     "i2lqr_config_default": (C.c_int, [C.POINTER(I2lqrConfig), C.c_int, C.c_int]),
     "i2lqr_create": (C.c_int, [C.POINTER(I2lqrConfig), C.POINTER(_P)]),
     "i2lqr_destroy": (C.c_int, [_P]),
+    "i2lqr_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
+    "i2lqr_set_workspace": (C.c_int, [_P, _P, C.c_int64]),
     "i2lqr_rollout": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "i2lqr_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "i2lqr_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

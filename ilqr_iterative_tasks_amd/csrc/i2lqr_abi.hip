@@ -10,6 +10,7 @@
 #include <new>
 
 #include "../../include/i2lqr.h"
+#include "i2lqr_lane.hpp"
 #include "i2lqr_wave.hpp"
 
 using namespace i2lqr;
@@ -70,9 +71,11 @@ template <class T, int n, int m> DevCfg<T, n, m> make_dev_cfg(const i2lqr_config
 
 struct i2lqr_handle {
   i2lqr_config cfg;
-  int lanes;        // lanes of a wavefront that cooperate on one problem
+  int lanes;        // lanes of a wavefront that cooperate on one problem (1: batch-minor layout)
   size_t lds_bytes; // dynamic LDS per workgroup (one wavefront)
   int device;
+  void* ws;         // caller-owned scratch of the batch-minor kernels
+  int64_t ws_bytes;
 };
 
 namespace {
@@ -156,10 +159,122 @@ template <class T, class Sys> struct Launch {
   }
 };
 
-// dispatch over (dtype, system)
+// Batch-minor layout: one problem per lane (i2lqr_lane.hpp); m == 2 systems.
+template <class T, class Sys> struct LaneLaunch {
+  static constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
+  using Cfg = DevCfg<T, n, m>;
+  static unsigned grid(int64_t B) { return (unsigned)((B + 63) / 64); }
+  static int64_t ws_bytes(int N, int64_t B) {
+    return lane_workspace_words<Sys>(N, B) * (int64_t)sizeof(T);
+  }
+  static int prepare(i2lqr_handle* h) {
+    h->lanes = 1;
+    h->lds_bytes = 0;
+    return I2LQR_OK;
+  }
+  static int need_ws(i2lqr_handle* h, int64_t B) {
+    const int64_t need = ws_bytes(h->cfg.N, B);
+    if (!h->ws || h->ws_bytes < need)
+      return fail(I2LQR_ERR_INVALID, "workspace of %lld B registered, batch %lld needs %lld B "
+                  "(i2lqr_workspace_bytes / i2lqr_set_workspace)", (long long)h->ws_bytes,
+                  (long long)B, (long long)need);
+    return I2LQR_OK;
+  }
+  static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a) {
+    const int N = h->cfg.N;
+    T* p = (T*)h->ws;
+    a.wsX = p; p += B * (int64_t)(n * (N + 1));
+    a.wsU = p; p += B * (int64_t)(m * N);
+    a.wsTR0 = p; p += B * (int64_t)(NT * (N + 1));
+    a.wsTR1 = p; p += B * (int64_t)(NT * (N + 1));
+    a.wsK = p; p += B * (int64_t)(m * n * N);
+    a.wsk = p;
+  }
+  static int iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
+                     const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                     int32_t* iters, int32_t* status, hipStream_t s) {
+    if (int rc = need_ws(h, B)) return rc;
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    LaneArgs<T> a;
+    a.B = B; a.n_iters = n_iters; a.early_exit = early_exit;
+    a.X = (T*)X; a.U = (T*)U; a.x_term = (const T*)x_term; a.lamb = (T*)lamb;
+    a.obs = (const T*)obs; a.cost = (T*)cost; a.K = (T*)K; a.k = (T*)k;
+    a.iters = iters; a.status = status;
+    carve(h, B, a);
+    if (c.flags)
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, a);
+    else
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, a);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
+                     hipStream_t s) {
+    if (int rc = need_ws(h, B)) return rc;
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    LaneArgs<T> a;
+    carve(h, B, a);
+    if (c.flags)
+      hipLaunchKernelGGL((k_lane_rollout<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (T*)X, (T*)U, (const T*)x_term, (T*)cost, a.wsTR0);
+    else
+      hipLaunchKernelGGL((k_lane_rollout<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (T*)X, (T*)U, (const T*)x_term, (T*)cost, a.wsTR0);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                      const void* lamb, const void* obs, void* K, void* k, hipStream_t s) {
+    if (int rc = need_ws(h, B)) return rc;
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    LaneArgs<T> a;
+    carve(h, B, a);
+    if (c.flags)
+      hipLaunchKernelGGL((k_lane_backward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
+                         (const T*)obs, (T*)K, (T*)k, a.wsTR0);
+    else
+      hipLaunchKernelGGL((k_lane_backward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
+                         (const T*)obs, (T*)K, (T*)k, a.wsTR0);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  static int forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                     const void* K, const void* k, void* Xn, void* Un, void* cost_new,
+                     hipStream_t s) {
+    if (int rc = need_ws(h, B)) return rc;
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    LaneArgs<T> a;
+    carve(h, B, a);
+    if (c.flags)
+      hipLaunchKernelGGL((k_lane_forward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
+                         (T*)Xn, (T*)Un, (T*)cost_new, a.wsTR0);
+    else
+      hipLaunchKernelGGL((k_lane_forward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+                         (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
+                         (T*)Xn, (T*)Un, (T*)cost_new, a.wsTR0);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+};
+
+// dispatch over (layout, dtype, system)
 #define I2LQR_DISPATCH(h, CALL)                                                               \
   do {                                                                                        \
     const int sid_ = (h)->cfg.system_id;                                                      \
+    if ((h)->cfg.layout == I2LQR_LAYOUT_BATCH_MINOR) {                                        \
+      if ((h)->cfg.dtype == I2LQR_F64) {                                                      \
+        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<double, Bicycle4<double>>::CALL;    \
+        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<double, Bicycle6<double>>::CALL;    \
+      } else {                                                                                \
+        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>>::CALL;      \
+        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>>::CALL;      \
+      }                                                                                       \
+      return fail(I2LQR_ERR_UNSUPPORTED, "system %d is not built for the batch-minor layout", \
+                  sid_);                                                                      \
+    }                                                                                         \
     if ((h)->cfg.dtype == I2LQR_F64) {                                                        \
       if (sid_ == I2LQR_SYS_BICYCLE4) return Launch<double, Bicycle4<double>>::CALL;          \
       if (sid_ == I2LQR_SYS_BICYCLE6) return Launch<double, Bicycle6<double>>::CALL;          \
@@ -335,8 +450,8 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
     return fail(I2LQR_ERR_INVALID, "horizon %d outside [1, %d]", cfg->N, I2LQR_MAX_HORIZON);
   if (cfg->dtype != I2LQR_F64 && cfg->dtype != I2LQR_F32)
     return fail(I2LQR_ERR_INVALID, "unknown dtype %d", cfg->dtype);
-  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
-    return fail(I2LQR_ERR_UNSUPPORTED, "layout %d is not built (problem-major only)", cfg->layout);
+  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR && cfg->layout != I2LQR_LAYOUT_BATCH_MINOR)
+    return fail(I2LQR_ERR_INVALID, "unknown layout %d", cfg->layout);
   if (!(cfg->dt > 0) || !(cfg->lamb_factor > 1) || cfg->max_iter < 0)
     return fail(I2LQR_ERR_INVALID, "need dt > 0, lamb_factor > 1, max_iter >= 0");
   for (int a = 0; a < m; a++)
@@ -347,6 +462,8 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   i2lqr_handle* h = new (std::nothrow) i2lqr_handle;
   if (!h) return fail(I2LQR_ERR_LAUNCH, "out of host memory");
   h->cfg = *cfg;
+  h->ws = nullptr;
+  h->ws_bytes = 0;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
   if (rc != I2LQR_OK) {
@@ -360,6 +477,26 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
 
 int i2lqr_destroy(i2lqr_handle* h) {
   delete h;
+  return I2LQR_OK;
+}
+
+int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
+  if (!h || B < 0 || h->cfg.layout != I2LQR_LAYOUT_BATCH_MINOR) return 0;
+  const int64_t sz = h->cfg.dtype == I2LQR_F64 ? 8 : 4;
+  const int N = h->cfg.N;
+  switch (h->cfg.system_id) {
+    case I2LQR_SYS_BICYCLE4: return lane_workspace_words<Bicycle4<double>>(N, B) * sz;
+    case I2LQR_SYS_BICYCLE6: return lane_workspace_words<Bicycle6<double>>(N, B) * sz;
+    default: return 0;
+  }
+}
+
+int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (bytes < 0 || (bytes > 0 && !workspace) || ((uintptr_t)workspace & 15))
+    return fail(I2LQR_ERR_INVALID, "workspace must be a 16-byte aligned device pointer");
+  h->ws = workspace;
+  h->ws_bytes = bytes;
   return I2LQR_OK;
 }
 
@@ -424,14 +561,15 @@ int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_te
   if (outer_iter < 0 || max_relax_iter < 1)
     return fail(I2LQR_ERR_INVALID, "need outer_iter >= 0 and max_relax_iter >= 1");
   const unsigned grid = (unsigned)((B + 255) / 256);
+  const int bm = h->cfg.layout == I2LQR_LAYOUT_BATCH_MINOR;
   hipStream_t s = (hipStream_t)stream;
   if (h->cfg.dtype == I2LQR_F64)
     hipLaunchKernelGGL((k_relax_cost<double>), dim3(grid), dim3(256), 0, s, B, h->cfg.n, h->cfg.N,
-                       (const double*)X, (const double*)x_term, qfun, outer_iter, max_relax_iter,
+                       bm, (const double*)X, (const double*)x_term, qfun, outer_iter, max_relax_iter,
                        (double*)cost_it);
   else
     hipLaunchKernelGGL((k_relax_cost<float>), dim3(grid), dim3(256), 0, s, B, h->cfg.n, h->cfg.N,
-                       (const float*)X, (const float*)x_term, qfun, outer_iter, max_relax_iter,
+                       bm, (const float*)X, (const float*)x_term, qfun, outer_iter, max_relax_iter,
                        (float*)cost_it);
   HIP_TRY(hipGetLastError());
   return I2LQR_OK;

@@ -1,0 +1,531 @@
+// One-problem-per-LANE iLQR kernels for gfx950 (MI355X): the throughput path for large batches.
+//
+// Every lane of a wavefront owns one iLQR problem; the Riccati step's small blocks (V_xx, the
+// A/B Jacobians, Q_xx / Q_ux / Q_uu) live in that lane's registers with every loop fully
+// unrolled at compile time, so the sparsity pattern of [A | B] folds into the instruction stream
+// and all 64 lanes do useful arithmetic on every VALU instruction.  The trajectory, gains and
+// the per-step trig cache stream through HBM in the BATCH-MINOR layout
+//     X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  lamb[B]  obs[6][B]
+// so a wavefront's access to one (component, t) is one fully coalesced 512-byte (fp64) row.
+// This is the HBM-bound form of the algorithm: per iteration and problem it moves X, U, K, k once
+// in each direction (SURVEY.md §8(d) algorithmic bytes).
+//
+// Reference being replaced: control/iterative_ilqr.py:7-160, control/ilqr_helper.py:9-150,
+// systems/kinetic_bicycle.py:10-52 (see i2lqr_wave.hpp for the per-phase citations; the
+// arithmetic and its order are the same).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "i2lqr_systems.hpp"
+#include "i2lqr_wave.hpp"
+
+namespace i2lqr {
+
+template <int Begin, int End, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (Begin < End) {
+    f(std::integral_constant<int, Begin>{});
+    static_for<Begin + 1, End>(f);
+  }
+}
+
+template <class T> struct LaneArgs {
+  int64_t B;
+  int n_iters, early_exit;
+  T* X; T* U; const T* x_term; T* lamb; const T* obs; T* cost; T* K; T* k;
+  int32_t* iters; int32_t* status;
+  // workspace (batch-minor): candidate trajectory, two trig caches, gains if K == null
+  T* wsX; T* wsU; T* wsTR0; T* wsTR1; T* wsK; T* wsk;
+};
+
+// words of T the workspace needs for B problems
+template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int N, int64_t B) {
+  constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
+  return B * (int64_t)(n * (N + 1) + m * N + 2 * NT * (N + 1) + m * n * N + m * N);
+}
+
+template <class T, class Sys, bool HASQR> struct LaneWorker {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG, NV = Sys::NVAR;
+  using Cfg = DevCfg<T, n, m>;
+  const Cfg& c;
+  const int N;
+  const int64_t B, b;  // batch size, this lane's problem
+
+  __device__ LaneWorker(const Cfg& c_, int64_t B_, int64_t b_) : c(c_), N(c_.N), B(B_), b(b_) {}
+
+  // batch-minor addressing
+  __device__ __forceinline__ int64_t ix(int comp, int t) const {  // X-like [comp][N+1][B]
+    return ((int64_t)comp * (N + 1) + t) * B + b;
+  }
+  __device__ __forceinline__ int64_t iu(int comp, int t) const {  // U-like [comp][N][B]
+    return ((int64_t)comp * N + t) * B + b;
+  }
+
+  template <int D> __device__ __forceinline__ T quad_form(const T* M, const T (&d)[D]) const {
+    T acc = T(0);
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+      T col = T(0);
+#pragma unroll
+      for (int i = 0; i < D; i++) col += d[i] * M[i * D + j];
+      acc += col * d[j];
+    }
+    return acc;
+  }
+  __device__ __forceinline__ T stage_cost(const T (&x)[n], const T* ref, const T (&u)[m]) const {
+    T l = T(0);
+    if constexpr (HASQR) {
+      T d[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) d[i] = x[i] - ref[i];
+      l += quad_form<n>(c.Q, d);
+      l += quad_form<m>(c.R, u);
+    }
+    return l;
+  }
+  __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
+    T d[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) d[i] = x[i] - xT[i];
+    return quad_form<n>(c.Qt, d);
+  }
+
+  // entry (i, a) of F = [A | B] from the compile-time pattern
+  template <int i, int a> __device__ __forceinline__ T f_entry(const T (&jv)[NV]) const {
+    constexpr int code = Sys::pat(i, a);
+    if constexpr (code == 1) return T(1);
+    else if constexpr (code == 2) return c.dt;
+    else return jv[code - 3];
+  }
+  // acc += F[i][a] * v  (skipped at compile time for structural zeros; exact for ones)
+  template <int i, int a> __device__ __forceinline__ void f_acc(T& acc, bool& first, T v,
+                                                                const T (&jv)[NV]) const {
+    constexpr int code = Sys::pat(i, a);
+    if constexpr (code == 0) {
+      return;
+    } else if constexpr (code == 1) {
+      acc = first ? v : acc + v;
+      first = false;
+    } else {
+      const T f = f_entry<i, a>(jv);
+      acc = first ? f * v : t_fma(f, v, acc);
+      first = false;
+    }
+  }
+
+  // -- nominal rollout + cost (control/iterative_ilqr.py:32-48); also fills the trig cache ------
+  __device__ __forceinline__ T rollout(T* X, T* U, T* TR, const T (&xT)[n]) const {
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = X[ix(i, 0)];
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        u[a] = clip(U[iu(a, t)], -c.u_max[a], c.u_max[a]);
+        U[iu(a, t)] = u[a];
+      }
+      Sys::trig(x, tr);
+#pragma unroll
+      for (int q = 0; q < NT; q++) TR[ix(q, t)] = tr[q];
+      Sys::step_tr(c, x, u, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) X[ix(i, t + 1)] = xn[i];
+      cost = cost + stage_cost(x, c.xtarget, u);
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    Sys::trig(x, tr);
+#pragma unroll
+    for (int q = 0; q < NT; q++) TR[ix(q, N)] = tr[q];
+    cost = cost + terminal_cost(x, xT);
+    return cost;
+  }
+
+  // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
+  __device__ __forceinline__ void obstacle(const T (&ob)[6], T px, T py, int t, T (&o)[5]) const {
+#pragma unroll
+    for (int q = 0; q < 5; q++) o[q] = T(0);
+    if (ob[5] >= T(0)) {
+      const int opt = (int)ob[5];
+      T dz = px - ob[0], dy = py - ob[1];
+      if (opt == 1) dy = py - (ob[1] + T(t) * ob[4]);
+      if (opt == 2) dz = px - (ob[0] - T(t) * ob[4]);
+      const T pa = T(1) / (ob[2] * ob[2]), pb = T(1) / (ob[3] * ob[3]);
+      const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
+      const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
+      const T e = t_exp(c.obs_q2 * h);
+      const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+      o[0] = c1 * hd0;
+      o[1] = c1 * hd1;
+      o[2] = c2 * (hd0 * hd0);
+      o[3] = c2 * (hd0 * hd1);
+      o[4] = c2 * (hd1 * hd1);
+    }
+  }
+
+  // regularised inverse of Q_uu (m == 2 closed form, control/iterative_ilqr.py:118-123)
+  __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
+                                              T (&inv)[m * m]) const {
+    static_assert(m == 2, "lane kernels are built for m == 2 systems");
+    const T a = Quu[0], bq = Quu[1], cc = Quu[2], d = Quu[3];
+    const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
+    T disc = hd * hd + bq * cc;
+    disc = disc < T(0) ? T(0) : disc;
+    const T s = t_sqrt(disc);
+    T l1 = (mean >= T(0)) ? mean + s : mean - s;
+    T l2 = (l1 != T(0)) ? (a * d - bq * cc) / l1 : T(0);
+    if (s == T(0)) { l1 = mean; l2 = mean; }
+    const T w[2] = {l1, l2};
+    T V[4];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const T lo = w[1 - e];
+      const T c0x = a - lo, c0y = cc, c1x = bq, c1y = d - lo;
+      const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
+      const bool firstc = n0 >= n1;
+      T vx = firstc ? c0x : c1x, vy = firstc ? c0y : c1y, nn = firstc ? n0 : n1;
+      if (nn == T(0)) { vx = (e == 0) ? T(1) : T(0); vy = (e == 0) ? T(0) : T(1); nn = T(1); }
+      const T r = T(1) / t_sqrt(nn);
+      V[0 * 2 + e] = vx * r;
+      V[1 * 2 + e] = vy * r;
+    }
+    T wr[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) wr[e] = T(1) / ((w[e] < T(0) ? T(0) : w[e]) + lamb);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        inv[i * 2 + j] = V[i * 2 + 0] * wr[0] * V[j * 2 + 0] + V[i * 2 + 1] * wr[1] * V[j * 2 + 1];
+  }
+
+  // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
+  // Reads the nominal (X, U, TR), writes the gains to gK[m][n][N][B], gk[m][N][B].
+  __device__ __forceinline__ void backward(const T* X, const T* U, const T* TR, const T (&xT)[n],
+                                           const T (&ob)[6], T lamb, T* gK, T* gk) const {
+    T Va[n][n + 1];  // [Vxx | Vx]
+    {
+      // get_cost_final(): control/ilqr_helper.py:106-150
+      T xN[n], o[5];
+#pragma unroll
+      for (int i = 0; i < n; i++) xN[i] = X[ix(i, N)];
+      obstacle(ob, xN[0], xN[1], N, o);
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T vx = T(0);
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+          Va[i][r] = T(2) * c.Qt[i * n + r];
+          vx += T(2) * c.Qt[i * n + r] * (xN[r] - xT[r]);
+        }
+        Va[i][n] = vx;
+      }
+      Va[0][0] += o[2]; Va[0][1] += o[3]; Va[1][0] += o[3]; Va[1][1] += o[4];
+      Va[0][n] += o[0]; Va[1][n] += o[1];
+    }
+    for (int t = N - 1; t >= 0; t--) {
+      T xe[n], u[m], tr[NT], jv[NV], o[5], xt[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) xe[i] = X[ix(i, t + 1)];
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+#pragma unroll
+      for (int q = 0; q < NT; q++) tr[q] = TR[ix(q, t + 1)];
+      if constexpr (HASQR) {
+#pragma unroll
+        for (int i = 0; i < n; i++) xt[i] = X[ix(i, t)];
+      } else {
+        xt[0] = X[ix(0, t)];
+        xt[1] = X[ix(1, t)];
+      }
+      Sys::jac_var(c, xe, u, tr, jv);
+      obstacle(ob, xt[0], xt[1], t, o);
+      // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
+      T lu[m], luu[m];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        const T e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
+        const T e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+        T l = T(0);
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) l += T(2) * c.R[a * m + bb] * u[bb];
+        }
+        lu[a] = l + (c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo);
+        luu[a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
+                 c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+      }
+
+      // Row by row: T1[a][:] = (F^T [Vxx|Vx])[a][:], then H[a][:] = L[a][:] + T1[a][:n] F
+      T Qa[n][n + 1];   // [Qxx | Qx]
+      T G[m][n + 1];    // [Qux | Qu]
+      T Quu[m * m];
+      static_for<0, W>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        T t1[n + 1];
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+          T acc = T(0);
+          bool first = true;
+          static_for<0, n>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            f_acc<i, a>(acc, first, Va[i][j], jv);
+          });
+          t1[j] = acc;
+        }
+        static_for<0, W>([&](auto b_) {
+          constexpr int bcol = decltype(b_)::value;
+          if constexpr (!(a < n && bcol >= n)) {  // Qxu is never used by the reference
+            T acc = T(0);
+            bool first = true;
+            static_for<0, n>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              f_acc<i, bcol>(acc, first, t1[i], jv);
+            });
+            T l = T(0);
+            if constexpr (a < n) {
+              if constexpr (HASQR) l = T(2) * c.Q[a * n + bcol];
+              if constexpr (a < 2 && bcol < 2) l += o[2 + a + bcol];
+              Qa[a][bcol] = l + acc;
+            } else if constexpr (bcol < n) {
+              G[a - n][bcol] = acc;
+            } else {
+              if constexpr (HASQR) l = T(2) * c.R[(a - n) * m + (bcol - n)];
+              if constexpr (a == bcol) l += luu[a - n];
+              Quu[(a - n) * m + (bcol - n)] = l + acc;
+            }
+          }
+        });
+        if constexpr (a < n) {
+          T l = T(0);
+          if constexpr (HASQR) {
+#pragma unroll
+            for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xt[r] - c.xtarget[r]);
+          }
+          if constexpr (a < 2) l += o[a];
+          Qa[a][n] = l + t1[n];
+        } else {
+          G[a - n][n] = lu[a - n] + t1[n];
+        }
+      });
+
+      // gains [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
+      T Qinv[m * m], Kk[m][n + 1];
+      quu_inverse(Quu, lamb, Qinv);
+#pragma unroll
+      for (int a = 0; a < m; a++)
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+          T acc = T(0);
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], G[bb][j], acc);
+          Kk[a][j] = -acc;
+        }
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+#pragma unroll
+        for (int j = 0; j < n; j++) gK[(((int64_t)a * n + j) * N + t) * B + b] = Kk[a][j];
+        gk[iu(a, t)] = Kk[a][n];
+      }
+      // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T ktq[m];
+#pragma unroll
+        for (int bb = 0; bb < m; bb++) {
+          T acc = T(0);
+#pragma unroll
+          for (int a = 0; a < m; a++) acc = t_fma(Kk[a][i], Quu[a * m + bb], acc);
+          ktq[bb] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+          T acc = T(0);
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) acc = t_fma(ktq[bb], Kk[bb][j], acc);
+          Va[i][j] = Qa[i][j] - acc;
+        }
+      }
+    }
+  }
+
+  // -- forward pass: control/iterative_ilqr.py:133-160; fills the candidate's trig cache --------
+  __device__ __forceinline__ T forward(const T* X, const T* U, const T* gK, const T* gk, T* Xn,
+                                       T* Un, T* TRn, const T (&xT)[n]) const {
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      x[i] = X[ix(i, 0)];
+      Xn[ix(i, 0)] = x[i];
+    }
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < n; j++)
+          acc = t_fma(gK[(((int64_t)a * n + j) * N + t) * B + b], x[j] - X[ix(j, t)], acc);
+        u[a] = clip(U[iu(a, t)] + gk[iu(a, t)] + acc, -c.u_max[a], c.u_max[a]);
+        Un[iu(a, t)] = u[a];
+      }
+      Sys::trig(x, tr);
+#pragma unroll
+      for (int q = 0; q < NT; q++) TRn[ix(q, t)] = tr[q];
+      Sys::step_tr(c, x, u, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) Xn[ix(i, t + 1)] = xn[i];
+      cost = cost + stage_cost(x, xT, u);
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    Sys::trig(x, tr);
+#pragma unroll
+    for (int q = 0; q < NT; q++) TRn[ix(q, N)] = tr[q];
+    cost = cost + terminal_cost(x, xT);
+    return cost;
+  }
+
+  // stage cost of a stored trajectory measured to xtarget (only needed when Q != 0, where the
+  // nominal cost of the next iteration differs from the accepted forward cost)
+  __device__ __forceinline__ T nominal_cost(const T* X, const T* U, const T (&xT)[n]) const {
+    T x[n], u[m];
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = X[ix(i, t)];
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+      cost = cost + stage_cost(x, c.xtarget, u);
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = X[ix(i, N)];
+    return cost + terminal_cost(x, xT);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Kernels: 64-thread workgroups (one wavefront), one problem per lane.
+// ---------------------------------------------------------------------------------------------
+template <class T, class Sys, bool HASQR>
+__global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys::m> c,
+                                                     const LaneArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  LaneWorker<T, Sys, HASQR> w(c, a.B, b);
+  const int N = c.N;
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = a.x_term[(int64_t)i * a.B + b];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[(int64_t)q * a.B + b] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[b];
+  T* gK = a.K ? a.K : a.wsK;
+  T* gk = a.K ? a.k : a.wsk;
+  // per-lane trajectory buffers: "cur" holds the nominal, "nxt" receives the candidate
+  T *Xc = a.X, *Uc = a.U, *TRc = a.wsTR0;
+  T *Xn = a.wsX, *Un = a.wsU, *TRn = a.wsTR1;
+
+  // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
+  // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
+  T cost = w.rollout(Xc, Uc, TRc, xT);
+  int it = 0, status = a.early_exit ? 2 : 0;
+  T cost_ret = cost;
+  while (it < a.n_iters) {
+    w.backward(Xc, Uc, TRc, xT, ob, lamb, gK, gk);
+    const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, TRn, xT);
+    it++;
+    if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
+      T* tp;
+      tp = Xc; Xc = Xn; Xn = tp;
+      tp = Uc; Uc = Un; Un = tp;
+      tp = TRc; TRc = TRn; TRn = tp;
+      lamb /= c.lamb_factor;
+      const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
+      cost_ret = cost_new;
+      // next iteration's nominal cost: stage terms are measured to xtarget, not x_terminal
+      cost = HASQR ? w.nominal_cost(Xc, Uc, xT) : cost_new;
+      if (conv) {
+        if (a.early_exit) { status = 1; break; }
+        if (status == 0) status = 1;
+      }
+    } else {  // control/iterative_ilqr.py:81-84
+      lamb *= c.lamb_factor;
+      cost_ret = cost;
+      if (lamb > c.max_lamb) {
+        if (a.early_exit) { status = 3; break; }
+        if (status == 0) status = 3;
+      }
+    }
+  }
+  if (!t_isfinite(cost_ret)) status = 4;
+  if (Xc != a.X) {  // the accepted trajectory sits in the workspace: copy it out
+    for (int e = 0; e < n * (N + 1); e++) a.X[(int64_t)e * a.B + b] = Xc[(int64_t)e * a.B + b];
+    for (int e = 0; e < m * N; e++) a.U[(int64_t)e * a.B + b] = Uc[(int64_t)e * a.B + b];
+  }
+  a.lamb[b] = lamb;
+  a.cost[b] = cost_ret;
+  if (a.iters) a.iters[b] = it;
+  if (a.status) a.status[b] = status;
+}
+
+template <class T, class Sys, bool HASQR>
+__global__ __launch_bounds__(64) void k_lane_rollout(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                     T* X, T* U, const T* x_term, T* cost,
+                                                     T* wsTR) {
+  constexpr int n = Sys::n;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  T xT[n];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
+  cost[b] = w.rollout(X, U, wsTR, xT);
+}
+
+template <class T, class Sys, bool HASQR>
+__global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                      const T* X, const T* U, const T* x_term,
+                                                      const T* lamb, const T* obs, T* K, T* k,
+                                                      T* wsTR) {
+  constexpr int n = Sys::n, NT = Sys::NTRIG;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = obs ? obs[(int64_t)q * B + b] : T(q == 5 ? -1 : 1);
+  // trig cache of the given nominal
+  for (int t = 0; t <= c.N; t++) {
+    T x[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = X[w.ix(i, t)];
+    Sys::trig(x, tr);
+#pragma unroll
+    for (int q = 0; q < NT; q++) wsTR[w.ix(q, t)] = tr[q];
+  }
+  w.backward(X, U, wsTR, xT, ob, lamb[b], K, k);
+}
+
+template <class T, class Sys, bool HASQR>
+__global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
+                                                     const T* X, const T* U, const T* x_term,
+                                                     const T* K, const T* k, T* Xn, T* Un,
+                                                     T* cost_new, T* wsTR) {
+  constexpr int n = Sys::n;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  T xT[n];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
+  cost_new[b] = w.forward(X, U, K, k, Xn, Un, wsTR, xT);
+}
+
+}  // namespace i2lqr

@@ -22,6 +22,13 @@ template <> __device__ __forceinline__ float t_sin<float>(float x) { return sinf
 template <class T> __device__ __forceinline__ T t_cos(T x);
 template <> __device__ __forceinline__ double t_cos<double>(double x) { return cos(x); }
 template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf(x); }
+template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
+template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
+  sincos(x, s, c);
+}
+template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
+  sincosf(x, s, c);
+}
 template <class T> __device__ __forceinline__ T t_exp(T x);
 template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
@@ -47,20 +54,39 @@ template <class T> struct Bicycle4 {
   static constexpr int n = 4, m = 2, NTRIG = 2, NVAR = 6;
   static constexpr int system_id = 0;
 
-  // kinetic_bicycle(): systems/kinetic_bicycle.py:10-27
+  // {cos(theta), sin(theta)}
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    t_sincos(xe[3], &tr[1], &tr[0]);
+  }
+  // kinetic_bicycle(): systems/kinetic_bicycle.py:10-27, with trig(x) supplied
   template <class Cfg>
-  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
-                                              T (&xn)[n]) {
+  static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                                 const T (&tr)[NTRIG], T (&xn)[n]) {
     const T dt = c.dt;
     const T w = x[2] * dt + (u[0] * dt * dt) / T(2);
-    xn[0] = x[0] + t_cos(x[3]) * w;
-    xn[1] = x[1] + t_sin(x[3]) * w;
+    xn[0] = x[0] + tr[0] * w;
+    xn[1] = x[1] + tr[1] * w;
     xn[2] = x[2] + u[0] * dt;
     xn[3] = x[3] + u[1] * dt;
   }
-  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
-    tr[0] = t_cos(xe[3]);
-    tr[1] = t_sin(xe[3]);
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    T tr[NTRIG];
+    trig(x, tr);
+    step_tr(c, x, u, tr, xn);
+  }
+  // compile-time pattern of F = [A | B]: 0 zero, 1 one, 2 dt, 3 + v = varying entry v
+  static constexpr int pat(int i, int j) {
+    if (i == j) return 1;
+    if (i == 0 && j == 2) return 3 + 0;
+    if (i == 0 && j == 3) return 3 + 1;
+    if (i == 1 && j == 2) return 3 + 2;
+    if (i == 1 && j == 3) return 3 + 3;
+    if (i == 0 && j == n) return 3 + 4;
+    if (i == 1 && j == n) return 3 + 5;
+    if ((i == 2 && j == n) || (i == 3 && j == n + 1)) return 2;
+    return 0;
   }
   // get_A_matrix / get_B_matrix: systems/kinetic_bicycle.py:30-52
   template <class Cfg>
@@ -97,21 +123,39 @@ template <class T> struct Bicycle6 {
   static constexpr int n = 6, m = 2, NTRIG = 2, NVAR = 6;
   static constexpr int system_id = 1;
 
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    t_sincos(xe[3], &tr[1], &tr[0]);
+  }
   template <class Cfg>
-  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
-                                              T (&xn)[n]) {
+  static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                                 const T (&tr)[NTRIG], T (&xn)[n]) {
     const T dt = c.dt;
     const T w = x[2] * dt + (x[4] * dt * dt) / T(2);
-    xn[0] = x[0] + t_cos(x[3]) * w;
-    xn[1] = x[1] + t_sin(x[3]) * w;
+    xn[0] = x[0] + tr[0] * w;
+    xn[1] = x[1] + tr[1] * w;
     xn[2] = x[2] + x[4] * dt;
     xn[3] = x[3] + x[5] * dt;
     xn[4] = x[4] + u[0] * dt;
     xn[5] = x[5] + u[1] * dt;
   }
-  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
-    tr[0] = t_cos(xe[3]);
-    tr[1] = t_sin(xe[3]);
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    T tr[NTRIG];
+    trig(x, tr);
+    step_tr(c, x, u, tr, xn);
+  }
+  static constexpr int pat(int i, int j) {
+    if (i == j) return 1;
+    if (i == 0 && j == 2) return 3 + 0;
+    if (i == 0 && j == 3) return 3 + 1;
+    if (i == 0 && j == 4) return 3 + 2;
+    if (i == 1 && j == 2) return 3 + 3;
+    if (i == 1 && j == 3) return 3 + 4;
+    if (i == 1 && j == 4) return 3 + 5;
+    if ((i == 2 && j == 4) || (i == 3 && j == 5)) return 2;
+    if ((i == 4 && j == n) || (i == 5 && j == n + 1)) return 2;
+    return 0;
   }
   template <class Cfg>
   static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&)[m],

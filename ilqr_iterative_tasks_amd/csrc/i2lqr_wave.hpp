@@ -667,15 +667,17 @@ __global__ __launch_bounds__(64) void k_forward(const DevCfg<T, Sys::n, Sys::m> 
 
 // relaxed terminal cost: utils/base.py:427-437.  One lane per candidate.
 template <class T>
-__global__ void k_relax_cost(int64_t B, int n, int N, const T* X, const T* x_term,
-                             const int32_t* qfun, int outer_iter, int max_relax_iter,
-                             T* cost_it) {
+__global__ void k_relax_cost(int64_t B, int n, int N, int batch_minor, const T* X,
+                             const T* x_term, const int32_t* qfun, int outer_iter,
+                             int max_relax_iter, T* cost_it) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const T* Xb = X + b * (int64_t)(n * (N + 1));
   double ss = 0.0;
   for (int i = 0; i < n; i++) {
-    const double d = (double)Xb[i * (N + 1) + N] - (double)x_term[b * n + i];
+    const double xN = batch_minor ? (double)X[((int64_t)i * (N + 1) + N) * B + b]
+                                  : (double)X[b * (int64_t)(n * (N + 1)) + i * (N + 1) + N];
+    const double xt = batch_minor ? (double)x_term[(int64_t)i * B + b] : (double)x_term[b * n + i];
+    const double d = xN - xt;
     ss += d * d;
   }
   const double nrm = sqrt(ss);

@@ -1,0 +1,82 @@
+"""Multi-GPU sharding of the candidate batch: one process per GPU, no data-path collective except
+ONE all-gather of the per-candidate terminal costs (RCCL over xGMI via torch.distributed, backend
+"nccl"; "gloo" in the CPU tests), followed by the arg-min every rank evaluates locally.
+
+The batch axis is the safe-set terminal candidates of iLqr.calc_input (utils/base.py:391-455, the
+`for id` / `for j` loops); candidates are independent given their own lamb0, and the only
+cross-candidate step is the pick at utils/base.py:462-469.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank); a no-op single-process world if WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of `total` candidates owned by `rank` (first ranks take the
+    remainder, so shards differ by at most one candidate)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=None) -> torch.Tensor:
+    """The one collective of the path: every rank contributes its shard of cost_it and receives the
+    full vector in shard order.  Equal shards use a single all_gather_into_tensor (one RCCL
+    ncclAllGather, B/world elements per rank); ragged shards are padded with +inf to the largest
+    shard and compacted afterwards."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return cost_local
+    world = dist.get_world_size(group)
+    n_local = cost_local.numel()
+    if total is None or total == n_local * world:
+        out = torch.empty(n_local * world, dtype=cost_local.dtype, device=cost_local.device)
+        try:
+            dist.all_gather_into_tensor(out, cost_local.contiguous(), group=group)
+        except (RuntimeError, NotImplementedError):  # backend without the fused form
+            parts = list(out.chunk(world))
+            dist.all_gather(parts, cost_local.contiguous(), group=group)
+        return out
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    padded = torch.full((width,), float("inf"), dtype=cost_local.dtype, device=cost_local.device)
+    padded[:n_local] = cost_local
+    gathered = allgather_costs(padded, None, group).view(world, width)
+    return torch.cat([gathered[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)])
+
+
+def select_best_flat(cost_all: torch.Tensor) -> tuple[int, float]:
+    """Flat arg-min with first-index tie-break (used for the synthetic 10^4..10^6 batches)."""
+    val, idx = torch.min(cost_all, dim=0)
+    # torch.min does not promise the first index on ties: resolve explicitly
+    first = int(torch.nonzero(cost_all == val, as_tuple=False)[0, 0]) if not torch.isnan(val) \
+        else int(idx)
+    return first, float(val)
+
+
+def select_best_lexicographic(cost_rows: list[list[float]]) -> tuple[int, int]:
+    """The reference's pick (utils/base.py:462-465): `cost_list.index(min(cost_list))` on a LIST OF
+    LISTS — Python compares the per-lap lists lexicographically — then the first minimum inside
+    that lap's list.  Returns (lap_position, candidate_position)."""
+    best_lap = cost_rows.index(min(cost_rows))
+    row = cost_rows[best_lap]
+    return best_lap, row.index(min(row))

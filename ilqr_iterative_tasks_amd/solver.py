@@ -4,9 +4,13 @@ PyTorch is plumbing only: it owns the HBM allocations and the HIP stream; every 
 runs in the hand-written HIP kernels of libi2lqr_hip.so.  There is no CPU path: constructing a
 solver without a visible HIP device, or without the built extension, raises.
 
-Tensor layout (problem-major, time contiguous — the reference's NumPy layout with a leading batch
-axis; control/iterative_ilqr.py:109-110, utils/base.py:405-409):
+Tensor layouts (cfg.layout):
+  problem-major (default; the reference's NumPy layout with a leading batch axis, time contiguous;
+  control/iterative_ilqr.py:109-110, utils/base.py:405-409) — one problem per wavefront kernels:
     X[B, n, N+1]   U[B, m, N]   K[B, m, n, N]   k[B, m, N]   x_term[B, n]   lamb[B]   obs[B, 6]
+  batch-minor (batch index fastest) — one problem per lane kernels, the large-batch path:
+    X[n, N+1, B]   U[m, N, B]   K[m, n, N, B]   k[m, N, B]   x_term[n, B]   lamb[B]   obs[6, B]
+`to_native()` / `to_problem_major()` convert between the two.
 """
 from __future__ import annotations
 
@@ -38,6 +42,8 @@ class BatchedILQR:
             self._check(self.lib.i2lqr_create(C.byref(self.cfg), C.byref(handle)))
         self._handle = handle
         self._argmin_ws = None
+        self.batch_minor = cfg.layout == _abi.LAYOUT_BATCH_MINOR
+        self._ws = None  # scratch of the batch-minor kernels (registered on the handle)
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc: int) -> None:
@@ -73,80 +79,114 @@ class BatchedILQR:
             raise ValueError(f"{name}: must be contiguous")
         return C.c_void_p(t.data_ptr())
 
+    # -- layout ---------------------------------------------------------------------------------
+    def shape(self, name: str, B: int) -> tuple:
+        n, m, N = self.n, self.m, self.N
+        core = {"X": (n, N + 1), "U": (m, N), "K": (m, n, N), "k": (m, N), "x_term": (n,),
+                "obs": (OBS_WORDS,), "lamb": (), "cost": (), "iters": (), "status": (),
+                "qfun": (), "cost_it": ()}[name]
+        return core + (B,) if self.batch_minor else (B,) + core
+
+    def to_native(self, t: torch.Tensor) -> torch.Tensor:
+        """problem-major [B, ...] tensor -> this solver's layout (contiguous)."""
+        if not self.batch_minor or t.dim() == 1:
+            return t.contiguous()
+        return t.movedim(0, -1).contiguous()
+
+    def to_problem_major(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.batch_minor or t.dim() == 1:
+            return t
+        return t.movedim(-1, 0).contiguous()
+
+    def batch_of(self, X: torch.Tensor) -> int:
+        return X.shape[-1] if self.batch_minor else X.shape[0]
+
+    def ensure_workspace(self, B: int) -> None:
+        need = int(self.lib.i2lqr_workspace_bytes(self._handle, B))
+        if need == 0:
+            return
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._check(self.lib.i2lqr_set_workspace(self._handle, C.c_void_p(self._ws.data_ptr()),
+                                                     self._ws.numel()))
+
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,
                            device=self.device)
 
     def alloc(self, B: int, want_gains: bool = True) -> dict:
         """Zero-initialised buffer set for B problems (U = 0, lamb = 1: utils/base.py:393, :405)."""
-        n, m, N = self.n, self.m, self.N
-        z = lambda *s, dtype=None: torch.zeros(*s, dtype=self.dtype if dtype is None else dtype,
-                                               device=self.device)
-        buf = dict(X=z(B, n, N + 1), U=z(B, m, N), x_term=z(B, n), lamb=z(B) + 1, cost=z(B),
-                   iters=z(B, dtype=torch.int32), status=z(B, dtype=torch.int32), obs=None)
-        buf["K"] = z(B, m, n, N) if want_gains else None
-        buf["k"] = z(B, m, N) if want_gains else None
+        z = lambda name, dtype=None: torch.zeros(
+            self.shape(name, B), dtype=self.dtype if dtype is None else dtype, device=self.device)
+        buf = dict(X=z("X"), U=z("U"), x_term=z("x_term"), lamb=z("lamb") + 1, cost=z("cost"),
+                   iters=z("iters", torch.int32), status=z("status", torch.int32), obs=None)
+        buf["K"] = z("K") if want_gains else None
+        buf["k"] = z("k") if want_gains else None
         return buf
 
     # -- the path ---------------------------------------------------------------------------
     def rollout(self, X, U, x_term, cost=None):
         """control/iterative_ilqr.py:32-48.  X[:, :, 0] = x0; U is clipped in place."""
-        B, n, m, N = X.shape[0], self.n, self.m, self.N
+        B, sh = self.batch_of(X), self.shape
         cost = self.empty(B) if cost is None else cost
+        self.ensure_workspace(B)
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_rollout(
-                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
-                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
+                self._handle, B, self._ptr(X, sh("X", B), name="X"),
+                self._ptr(U, sh("U", B), name="U"), self._ptr(x_term, sh("x_term", B), name="x_term"),
                 self._ptr(cost, (B,), name="cost"), self._stream()))
         return cost
 
     def backward(self, X, U, x_term, lamb, obs=None, K=None, k=None):
         """control/iterative_ilqr.py:88-130.  Returns (k[B,m,N], K[B,m,n,N])."""
-        B, n, m, N = X.shape[0], self.n, self.m, self.N
-        K = self.empty(B, m, n, N) if K is None else K
-        k = self.empty(B, m, N) if k is None else k
+        B, sh = self.batch_of(X), self.shape
+        K = self.empty(*sh("K", B)) if K is None else K
+        k = self.empty(*sh("k", B)) if k is None else k
+        self.ensure_workspace(B)
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_backward(
-                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
-                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
-                self._ptr(lamb, (B,), name="lamb"), self._ptr(obs, (B, OBS_WORDS), name="obs"),
-                self._ptr(K, (B, m, n, N), name="K"), self._ptr(k, (B, m, N), name="k"),
+                self._handle, B, self._ptr(X, sh("X", B), name="X"),
+                self._ptr(U, sh("U", B), name="U"), self._ptr(x_term, sh("x_term", B), name="x_term"),
+                self._ptr(lamb, (B,), name="lamb"), self._ptr(obs, sh("obs", B), name="obs"),
+                self._ptr(K, sh("K", B), name="K"), self._ptr(k, sh("k", B), name="k"),
                 self._stream()))
         return k, K
 
     def forward(self, X, U, x_term, K, k, X_new=None, U_new=None, cost_new=None):
         """control/iterative_ilqr.py:133-160.  Returns (X_new, U_new, cost_new)."""
-        B, n, m, N = X.shape[0], self.n, self.m, self.N
-        X_new = self.empty(B, n, N + 1) if X_new is None else X_new
-        U_new = self.empty(B, m, N) if U_new is None else U_new
+        B, sh = self.batch_of(X), self.shape
+        X_new = self.empty(*sh("X", B)) if X_new is None else X_new
+        U_new = self.empty(*sh("U", B)) if U_new is None else U_new
         cost_new = self.empty(B) if cost_new is None else cost_new
+        self.ensure_workspace(B)
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_forward(
-                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
-                self._ptr(U, (B, m, N), name="U"), self._ptr(x_term, (B, n), name="x_term"),
-                self._ptr(K, (B, m, n, N), name="K"), self._ptr(k, (B, m, N), name="k"),
-                self._ptr(X_new, (B, n, N + 1), name="X_new"),
-                self._ptr(U_new, (B, m, N), name="U_new"),
+                self._handle, B, self._ptr(X, sh("X", B), name="X"),
+                self._ptr(U, sh("U", B), name="U"), self._ptr(x_term, sh("x_term", B), name="x_term"),
+                self._ptr(K, sh("K", B), name="K"), self._ptr(k, sh("k", B), name="k"),
+                self._ptr(X_new, sh("X", B), name="X_new"),
+                self._ptr(U_new, sh("U", B), name="U_new"),
                 self._ptr(cost_new, (B,), name="cost_new"), self._stream()))
         return X_new, U_new, cost_new
 
     def _iter_args(self, buf, B):
-        n, m, N = self.n, self.m, self.N
-        return (self._ptr(buf["X"], (B, n, N + 1), name="X"),
-                self._ptr(buf["U"], (B, m, N), name="U"),
-                self._ptr(buf["x_term"], (B, n), name="x_term"),
+        sh = self.shape
+        self.ensure_workspace(B)
+        return (self._ptr(buf["X"], sh("X", B), name="X"),
+                self._ptr(buf["U"], sh("U", B), name="U"),
+                self._ptr(buf["x_term"], sh("x_term", B), name="x_term"),
                 self._ptr(buf["lamb"], (B,), name="lamb"),
-                self._ptr(buf.get("obs"), (B, OBS_WORDS), name="obs"),
+                self._ptr(buf.get("obs"), sh("obs", B), name="obs"),
                 self._ptr(buf["cost"], (B,), name="cost"),
-                self._ptr(buf.get("K"), (B, m, n, N), name="K"),
-                self._ptr(buf.get("k"), (B, m, N), name="k"),
+                self._ptr(buf.get("K"), sh("K", B), name="K"),
+                self._ptr(buf.get("k"), sh("k", B), name="k"),
                 self._ptr(buf.get("iters"), (B,), torch.int32, name="iters"),
                 self._ptr(buf.get("status"), (B,), torch.int32, name="status"))
 
     def iterate(self, buf: dict, n_iters: int) -> dict:
         """`n_iters` fused iLQR iterations per problem without early exits (the throughput unit);
         in place on buf['X'], buf['U'], buf['lamb'].  control/iterative_ilqr.py:29-84."""
-        B = buf["X"].shape[0]
+        B = self.batch_of(buf["X"])
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_iterate(self._handle, B, int(n_iters),
                                                *self._iter_args(buf, B), self._stream()))
@@ -154,7 +194,7 @@ class BatchedILQR:
 
     def solve(self, buf: dict) -> dict:
         """ilqr() to termination for every problem (control/iterative_ilqr.py:7-85), in place."""
-        B = buf["X"].shape[0]
+        B = self.batch_of(buf["X"])
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_solve(self._handle, B, *self._iter_args(buf, B),
                                              self._stream()))
@@ -163,12 +203,12 @@ class BatchedILQR:
     def relax_cost(self, X, x_term, qfun, outer_iter: int, max_relax_iter: int = 55,
                    cost_it=None):
         """utils/base.py:427-437 for every candidate."""
-        B, n, N = X.shape[0], self.n, self.N
+        B = self.batch_of(X)
         cost_it = self.empty(B) if cost_it is None else cost_it
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_relax_cost(
-                self._handle, B, self._ptr(X, (B, n, N + 1), name="X"),
-                self._ptr(x_term, (B, n), name="x_term"),
+                self._handle, B, self._ptr(X, self.shape("X", B), name="X"),
+                self._ptr(x_term, self.shape("x_term", B), name="x_term"),
                 self._ptr(qfun, (B,), torch.int32, name="qfun"), int(outer_iter),
                 int(max_relax_iter), self._ptr(cost_it, (B,), name="cost_it"), self._stream()))
         return cost_it

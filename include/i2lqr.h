@@ -119,6 +119,16 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
 int i2lqr_destroy(i2lqr_handle* h);
 
 /*
+ * Scratch for the batch-minor (one problem per lane) kernels: the candidate trajectory of the
+ * forward pass, the per-step trig caches and, when the caller does not ask for K/k, the gains.
+ * The caller owns the memory (device pointer, 16-byte aligned) and registers it on the handle;
+ * i2lqr_workspace_bytes() is 0 for the problem-major layout.  A call whose batch needs more than
+ * the registered size fails with I2LQR_ERR_INVALID.
+ */
+int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B);
+int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
+
+/*
  * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.
  * In: X[.,:,0] = x0, U.  Out: U clipped in place, X[.,:,1..N], cost[B] (stage cost to xtarget +
  * terminal cost to x_term; barrier terms are NOT part of the cost, as in the reference).

@@ -25,11 +25,18 @@ def batch_rel_err(a, b, floor=1e-300):
 
 
 def to_dev(solver, arr, dtype=None):
+    """Host array in the problem-major convention [B, ...] -> device tensor in the solver's
+    native layout (batch-minor solvers get the batch axis moved last)."""
     import torch
     t = torch.as_tensor(np.ascontiguousarray(arr))
     if t.dtype in (torch.float64, torch.float32):
         t = t.to(solver.dtype if dtype is None else dtype)
-    return t.to(solver.device).contiguous()
+    return solver.to_native(t.to(solver.device))
+
+
+def to_host(solver, t):
+    """Device tensor in the solver's native layout -> NumPy array, problem-major [B, ...]."""
+    return solver.to_problem_major(t).cpu().numpy()
 
 
 def dev_batch(solver, host: dict, want_gains=True):
