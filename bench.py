@@ -121,44 +121,36 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
 
 
 def cpu_baseline(cfg, B, iters, budget_s):
-    """The CPU oracle (port of the reference algorithm, oracle/ilqr_oracle.c) on the host cores of
-    this box, same synthetic workload, same fixed iteration count, bounded sample."""
-    from concurrent.futures import ThreadPoolExecutor
+    """The CPU oracle (a port of the reference algorithm, oracle/ilqr_oracle.c, OpenMP over the
+    batch) on the host cores of this box: same synthetic workload, same fixed iteration count,
+    bounded sample (about `budget_s` seconds of wall time)."""
     from ilqr_iterative_tasks_amd import workloads
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
-    host = workloads.make_batch(cfg, min(B, 4096))
+    host = workloads.make_batch(cfg, 8192)
 
-    def run(sl):
+    def run(nprob):
+        sl = slice(0, nprob)
+        t0 = time.perf_counter()
         orc.ilqr_batch(cfg, host["X"][sl], host["U"][sl], host["x_term"][sl], host["lamb"][sl],
                        host["obs"][sl], max_iter=iters, early_exit=False, want_gains=True)
+        return time.perf_counter() - t0
 
-    # calibrate on one thread
-    n_cal = 32
+    orc.set_threads(1)
+    t1 = run(256)
+    one_thread = 256 * iters / t1
+    threads = orc.set_threads(cores)
+    run(min(8192, 64 * threads))  # warm the thread pool
+    t_all = run(8192)
+    sweeps = max(1, min(200, int(budget_s / max(t_all, 1e-6))))
     t0 = time.perf_counter()
-    run(slice(0, n_cal))
-    per_problem = (time.perf_counter() - t0) / n_cal
-    # all cores: ctypes releases the GIL during the C call; every thread sweeps its own slice
-    # `reps` times so that the whole sample is about `budget_s` seconds of wall time
-    n_per = max(8, len(host["X"]) // cores)
-    reps = max(1, int(budget_s / (n_per * per_problem)))
-    slices = [slice(i * n_per, (i + 1) * n_per) for i in range(cores)]
-
-    def worker(sl):
-        for _ in range(reps):
-            run(sl)
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(worker, slices))
+    for _ in range(sweeps):
+        run(8192)
     dt = time.perf_counter() - t0
-    total = n_per * cores * reps
-    t0 = time.perf_counter()
-    run(slices[0])
-    one_thread = n_per * iters / (time.perf_counter() - t0)
-    return dict(value=total * iters / dt, unit="iLQR iterations/s", cores=cores, kind="port",
-                sample=f"{n_per * cores} problems x {iters} iterations x {reps} sweeps of the "
-                       f"bench workload on {cores} threads ({dt:.1f} s wall)",
+    return dict(value=8192 * sweeps * iters / dt, unit="iLQR iterations/s", cores=threads,
+                kind="port",
+                sample=f"8192 problems x {iters} iterations x {sweeps} sweeps of the bench "
+                       f"workload, OpenMP on {threads} threads ({dt:.1f} s wall)",
                 value_1thread=one_thread)
 
 

@@ -1,0 +1,234 @@
+"""i2LQR controller — host-side counterpart of the reference's `iLqr` (utils/base.py:305-479)
+with the same public surface: set_timestep / set_state / calc_input / get_input (ControlBase,
+utils/base.py:216-234), add_trajectory (:343-369) and the public `obstacle` attribute.
+
+The per-candidate `ilqr()` calls of the reference (`for id` / `for j` loops, :391-455) become
+batched solves on the GPU.  Two regularisation modes:
+
+  lamb_mode="chained"      the reference's exact semantics: inside one lap's candidate list the
+                           final lamb of candidate j seeds candidate j+1 (utils/base.py:393, :414),
+                           so candidates of one lap are solved in sequence; the laps of the safe
+                           set (independent, lamb is reset per lap) are batched.
+  lamb_mode="independent"  every candidate starts from ilqr_param.lamb: one launch per round over
+                           all (lap, candidate) pairs — the form that shards across GPUs
+                           (documented deviation; config-1 laps 121/54/28/23
+                           instead of 121/54/29/23).
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+
+import numpy as np
+
+from .params import X_DIM, U_DIM, config_from_params, obstacle_record
+
+
+class ControlBase:
+    def __init__(self):
+        self.time = 0.0
+        self.timestep = None
+        self.x = None
+        self.u = None
+        self.iters = 0
+
+    def set_timestep(self, timestep):
+        self.timestep = timestep
+
+    def set_state(self, x):
+        self.x = x
+
+    def calc_input(self):
+        pass
+
+    def get_input(self):
+        return self.u
+
+
+def _plant_step(x, u, dt):
+    """kinetic_bicycle(): systems/kinetic_bicycle.py:10-27 (host copy for the N <= 1 branch)."""
+    w = x[2] * dt + (u[0] * dt ** 2) / 2
+    return np.array([x[0] + np.cos(x[3]) * w, x[1] + np.sin(x[3]) * w, x[2] + u[0] * dt,
+                     x[3] + u[1] * dt])
+
+
+class iLqr(ControlBase):
+    def __init__(self, ilqr_param, obstacle=None, system_param=None, solver=None,
+                 lamb_mode="chained", verbose=False):
+        ControlBase.__init__(self)
+        assert lamb_mode in ("chained", "independent")
+        self.ilqr_param = ilqr_param
+        self.system_param = system_param
+        self.ss = []
+        self.u_ss = []
+        self.Qfun = []
+        self.ss_point_selected_id = []
+        self.x_terminal_guess = None
+        self.x_guess = None
+        self.iter = 0
+        self.iter_cost = []
+        self.cost = None
+        self.old_cost = None
+        self.old_iter = None
+        self.u_old = None
+        self.x_pred = None
+        self.u_pred = None
+        self.cost_improve = None
+        self.num_horizon = self.ilqr_param.num_horizon
+        self.matrix_Qterminal = self.ilqr_param.matrix_Qterminal
+        self.matrix_Q = self.ilqr_param.matrix_Q
+        self.matrix_R = self.ilqr_param.matrix_R
+        self.obstacle = obstacle
+        self.lamb_mode = lamb_mode
+        self.verbose = verbose
+        self._solver = solver
+        self.last_round = None  # diagnostics of the most recent calc_input (tests)
+
+    # -- safe set ---------------------------------------------------------------------------
+    def select_close_ss(self, iter, x0):
+        """k nearest safe-set columns in the 1-norm: utils/base.py:332-341."""
+        x = self.ss[iter]
+        diff = x - np.asarray(x0, float).reshape(-1, 1)
+        norm = np.linalg.norm(diff, 1, axis=0)
+        index_min_norm = np.argsort(norm)
+        return index_min_norm[0: self.ilqr_param.num_ss_points]
+
+    def add_trajectory(self, x, u):
+        """utils/base.py:343-369.  x[T, n], u[T-1, m] of a finished lap."""
+        self.ss.append(deepcopy(x.T))
+        self.u_ss.append(deepcopy(u.T))
+        self.Qfun.append(deepcopy(np.arange(x.shape[0] - 1, -1, -1)))
+        self.num_horizon = self.ilqr_param.num_horizon
+        self.x_terminal_guess = x.T[:, self.num_horizon]
+        self.cost = self.Qfun[-1][0]
+        self.iter_cost.append(deepcopy(self.cost))
+        self.old_cost = self.cost + 1
+        self.old_iter = self.iter
+        self.x_sol = x.T[:, 0: (self.num_horizon + 1)]
+        self.u_sol = u.T[:, 0: (self.num_horizon)]
+        self.cost_improve = -1
+        self.iter = self.iter + 1
+        self.ss_point_selected_id = []
+        min_cost = np.min(self.iter_cost)
+        for id in range(self.iter):
+            iter_cost = np.shape(self.ss[id])[1] - 1
+            if self.ilqr_param.all_ss_point:
+                self.ss_point_selected_id.append(np.arange(0, self.ss[id].shape[1]))
+            else:
+                self.ss_point_selected_id.append(np.arange(
+                    iter_cost - min_cost + self.num_horizon,
+                    iter_cost - min_cost + self.num_horizon + self.ilqr_param.num_ss_points))
+
+    # -- solve --------------------------------------------------------------------------------
+    def _get_solver(self):
+        if self._solver is None:
+            from .iterative_ilqr import default_solver
+            self._solver = default_solver()  # HIP; raises without a GPU / built extension
+        return self._solver
+
+    def _relax_cost(self, x_end, x_terminal, cost_terminal, outer_iter, num_horizon):
+        """Relaxed terminal cost of one candidate: utils/base.py:427-437."""
+        nrm = np.linalg.norm([x_end - x_terminal])
+        p = self.ilqr_param
+        for i in range(1, p.max_relax_iter + 1):
+            if nrm <= 80.0 * i / (10 ** outer_iter):
+                return cost_terminal + num_horizon + 100 * i
+            elif nrm > 80.0 * p.max_relax_iter / (10 ** outer_iter):
+                return float("Inf")
+        return float("Inf")  # NaN norm (the reference would leave cost_it unset)
+
+    def solve(self, x0, candidates, outer_iter):
+        """Batched replacement of the `for id` / `for j` loops (utils/base.py:391-455).
+        candidates: list over laps of (lap_id, index_ss_points).  Returns per lap the lists
+        (cost_iter, U list, X list)."""
+        p = self.ilqr_param
+        N = self.num_horizon
+        xtarget = np.zeros(X_DIM)
+        cfg = config_from_params(p, self.system_param, N, self.timestep, xtarget)
+        obs = None if self.obstacle is None else obstacle_record(self.obstacle)
+        solver = self._get_solver()
+        n_laps = len(candidates)
+        width = max(len(idx) for _, idx in candidates)
+        U = [[None] * len(idx) for _, idx in candidates]
+        X = [[None] * len(idx) for _, idx in candidates]
+        if self.lamb_mode == "independent":
+            x_terms = np.stack([self.ss[lap][:, j] for lap, idx in candidates for j in idx])
+            out = solver.solve(cfg, x0, x_terms, np.full(len(x_terms), float(p.lamb)), obs)
+            pos = 0
+            for a, (lap, idx) in enumerate(candidates):
+                for c in range(len(idx)):
+                    U[a][c], X[a][c] = out["U"][pos], out["X"][pos]
+                    pos += 1
+        else:
+            lamb = np.full(n_laps, float(p.lamb))  # reset per lap: utils/base.py:393
+            for c in range(width):
+                rows = [a for a, (_, idx) in enumerate(candidates) if c < len(idx)]
+                x_terms = np.stack([self.ss[candidates[a][0]][:, candidates[a][1][c]] for a in rows])
+                out = solver.solve(cfg, x0, x_terms, lamb[rows], obs)
+                for r, a in enumerate(rows):
+                    U[a][c], X[a][c] = out["U"][r], out["X"][r]
+                    lamb[a] = out["lamb"][r]  # candidate j+1 starts from candidate j's lamb
+        cost = [[self._relax_cost(X[a][c][:, -1], self.ss[lap][:, j], self.Qfun[lap][j],
+                                  outer_iter, N)
+                 for c, j in enumerate(idx)] for a, (lap, idx) in enumerate(candidates)]
+        return cost, U, X
+
+    def calc_input(self):
+        """utils/base.py:371-479."""
+        p = self.ilqr_param
+        num_horizon = self.num_horizon
+        min_iter = np.max([0, self.iter - p.num_ss_iter])
+        rounds = []
+        if self.num_horizon < p.num_horizon:
+            # horizon-shrinking replay of the last plan: utils/base.py:377-382
+            self.u_pred = self.u_old
+            self.u = self.u_pred[:, 0]
+            self.u_old = self.u_pred[:, 1:]
+            self.num_horizon = self.num_horizon - 1
+        else:
+            for it in range(p.max_outloop_iter):
+                candidates = []
+                for id in range(min_iter, self.iter):
+                    self.x_guess = self.x if it == 0 else self.x_pred[:, -1]
+                    candidates.append((id, self.select_close_ss(id, self.x_guess)))
+                if self.num_horizon > 1:
+                    cost_list, u_pred, x_pred = self.solve(np.asarray(self.x, float), candidates, it)
+                else:
+                    # N <= 1: apply the stored input and test reachability: utils/base.py:438-450
+                    cost_list, u_pred, x_pred = [], [], []
+                    for id, idx in candidates:
+                        cl, ul, xl = [], [], []
+                        for j in idx:
+                            uvar = np.zeros((U_DIM, num_horizon))
+                            xvar = np.zeros((X_DIM, num_horizon + 1))
+                            xvar[:, 0] = self.x
+                            x_next = _plant_step(np.asarray(self.x, float), self.u_old[:, 0],
+                                                 self.timestep)
+                            xvar[:, -1] = x_next
+                            uvar[:, 0] = self.u_old[:, 0]
+                            ok = np.linalg.norm([x_next - self.ss[id][:, j]]) <= p.reach_error
+                            cl.append(1 + self.Qfun[id][j] if ok else float("Inf"))
+                            ul.append(uvar)
+                            xl.append(xvar)
+                        cost_list.append(cl), u_pred.append(ul), x_pred.append(xl)
+                # pick: list-of-lists min is lexicographic, then first min inside that lap's
+                # list (utils/base.py:462-465)
+                best_iter_loc_ss = cost_list.index(min(cost_list))
+                cost_vec = cost_list[best_iter_loc_ss]
+                best_time = cost_vec.index(min(cost_vec))
+                best_iter = best_iter_loc_ss + min_iter
+                self.u_pred = u_pred[best_iter_loc_ss][best_time]
+                self.x_pred = x_pred[best_iter_loc_ss][best_time]
+                self.u = self.u_pred[:, 0]
+                self.x_terminal_guess = self.x_pred[:, -1]
+                if self.num_horizon > 1:
+                    self.u_old = self.u_pred[:, 1:]
+                rounds.append(dict(index=[np.array(idx) for _, idx in candidates],
+                                   cost=cost_list, best=(best_iter_loc_ss, best_time)))
+                if it == 2:
+                    # shrink the horizon when the chosen terminal point is the lap's last point
+                    if (candidates[best_iter_loc_ss][1][best_time] + 1) > (
+                            self.ss[best_iter].shape[1] - 1):
+                        self.num_horizon = self.num_horizon - 1
+                    break
+        self.last_round = rounds
+        self.time += self.timestep

@@ -649,8 +649,9 @@ void orc_ilqr_batch(const cfg_t* c, int64_t B, int max_iter, int early_exit, dou
                     const double* x_term, double* lamb, const double* obs, double* K, double* k,
                     double* cost, int32_t* iters, int32_t* status) {
   const int n = c->n, m = c->m, N = c->N;
-  double Ktmp[MAXM * MAXN * MAXH], ktmp[MAXM * MAXH];
+#pragma omp parallel for schedule(dynamic, 8)
   for (int64_t b = 0; b < B; b++) {
+    double Ktmp[MAXM * MAXN * MAXH], ktmp[MAXM * MAXH];
     int st = 0;
     double cst = 0.0;
     double* Kb = K ? K + b * (int64_t)(m * n * N) : Ktmp;
@@ -713,3 +714,15 @@ void orc_quu_inverse_reg(int m, const double* Quu, double lamb, double* inv) {
   quu_inverse_reg(m, Quu, lamb, inv);
 }
 int orc_config_size(void) { return (int)sizeof(cfg_t); }
+
+/* Threads used by orc_ilqr_batch (OpenMP); 0 restores the runtime default.  Returns the count in
+ * effect. */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+#else
+int orc_set_threads(int n) { (void)n; return 1; }
+#endif

@@ -56,6 +56,11 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def set_threads(n: int) -> int:
+    """OpenMP threads of the batched drivers (ilqr_batch); returns the count in effect."""
+    return int(lib().orc_set_threads(int(n)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

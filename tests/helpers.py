@@ -57,3 +57,27 @@ def problems_from_calls(g, N, n=4, m=2):
     X[:, :, 0] = g["x0"]
     return dict(X=X, U=np.zeros((B, m, N)), x_term=np.array(g["x_term"], float),
                 lamb=np.array(g["lamb_in"], float), obs=np.array(g["obs"], float))
+
+
+class OracleCandidateSolver:
+    """Test double for control.iterative_ilqr.HipCandidateSolver backed by the CPU oracle — lets
+    the host-side controller logic run in the CPU-only suite.  Lives in tests/ on purpose: the
+    product package never imports the oracle."""
+
+    def __init__(self):
+        self.calls = 0
+        self.problems = 0
+
+    def solve(self, cfg, x0, x_terms, lamb0, obs_rec, U0=None):
+        from oracle import oracle as orc
+        x_terms = np.atleast_2d(np.asarray(x_terms, float))
+        B = x_terms.shape[0]
+        X = np.zeros((B, cfg.n, cfg.N + 1))
+        X[:, :, 0] = np.asarray(x0, float)
+        U = np.zeros((B, cfg.m, cfg.N)) if U0 is None else np.asarray(U0, float).reshape(
+            B, cfg.m, cfg.N)
+        obs = None if obs_rec is None else np.tile(np.asarray(obs_rec, float), (B, 1))
+        self.calls += 1
+        self.problems += B
+        return orc.ilqr_batch(cfg, X, U, x_terms, np.asarray(lamb0, float).reshape(B), obs,
+                              want_gains=False)
