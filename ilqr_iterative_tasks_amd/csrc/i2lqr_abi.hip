@@ -96,13 +96,21 @@ template <class T, class Sys> struct Launch {
                   h->cfg.N, h->lds_bytes);
     if (h->lds_bytes > 64 * 1024) {
       const int bytes = (int)h->lds_bytes;
-      HIP_TRY(hipFuncSetAttribute((const void*)k_iterate<T, Sys, LANES>,
+      HIP_TRY(hipFuncSetAttribute((const void*)k_iterate<T, Sys, LANES, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_backward<T, Sys, LANES>,
+      HIP_TRY(hipFuncSetAttribute((const void*)k_iterate<T, Sys, LANES, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_forward<T, Sys, LANES>,
+      HIP_TRY(hipFuncSetAttribute((const void*)k_backward<T, Sys, LANES, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_rollout<T, Sys, LANES>,
+      HIP_TRY(hipFuncSetAttribute((const void*)k_backward<T, Sys, LANES, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_forward<T, Sys, LANES, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_forward<T, Sys, LANES, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_rollout<T, Sys, LANES, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_rollout<T, Sys, LANES, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     return I2LQR_OK;
@@ -126,24 +134,38 @@ template <class T, class Sys> struct Launch {
     a.k = (T*)k;
     a.iters = iters;
     a.status = status;
-    hipLaunchKernelGGL((k_iterate<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, a);
+    if (c.flags)
+      hipLaunchKernelGGL((k_iterate<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes, s,
+                         c, a);
+    else
+      hipLaunchKernelGGL((k_iterate<T, Sys, LANES, false>), dim3(grid(B)), dim3(64), h->lds_bytes,
+                         s, c, a);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
   static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      hipStream_t s) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
-    hipLaunchKernelGGL((k_rollout<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
-                       (T*)X, (T*)U, (const T*)x_term, (T*)cost);
+    if (c.flags)
+      hipLaunchKernelGGL((k_rollout<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes, s,
+                         c, B, (T*)X, (T*)U, (const T*)x_term, (T*)cost);
+    else
+      hipLaunchKernelGGL((k_rollout<T, Sys, LANES, false>), dim3(grid(B)), dim3(64), h->lds_bytes,
+                         s, c, B, (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
   static int backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
                       const void* lamb, const void* obs, void* K, void* k, hipStream_t s) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
-    hipLaunchKernelGGL((k_backward<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
-                       (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb, (const T*)obs,
-                       (T*)K, (T*)k);
+    if (c.flags)
+      hipLaunchKernelGGL((k_backward<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes,
+                         s, c, B, (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
+                         (const T*)obs, (T*)K, (T*)k);
+    else
+      hipLaunchKernelGGL((k_backward<T, Sys, LANES, false>), dim3(grid(B)), dim3(64), h->lds_bytes,
+                         s, c, B, (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
+                         (const T*)obs, (T*)K, (T*)k);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -151,9 +173,14 @@ template <class T, class Sys> struct Launch {
                      const void* K, const void* k, void* Xn, void* Un, void* cost_new,
                      hipStream_t s) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
-    hipLaunchKernelGGL((k_forward<T, Sys, LANES>), dim3(grid(B)), dim3(64), h->lds_bytes, s, c, B,
-                       (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
-                       (T*)Xn, (T*)Un, (T*)cost_new);
+    if (c.flags)
+      hipLaunchKernelGGL((k_forward<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes, s,
+                         c, B, (const T*)X, (const T*)U, (const T*)x_term, (const T*)K,
+                         (const T*)k, (T*)Xn, (T*)Un, (T*)cost_new);
+    else
+      hipLaunchKernelGGL((k_forward<T, Sys, LANES, false>), dim3(grid(B)), dim3(64), h->lds_bytes,
+                         s, c, B, (const T*)X, (const T*)U, (const T*)x_term, (const T*)K,
+                         (const T*)k, (T*)Xn, (T*)Un, (T*)cost_new);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }

@@ -179,27 +179,25 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     T l2 = (l1 != T(0)) ? (a * d - bq * cc) / l1 : T(0);
     if (s == T(0)) { l1 = mean; l2 = mean; }
     const T w[2] = {l1, l2};
-    T V[4];
+    T vx[2], vy[2], sc[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
+      // eigenvector of w[e] = a non-zero column of (Quu - w[other] I); its normalisation is
+      // folded into the eigenvalue division: v v^T / (|v|^2 w)
       const T lo = w[1 - e];
       const T c0x = a - lo, c0y = cc, c1x = bq, c1y = d - lo;
       const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
       const bool firstc = n0 >= n1;
-      T vx = firstc ? c0x : c1x, vy = firstc ? c0y : c1y, nn = firstc ? n0 : n1;
-      if (nn == T(0)) { vx = (e == 0) ? T(1) : T(0); vy = (e == 0) ? T(0) : T(1); nn = T(1); }
-      const T r = T(1) / t_sqrt(nn);
-      V[0 * 2 + e] = vx * r;
-      V[1 * 2 + e] = vy * r;
+      T ex = firstc ? c0x : c1x, ey = firstc ? c0y : c1y, nn = firstc ? n0 : n1;
+      if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
+      vx[e] = ex;
+      vy[e] = ey;
+      sc[e] = T(1) / (nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
     }
-    T wr[2];
-#pragma unroll
-    for (int e = 0; e < 2; e++) wr[e] = T(1) / ((w[e] < T(0) ? T(0) : w[e]) + lamb);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-        inv[i * 2 + j] = V[i * 2 + 0] * wr[0] * V[j * 2 + 0] + V[i * 2 + 1] * wr[1] * V[j * 2 + 1];
+    inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
+    inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
+    inv[2] = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
+    inv[3] = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
@@ -226,21 +224,32 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       Va[0][0] += o[2]; Va[0][1] += o[3]; Va[1][0] += o[3]; Va[1][1] += o[4];
       Va[0][n] += o[0]; Va[1][n] += o[1];
     }
+    // software pipeline: the inputs of step t-1 are requested before step t is computed, so the
+    // HBM latency of the (independent) trajectory reads hides under the Riccati arithmetic
+    constexpr int NXT = HASQR ? n : 2;  // x_t is only needed for the obstacle (x, y) unless Q != 0
+    T xe_n[n], u_n[m], tr_n[NT], xt_n[NXT];
+    auto load_step = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < n; i++) xe_n[i] = X[ix(i, t + 1)];
+#pragma unroll
+      for (int a = 0; a < m; a++) u_n[a] = U[iu(a, t)];
+#pragma unroll
+      for (int q = 0; q < NT; q++) tr_n[q] = TR[ix(q, t + 1)];
+#pragma unroll
+      for (int i = 0; i < NXT; i++) xt_n[i] = X[ix(i, t)];
+    };
+    load_step(N - 1);
     for (int t = N - 1; t >= 0; t--) {
       T xe[n], u[m], tr[NT], jv[NV], o[5], xt[n];
 #pragma unroll
-      for (int i = 0; i < n; i++) xe[i] = X[ix(i, t + 1)];
+      for (int i = 0; i < n; i++) xe[i] = xe_n[i];
 #pragma unroll
-      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) u[a] = u_n[a];
 #pragma unroll
-      for (int q = 0; q < NT; q++) tr[q] = TR[ix(q, t + 1)];
-      if constexpr (HASQR) {
+      for (int q = 0; q < NT; q++) tr[q] = tr_n[q];
 #pragma unroll
-        for (int i = 0; i < n; i++) xt[i] = X[ix(i, t)];
-      } else {
-        xt[0] = X[ix(0, t)];
-        xt[1] = X[ix(1, t)];
-      }
+      for (int i = 0; i < NXT; i++) xt[i] = xt_n[i];
+      if (t > 0) load_step(t - 1);
       Sys::jac_var(c, xe, u, tr, jv);
       obstacle(ob, xt[0], xt[1], t, o);
       // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
@@ -362,14 +371,38 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       Xn[ix(i, 0)] = x[i];
     }
     T cost = T(0);
+    // software pipeline: the nominal state, input and gains of step t+1 do not depend on the
+    // candidate state, so they are requested one step ahead of the serial rollout
+    T xo_n[n], uo_n[m], kk_n[m][n + 1];
+    auto load_step = [&](int t) {
+#pragma unroll
+      for (int j = 0; j < n; j++) xo_n[j] = X[ix(j, t)];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        uo_n[a] = U[iu(a, t)];
+#pragma unroll
+        for (int j = 0; j < n; j++) kk_n[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
+        kk_n[a][n] = gk[iu(a, t)];
+      }
+    };
+    load_step(0);
     for (int t = 0; t < N; t++) {
+      T xo[n], uo[m], kk[m][n + 1];
+#pragma unroll
+      for (int j = 0; j < n; j++) xo[j] = xo_n[j];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        uo[a] = uo_n[a];
+#pragma unroll
+        for (int j = 0; j <= n; j++) kk[a][j] = kk_n[a][j];
+      }
+      if (t + 1 < N) load_step(t + 1);
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++)
-          acc = t_fma(gK[(((int64_t)a * n + j) * N + t) * B + b], x[j] - X[ix(j, t)], acc);
-        u[a] = clip(U[iu(a, t)] + gk[iu(a, t)] + acc, -c.u_max[a], c.u_max[a]);
+        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
+        u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
         Un[iu(a, t)] = u[a];
       }
       Sys::trig(x, tr);

@@ -22,15 +22,69 @@ template <> __device__ __forceinline__ float t_sin<float>(float x) { return sinf
 template <class T> __device__ __forceinline__ T t_cos(T x);
 template <> __device__ __forceinline__ double t_cos<double>(double x) { return cos(x); }
 template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf(x); }
+// sin and cos of one argument.  fp64: Cody-Waite reduction by pi/2 in three FMA steps (exact for
+// |x| < 2^20 pi/2) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]
+// (<= ~1 ulp each); about a third of the instructions of the general-range library routine, which
+// stays as the fallback for |x| >= 1e5.  fp32: the library routine.
 template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
-  sincos(x, s, c);
+  if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {
+    sincos(x, s, c);
+    return;
+  }
+  const double kf = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = __builtin_fma(-kf, 1.57079632679489655800e+00, x);      // pi/2 hi
+  r = __builtin_fma(-kf, 6.12323399573676603587e-17, r);            // pi/2 mid
+  r = __builtin_fma(-kf, -1.49738490485916983327e-33, r);           // pi/2 lo
+  const int q = (int)kf;
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(ps * z, r, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+  const bool swap = q & 1;
+  const double sv = swap ? cr : sr, cv = swap ? sr : cr;
+  *s = (q & 2) ? -sv : sv;
+  *c = ((q + 1) & 2) ? -cv : cv;
 }
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
   sincosf(x, s, c);
 }
 template <class T> __device__ __forceinline__ T t_exp(T x);
-template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+// fp64 exp: x = k ln2 + r (Cody-Waite), degree-13 Horner on |r| <= ln2/2, v_ldexp (<= ~2 ulp;
+// overflow / underflow / NaN through ldexp and the clamped exponent).
+template <> __device__ __forceinline__ double t_exp<double>(double x0) {
+  const double x = x0 < -746.0 ? -746.0 : (x0 > 710.0 ? 710.0 : x0);  // NaN passes through
+  const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;  // 1/13!
+  p = __builtin_fma(p, r, 2.0876756987868098979e-09);
+  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
+  p = __builtin_fma(p, r, 2.7557319223985892511e-06);
+  p = __builtin_fma(p, r, 2.4801587301587301566e-05);
+  p = __builtin_fma(p, r, 1.9841269841269841253e-04);
+  p = __builtin_fma(p, r, 1.3888888888888889419e-03);
+  p = __builtin_fma(p, r, 8.3333333333333332177e-03);
+  p = __builtin_fma(p, r, 4.1666666666666664354e-02);
+  p = __builtin_fma(p, r, 1.6666666666666665741e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const double e = __builtin_ldexp(p, (int)kf);
+  return x0 < -745.14 ? 0.0 : (x0 > 709.79 ? __builtin_inf() : e);
+}
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
 template <class T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }

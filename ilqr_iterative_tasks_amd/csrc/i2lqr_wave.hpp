@@ -75,7 +75,7 @@ template <class T> __device__ __forceinline__ T clip(T v, T lo, T hi) {
 template <class Sys> struct Layout {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
   int N;
-  int X0, X1, U0, U1, Kk, trg, lu, luu, ob, Va, F, T1, H, g, total;
+  int X0, X1, U0, U1, Kk, trg, lu, luu, ob, Va, F, T1, H, g, Qt, total;
   __host__ __device__ explicit Layout(int N_) : N(N_) {
     int o = 0;
     X0 = o; o += n * (N + 1);
@@ -92,6 +92,7 @@ template <class Sys> struct Layout {
     T1 = o; o += W * (n + 1);
     H = o; o += W * W;
     g = o; o += W;
+    Qt = o; o += n * n;
     total = (o + 1) & ~1;  // keep every problem slice 16-byte aligned for fp64
   }
 };
@@ -99,7 +100,7 @@ template <class Sys> struct Layout {
 // ---------------------------------------------------------------------------------------------
 // The per-problem worker.  All LANES lanes of a problem execute every method together.
 // ---------------------------------------------------------------------------------------------
-template <class T, class Sys, int LANES> struct Worker {
+template <class T, class Sys, int LANES, bool HASQR> struct Worker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
   using Cfg = DevCfg<T, n, m>;
   const Cfg& c;
@@ -127,21 +128,28 @@ template <class T, class Sys, int LANES> struct Worker {
 
   __device__ __forceinline__ T stage_cost(const T (&x)[n], const T* ref, const T (&u)[m]) const {
     T l = T(0);
-    if (c.flags & FLAG_HAS_Q) {
+    if constexpr (HASQR) {
       T d[n];
 #pragma unroll
       for (int i = 0; i < n; i++) d[i] = x[i] - ref[i];
       l += quad_form<n>(c.Q, d);
+      l += quad_form<m>(c.R, u);
     }
-    if (c.flags & FLAG_HAS_R) l += quad_form<m>(c.R, u);
     return l;
   }
 
+  // Q_terminal is staged in LDS (stage_consts): the n^2 uniform weights would otherwise occupy
+  // 2 n^2 SGPRs for the whole kernel and spill
   __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
     T d[n];
 #pragma unroll
     for (int i = 0; i < n; i++) d[i] = x[i] - xT[i];
-    return quad_form<n>(c.Qt, d);
+    return quad_form<n>(S + L.Qt, d);
+  }
+
+  // once per kernel: constants that live in LDS
+  __device__ __forceinline__ void stage_consts() const {
+    for (int e = sl; e < n * n; e += LANES) S[L.Qt + e] = c.Qt[e];
   }
 
   // -- HBM <-> LDS ---------------------------------------------------------------------------
@@ -180,8 +188,16 @@ template <class T, class Sys, int LANES> struct Worker {
     }
   }
 
+  // publish an n-vector held (redundantly) in registers: lane 0 stores it contiguously
+  template <int D> __device__ __forceinline__ void publish(int off, const T (&v)[D]) const {
+    if (sl == 0) {
+#pragma unroll
+      for (int i = 0; i < D; i++) S[off + i] = v[i];
+    }
+  }
+
   // -- nominal rollout + cost: control/iterative_ilqr.py:32-48 -------------------------------
-  // Every lane of the problem runs the (serial) recursion redundantly; lanes < n / < m publish.
+  // Every lane of the problem runs the (serial) recursion redundantly; lane 0 publishes.
   __device__ __forceinline__ T rollout(int Xo, int Uo, const T (&xT)[n]) const {
     T x[n], u[m], xn[n];
 #pragma unroll
@@ -190,9 +206,9 @@ template <class T, class Sys, int LANES> struct Worker {
     for (int t = 0; t < N; t++) {
 #pragma unroll
       for (int a = 0; a < m; a++) u[a] = clip(S[Uo + t * m + a], -c.u_max[a], c.u_max[a]);
-      if (sl < m) S[Uo + t * m + sl] = pick<T, m>(u, sl);
+      publish<m>(Uo + t * m, u);
       Sys::step(c, x, u, xn);
-      if (sl < n) S[Xo + (t + 1) * n + sl] = pick<T, n>(xn, sl);
+      publish<n>(Xo + (t + 1) * n, xn);
       cost = cost + stage_cost(x, c.xtarget, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
@@ -200,6 +216,23 @@ template <class T, class Sys, int LANES> struct Worker {
     cost = cost + terminal_cost(x, xT);
     wave_sync();
     return cost;
+  }
+
+  // nominal cost of a trajectory that is already rolled out in LDS (needed only when Q != 0:
+  // the nominal stage cost is measured to xtarget, the forward one to x_terminal)
+  __device__ __forceinline__ T nominal_cost(int Xo, int Uo, const T (&xT)[n]) const {
+    T x[n], u[m];
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = S[Xo + t * n + i];
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = S[Uo + t * m + a];
+      cost = cost + stage_cost(x, c.xtarget, u);
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[Xo + N * n + i];
+    return cost + terminal_cost(x, xT);
   }
 
   // -- per-step caches, parallel over t: trig of x_{t+1}, input barrier of u_t, obstacle barrier
@@ -222,7 +255,7 @@ template <class T, class Sys, int LANES> struct Worker {
           const T e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
           const T e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
           T lu = T(0);
-          if (c.flags & FLAG_HAS_R) {
+          if constexpr (HASQR) {
 #pragma unroll
             for (int b = 0; b < m; b++) lu += T(2) * c.R[a * m + b] * u[b];
           }
@@ -261,8 +294,11 @@ template <class T, class Sys, int LANES> struct Worker {
     wave_sync();
   }
 
-  // Regularised inverse of Q_uu: control/iterative_ilqr.py:118-123.  m == 2 follows the
-  // reference's NON-symmetric eig (unit-norm eigenvectors, not orthogonalised) in closed form;
+  // Regularised inverse of Q_uu: control/iterative_ilqr.py:118-123
+  //   w, V = eig(Quu); w[w<0] = 0; w += lamb; inv = V diag(1/w) V^T.
+  // m == 2 follows the reference's NON-symmetric eig (unit-norm eigenvectors that are not
+  // orthogonalised) in closed form; the normalisation is folded into the eigenvalue division
+  // (v v^T / (|v|^2 w) instead of (v/|v|)(v/|v|)^T / w: one sqrt and three divisions in all).
   // m > 2 runs cyclic Jacobi on the symmetrised matrix (no reference counterpart).
   __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
                                               T (&inv)[m * m]) const {
@@ -276,27 +312,24 @@ template <class T, class Sys, int LANES> struct Worker {
       T l2 = (l1 != T(0)) ? (a * d - b * cc) / l1 : T(0);
       if (s == T(0)) { l1 = mean; l2 = mean; }
       const T w[2] = {l1, l2};
-      T V[4];
+      T vx[2], vy[2], sc[2];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
+        // eigenvector of w[e] = a non-zero column of (Quu - w[other] I)  (Cayley-Hamilton)
         const T lo = w[1 - e];
         const T c0x = a - lo, c0y = cc, c1x = b, c1y = d - lo;
         const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
         const bool first = n0 >= n1;
-        T vx = first ? c0x : c1x, vy = first ? c0y : c1y, nn = first ? n0 : n1;
-        if (nn == T(0)) { vx = (e == 0) ? T(1) : T(0); vy = (e == 0) ? T(0) : T(1); nn = T(1); }
-        const T r = T(1) / t_sqrt(nn);
-        V[0 * 2 + e] = vx * r;
-        V[1 * 2 + e] = vy * r;
+        T ex = first ? c0x : c1x, ey = first ? c0y : c1y, nn = first ? n0 : n1;
+        if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
+        vx[e] = ex;
+        vy[e] = ey;
+        sc[e] = T(1) / (nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
       }
-      T wr[2];
-#pragma unroll
-      for (int e = 0; e < 2; e++) wr[e] = T(1) / ((w[e] < T(0) ? T(0) : w[e]) + lamb);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          inv[i * 2 + j] = V[i * 2 + 0] * wr[0] * V[j * 2 + 0] + V[i * 2 + 1] * wr[1] * V[j * 2 + 1];
+      inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
+      inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
+      inv[2] = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
+      inv[3] = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
     } else {
       T Sm[m * m], V[m * m];
 #pragma unroll
@@ -357,32 +390,63 @@ template <class T, class Sys, int LANES> struct Worker {
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
-  // Needs prep() on the same trajectory.  Leaves the gains in LDS (Kk).
+  // Needs prep() on the same trajectory.  Leaves the gains in LDS (Kk).  Three LDS round trips
+  // per horizon step; every lane's role in each phase is fixed, so its indices are hoisted.
   __device__ __forceinline__ void backward(int Xo, int Uo, const T (&xT)[n], T lamb) const {
+    constexpr int NA = n + 1;                               // width of [Vxx | Vx], [K | k]
+    constexpr int P1N = W * NA, P2N = W * W, P4N = n * NA;  // elements per phase
+    constexpr int P1P = (P1N + LANES - 1) / LANES, P2P = (P2N + LANES - 1) / LANES,
+                  P4P = (P4N + LANES - 1) / LANES, VP = (Sys::NVAR + LANES - 1) / LANES,
+                  GP = (W + LANES - 1) / LANES;
     // constant pattern of F = [A | B]; the state-dependent entries are refreshed every step
     for (int e = sl; e < n * W; e += LANES) S[L.F + e] = Sys::jac_const(c, e / W, e % W);
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150
-    for (int e = sl; e < n * (n + 1); e += LANES) {
-      const int i = e / (n + 1), j = e - i * (n + 1);
+    for (int e = sl; e < P4N; e += LANES) {
+      const int i = e / NA, j = e - i * NA;
       T v;
       if (j < n) {
-        v = T(2) * c.Qt[i * n + j];
+        v = T(2) * S[L.Qt + i * n + j];
         if (i < 2 && j < 2) v += S[L.ob + N * 5 + 2 + i + j];
       } else {
         v = T(0);
 #pragma unroll
-        for (int r = 0; r < n; r++) v += T(2) * c.Qt[i * n + r] * (S[Xo + N * n + r] - xT[r]);
+        for (int r = 0; r < n; r++) v += T(2) * S[L.Qt + i * n + r] * (S[Xo + N * n + r] - xT[r]);
         if (i < 2) v += S[L.ob + N * 5 + i];
       }
       S[L.Va + e] = v;
     }
-    wave_sync();
-
-    // lanes that own a varying Jacobian entry
-    constexpr int VPASS = (Sys::NVAR + LANES - 1) / LANES;
-    int var_at[VPASS];
+    // fixed lane roles
+    int var_at[VP];
 #pragma unroll
-    for (int r = 0; r < VPASS; r++) var_at[r] = Sys::var_idx(sl + r * LANES);
+    for (int r = 0; r < VP; r++) var_at[r] = Sys::var_idx(sl + r * LANES);
+    int p1_f[P1P], p1_v[P1P];    // column a of F, column j of [Vxx|Vx]
+#pragma unroll
+    for (int r = 0; r < P1P; r++) {
+      const int e = sl + r * LANES, a = e / NA, j = e - a * NA;
+      p1_f[r] = L.F + a;
+      p1_v[r] = L.Va + j;
+    }
+    int p2_t[P2P], p2_f[P2P], p2_kind[P2P];  // row a of T1, column b of F, which l-term
+    T p2_const[P2P];
+#pragma unroll
+    for (int r = 0; r < P2P; r++) {
+      const int e = sl + r * LANES, a = e / W, b = e - a * W;
+      p2_t[r] = L.T1 + a * NA;
+      p2_f[r] = L.F + b;
+      // kind: -1 unused (Qxu / out of range), 0 plain, 1 obstacle block (a,b < 2), 2 luu diagonal
+      int kind = 0;
+      if (e >= P2N || (a < n && b >= n)) kind = -1;
+      else if (a < 2 && b < 2) kind = 1;
+      else if (a >= n && a == b) kind = 2;
+      p2_kind[r] = kind;
+      T lc = T(0);
+      if constexpr (HASQR) {
+        if (e < P2N && a < n && b < n) lc = T(2) * c.Q[a * n + b];
+        if (e < P2N && a >= n && b >= n) lc = T(2) * c.R[(a - n) * m + (b - n)];
+      }
+      p2_const[r] = lc;
+    }
+    wave_sync();
 
     for (int t = N - 1; t >= 0; t--) {
       // P0: refresh F at (x_{t+1}, u_t): control/iterative_ilqr.py:92-99
@@ -396,89 +460,100 @@ template <class T, class Sys, int LANES> struct Worker {
         for (int q = 0; q < NT; q++) tr[q] = S[L.trg + t * NT + q];
         Sys::jac_var(c, xe, u, tr, jv);
 #pragma unroll
-        for (int r = 0; r < VPASS; r++) {
+        for (int r = 0; r < VP; r++) {
           const int v = sl + r * LANES;
           if (v < Sys::NVAR) S[L.F + var_at[r]] = pick<T, Sys::NVAR>(jv, v);
         }
       }
       wave_sync();
       // P1: T1 = F^T [Vxx | Vx]   ((n+m) x (n+1)); f.T @ V of control/iterative_ilqr.py:112-116
-      for (int e = sl; e < W * (n + 1); e += LANES) {
-        const int a = e / (n + 1), j = e - a * (n + 1);
-        T acc = T(0);
 #pragma unroll
-        for (int i = 0; i < n; i++)
-          acc = t_fma(S[L.F + i * W + a], S[L.Va + i * (n + 1) + j], acc);
-        S[L.T1 + e] = acc;
+      for (int r = 0; r < P1P; r++) {
+        if (sl + r * LANES < P1N) {
+          T acc = T(0);
+#pragma unroll
+          for (int i = 0; i < n; i++) acc = t_fma(S[p1_f[r] + i * W], S[p1_v[r] + i * NA], acc);
+          S[L.T1 + sl + r * LANES] = acc;
+        }
       }
       wave_sync();
       // P2: H = L + T1[:, :n] F  ((n+m) x (n+m): Qxx | . ; Qux | Quu),  g = l + T1[:, n]
-      for (int e = sl; e < W * W; e += LANES) {
-        const int a = e / W, b = e - a * W;
-        if (a < n && b >= n) continue;  // Qxu is never used by the reference
-        T acc = T(0);
 #pragma unroll
-        for (int i = 0; i < n; i++)
-          acc = t_fma(S[L.T1 + a * (n + 1) + i], S[L.F + i * W + b], acc);
-        T l = T(0);
-        if (a < n) {  // l_xx = 2Q (+ obstacle block): control/ilqr_helper.py:30, :51
-          if (c.flags & FLAG_HAS_Q) l = T(2) * c.Q[a * n + b];
-          if (a < 2 && b < 2) l += S[L.ob + t * 5 + 2 + a + b];
-        } else if (b >= n) {  // l_uu = 2R + barrier: control/ilqr_helper.py:28
-          if (c.flags & FLAG_HAS_R) l = T(2) * c.R[(a - n) * m + (b - n)];
-          if (a == b) l += S[L.luu + t * m + (a - n)];
+      for (int r = 0; r < P2P; r++) {
+        if (p2_kind[r] >= 0) {
+          T acc = T(0);
+#pragma unroll
+          for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + i * W], acc);
+          T l = p2_const[r];  // 2Q / 2R: control/ilqr_helper.py:28, :30
+          const int e = sl + r * LANES, a = e / W, b = e - a * W;
+          if (p2_kind[r] == 1) l += S[L.ob + t * 5 + 2 + a + b];   // obstacle block, :51
+          if (p2_kind[r] == 2) l += S[L.luu + t * m + (a - n)];    // input barrier, :28
+          S[L.H + e] = l + acc;
         }
-        S[L.H + e] = l + acc;
       }
-      for (int a = sl; a < W; a += LANES) {
-        T l;
-        if (a < n) {  // l_x = 2Q dX[:, t] (+ obstacle): control/ilqr_helper.py:29, :50
-          l = T(0);
-          if (c.flags & FLAG_HAS_Q) {
 #pragma unroll
-            for (int r = 0; r < n; r++)
-              l += T(2) * c.Q[a * n + r] * (S[Xo + t * n + r] - c.xtarget[r]);
+      for (int r = 0; r < GP; r++) {
+        const int a = sl + r * LANES;
+        if (a < W) {
+          T l;
+          if (a < n) {  // l_x = 2Q dX[:, t] (+ obstacle): control/ilqr_helper.py:29, :50
+            l = T(0);
+            if constexpr (HASQR) {
+#pragma unroll
+              for (int q = 0; q < n; q++)
+                l += T(2) * c.Q[a * n + q] * (S[Xo + t * n + q] - c.xtarget[q]);
+            }
+            if (a < 2) l += S[L.ob + t * 5 + a];
+          } else {
+            l = S[L.lu + t * m + (a - n)];
           }
-          if (a < 2) l += S[L.ob + t * 5 + a];
-        } else {
-          l = S[L.lu + t * m + (a - n)];
+          S[L.g + a] = l + S[L.T1 + a * NA + n];
         }
-        S[L.g + a] = l + S[L.T1 + a * (n + 1) + n];
       }
       wave_sync();
-      // P3: gains [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
+      // P3+P4 fused: every lane inverts Quu (m x m, redundantly) and forms the two gain columns
+      // it needs itself:  [K | k] = -Quu_inv [Qux | Qu]  (control/iterative_ilqr.py:118-126),
+      //   [Vxx | Vx] = [Qxx | Qx] - (K^T Quu) [K | k]  with the UNregularised Quu (:128-129).
       T Quu[m * m], Qinv[m * m];
 #pragma unroll
       for (int a = 0; a < m; a++)
 #pragma unroll
         for (int b = 0; b < m; b++) Quu[a * m + b] = S[L.H + (n + a) * W + (n + b)];
       quu_inverse(Quu, lamb, Qinv);
-      for (int e = sl; e < m * (n + 1); e += LANES) {
-        const int a = e / (n + 1), j = e - a * (n + 1);
-        T acc = T(0);
 #pragma unroll
-        for (int b = 0; b < m; b++) {
-          const T gq = (j < n) ? S[L.H + (n + b) * W + j] : S[L.g + n + b];
-          acc = t_fma(pick<T, m * m>(Qinv, a * m + b), gq, acc);
+      for (int r = 0; r < P4P; r++) {
+        const int e = sl + r * LANES;
+        if (e < P4N) {
+          const int i = e / NA, j = e - i * NA;
+          T Ki[m], Kj[m];
+#pragma unroll
+          for (int a = 0; a < m; a++) {
+            T ai = T(0), aj = T(0);
+#pragma unroll
+            for (int b = 0; b < m; b++) {
+              const T gi = S[L.H + (n + b) * W + i];
+              const T gj = (j < n) ? S[L.H + (n + b) * W + j] : S[L.g + n + b];
+              ai = t_fma(Qinv[a * m + b], gi, ai);
+              aj = t_fma(Qinv[a * m + b], gj, aj);
+            }
+            Ki[a] = -ai;
+            Kj[a] = -aj;
+          }
+          if (i == 0) {  // lanes of the first row publish column j of [K | k]
+#pragma unroll
+            for (int a = 0; a < m; a++) S[L.Kk + (t * m + a) * NA + j] = Kj[a];
+          }
+          T acc = T(0);
+#pragma unroll
+          for (int b = 0; b < m; b++) {
+            T ktq = T(0);
+#pragma unroll
+            for (int a = 0; a < m; a++) ktq = t_fma(Ki[a], Quu[a * m + b], ktq);
+            acc = t_fma(ktq, Kj[b], acc);
+          }
+          const T qv = (j < n) ? S[L.H + i * W + j] : S[L.g + i];
+          S[L.Va + e] = qv - acc;
         }
-        S[L.Kk + t * m * (n + 1) + e] = -acc;
-      }
-      wave_sync();
-      // P4: value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
-      //     [Vxx | Vx] = [Qxx | Qx] - (K^T Quu) [K | k]
-      for (int e = sl; e < n * (n + 1); e += LANES) {
-        const int i = e / (n + 1), j = e - i * (n + 1);
-        T acc = T(0);
-#pragma unroll
-        for (int b = 0; b < m; b++) {
-          T ktq = T(0);
-#pragma unroll
-          for (int a = 0; a < m; a++)
-            ktq = t_fma(S[L.Kk + (t * m + a) * (n + 1) + i], Quu[a * m + b], ktq);
-          acc = t_fma(ktq, S[L.Kk + (t * m + b) * (n + 1) + j], acc);
-        }
-        const T qv = (j < n) ? S[L.H + i * W + j] : S[L.g + i];
-        S[L.Va + e] = qv - acc;
       }
       wave_sync();
     }
@@ -490,7 +565,7 @@ template <class T, class Sys, int LANES> struct Worker {
     T x[n], u[m], xn[n];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = S[Xo + i];
-    if (sl < n) S[Xn + sl] = pick<T, n>(x, sl);
+    publish<n>(Xn, x);
     T cost = T(0);
     for (int t = 0; t < N; t++) {
 #pragma unroll
@@ -501,9 +576,9 @@ template <class T, class Sys, int LANES> struct Worker {
         for (int j = 0; j < n; j++) acc = t_fma(kk[j], x[j] - S[Xo + t * n + j], acc);
         u[a] = clip(S[Uo + t * m + a] + kk[n] + acc, -c.u_max[a], c.u_max[a]);
       }
-      if (sl < m) S[Un + t * m + sl] = pick<T, m>(u, sl);
+      publish<m>(Un + t * m, u);
       Sys::step(c, x, u, xn);
-      if (sl < n) S[Xn + (t + 1) * n + sl] = pick<T, n>(xn, sl);
+      publish<n>(Xn + (t + 1) * n, xn);
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
@@ -521,7 +596,7 @@ template <class T> __device__ __forceinline__ bool t_isfinite(T v) {
   return (v - v) == T(0);
 }
 
-template <class T, class Sys, int LANES>
+template <class T, class Sys, int LANES, bool HASQR>
 __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> c,
                                                 const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
@@ -529,7 +604,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
   if (prob >= a.B) return;
-  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  Worker<T, Sys, LANES, HASQR> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   const auto& L = w.L;
   T* S = w.S;
@@ -538,6 +613,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   const T* gX = a.X + prob * (int64_t)(n * (N + 1));
   if (w.sl < n) S[L.X0 + w.sl] = gX[w.sl * (N + 1)];
   w.load_rec(a.U + prob * (int64_t)(m * N), L.U0, m, N);
+  w.stage_consts();
   T xT[n], ob[6];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
@@ -546,29 +622,34 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   T lamb = a.lamb[prob];
   wave_sync();
 
+  // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
+  // iteration i (same inputs, same code) and unchanged after a rejected one: it runs once.
   int cur = 0;  // which of the two trajectory buffers holds the nominal
+  T cost = w.rollout(L.X0, L.U0, xT);
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
-  T cost_ret = T(0);
-  for (it = 0; it < a.n_iters;) {
+  T cost_ret = cost;
+  while (it < a.n_iters) {
     const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
     const int Xn = cur ? L.X0 : L.X1, Un = cur ? L.U0 : L.U1;
-    const T cost = w.rollout(Xo, Uo, xT);
     w.prep(Xo, Uo, ob);
     w.backward(Xo, Uo, xT, lamb);
     const T cost_new = w.forward(Xo, Uo, Xn, Un, xT);
     it++;
-    cost_ret = cost;
     // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
     if (cost_new < cost) {
       cur ^= 1;
       lamb /= c.lamb_factor;
+      const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
-      if (t_abs((cost_new - cost) / cost) < c.eps) {
+      // next nominal cost: stage terms are measured to xtarget, not x_terminal, when Q != 0
+      cost = HASQR ? w.nominal_cost(Xn, Un, xT) : cost_new;
+      if (conv) {
         if (a.early_exit) { status = 1; break; }
         if (status == 0) status = 1;
       }
     } else {
       lamb *= c.lamb_factor;
+      cost_ret = cost;
       if (lamb > c.max_lamb) {
         if (a.early_exit) { status = 3; break; }
         if (status == 0) status = 3;
@@ -591,7 +672,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
 }
 
 // rollout only: control/iterative_ilqr.py:32-48
-template <class T, class Sys, int LANES>
+template <class T, class Sys, int LANES, bool HASQR>
 __global__ __launch_bounds__(64) void k_rollout(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                 T* X, T* U, const T* x_term, T* cost) {
   constexpr int n = Sys::n, m = Sys::m;
@@ -599,11 +680,12 @@ __global__ __launch_bounds__(64) void k_rollout(const DevCfg<T, Sys::n, Sys::m> 
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
   if (prob >= B) return;
-  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  Worker<T, Sys, LANES, HASQR> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   const T* gX = X + prob * (int64_t)(n * (N + 1));
   if (w.sl < n) w.S[w.L.X0 + w.sl] = gX[w.sl * (N + 1)];
   w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  w.stage_consts();
   T xT[n];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
@@ -615,7 +697,7 @@ __global__ __launch_bounds__(64) void k_rollout(const DevCfg<T, Sys::n, Sys::m> 
 }
 
 // backward only: control/iterative_ilqr.py:88-130
-template <class T, class Sys, int LANES>
+template <class T, class Sys, int LANES, bool HASQR>
 __global__ __launch_bounds__(64) void k_backward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                  const T* X, const T* U, const T* x_term,
                                                  const T* lamb, const T* obs, T* K, T* k) {
@@ -624,10 +706,11 @@ __global__ __launch_bounds__(64) void k_backward(const DevCfg<T, Sys::n, Sys::m>
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
   if (prob >= B) return;
-  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  Worker<T, Sys, LANES, HASQR> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   w.load_rec(X + prob * (int64_t)(n * (N + 1)), w.L.X0, n, N + 1);
   w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
+  w.stage_consts();
   T xT[n], ob[6];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
@@ -640,7 +723,7 @@ __global__ __launch_bounds__(64) void k_backward(const DevCfg<T, Sys::n, Sys::m>
 }
 
 // forward only: control/iterative_ilqr.py:133-160
-template <class T, class Sys, int LANES>
+template <class T, class Sys, int LANES, bool HASQR>
 __global__ __launch_bounds__(64) void k_forward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                 const T* X, const T* U, const T* x_term,
                                                 const T* K, const T* k, T* Xn, T* Un,
@@ -650,11 +733,12 @@ __global__ __launch_bounds__(64) void k_forward(const DevCfg<T, Sys::n, Sys::m> 
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
   if (prob >= B) return;
-  Worker<T, Sys, LANES> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  Worker<T, Sys, LANES, HASQR> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   w.load_rec(X + prob * (int64_t)(n * (N + 1)), w.L.X0, n, N + 1);
   w.load_rec(U + prob * (int64_t)(m * N), w.L.U0, m, N);
   w.load_gains(K + prob * (int64_t)(m * n * N), k + prob * (int64_t)(m * N));
+  w.stage_consts();
   T xT[n];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = x_term[prob * n + i];
