@@ -134,6 +134,10 @@ template <class T, class Sys> struct Launch {
     a.k = (T*)k;
     a.iters = iters;
     a.status = status;
+    a.dbg = nullptr;
+#ifdef I2LQR_STAMPS
+    a.dbg = (unsigned long long*)h->ws;  // diagnostic build: caller registers [B][8] u64 here
+#endif
     if (c.flags)
       hipLaunchKernelGGL((k_iterate<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes, s,
                          c, a);

@@ -224,32 +224,24 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       Va[0][0] += o[2]; Va[0][1] += o[3]; Va[1][0] += o[3]; Va[1][1] += o[4];
       Va[0][n] += o[0]; Va[1][n] += o[1];
     }
-    // software pipeline: the inputs of step t-1 are requested before step t is computed, so the
-    // HBM latency of the (independent) trajectory reads hides under the Riccati arithmetic
+    // Software pipeline: the trajectory inputs of a step are consumed at its start (Jacobian
+    // entries, barrier terms); the loads of step t-1 are then issued into the same registers, so
+    // the HBM latency hides under the Riccati arithmetic of step t.
     constexpr int NXT = HASQR ? n : 2;  // x_t is only needed for the obstacle (x, y) unless Q != 0
-    T xe_n[n], u_n[m], tr_n[NT], xt_n[NXT];
+    T xe[n], u[m], tr[NT], xt[NXT];
     auto load_step = [&](int t) {
 #pragma unroll
-      for (int i = 0; i < n; i++) xe_n[i] = X[ix(i, t + 1)];
+      for (int i = 0; i < n; i++) xe[i] = X[ix(i, t + 1)];
 #pragma unroll
-      for (int a = 0; a < m; a++) u_n[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
 #pragma unroll
-      for (int q = 0; q < NT; q++) tr_n[q] = TR[ix(q, t + 1)];
+      for (int q = 0; q < NT; q++) tr[q] = TR[ix(q, t + 1)];
 #pragma unroll
-      for (int i = 0; i < NXT; i++) xt_n[i] = X[ix(i, t)];
+      for (int i = 0; i < NXT; i++) xt[i] = X[ix(i, t)];
     };
     load_step(N - 1);
     for (int t = N - 1; t >= 0; t--) {
-      T xe[n], u[m], tr[NT], jv[NV], o[5], xt[n];
-#pragma unroll
-      for (int i = 0; i < n; i++) xe[i] = xe_n[i];
-#pragma unroll
-      for (int a = 0; a < m; a++) u[a] = u_n[a];
-#pragma unroll
-      for (int q = 0; q < NT; q++) tr[q] = tr_n[q];
-#pragma unroll
-      for (int i = 0; i < NXT; i++) xt[i] = xt_n[i];
-      if (t > 0) load_step(t - 1);
+      T jv[NV], o[5];
       Sys::jac_var(c, xe, u, tr, jv);
       obstacle(ob, xt[0], xt[1], t, o);
       // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
@@ -267,6 +259,17 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
         luu[a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
                  c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
       }
+      T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
+#pragma unroll
+      for (int a = 0; a < n; a++) {
+        T l = T(0);
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xt[r] - c.xtarget[r]);
+        }
+        lxq[a] = l;
+      }
+      if (t > 0) load_step(t - 1);
 
       // Row by row: T1[a][:] = (F^T [Vxx|Vx])[a][:], then H[a][:] = L[a][:] + T1[a][:n] F
       T Qa[n][n + 1];   // [Qxx | Qx]
@@ -309,11 +312,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
           }
         });
         if constexpr (a < n) {
-          T l = T(0);
-          if constexpr (HASQR) {
-#pragma unroll
-            for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xt[r] - c.xtarget[r]);
-          }
+          T l = lxq[a];
           if constexpr (a < 2) l += o[a];
           Qa[a][n] = l + t1[n];
         } else {
@@ -371,40 +370,33 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       Xn[ix(i, 0)] = x[i];
     }
     T cost = T(0);
-    // software pipeline: the nominal state, input and gains of step t+1 do not depend on the
-    // candidate state, so they are requested one step ahead of the serial rollout
-    T xo_n[n], uo_n[m], kk_n[m][n + 1];
+    // The nominal state / input / gains of a step are consumed at its very start (the feedback
+    // law); the loads for step t+1 are issued right after, into the same registers, so the HBM
+    // latency hides under the rest of the serial step.
+    T xo[n], uo[m], kk[m][n + 1];
     auto load_step = [&](int t) {
 #pragma unroll
-      for (int j = 0; j < n; j++) xo_n[j] = X[ix(j, t)];
+      for (int j = 0; j < n; j++) xo[j] = X[ix(j, t)];
 #pragma unroll
       for (int a = 0; a < m; a++) {
-        uo_n[a] = U[iu(a, t)];
+        uo[a] = U[iu(a, t)];
 #pragma unroll
-        for (int j = 0; j < n; j++) kk_n[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
-        kk_n[a][n] = gk[iu(a, t)];
+        for (int j = 0; j < n; j++) kk[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
+        kk[a][n] = gk[iu(a, t)];
       }
     };
     load_step(0);
     for (int t = 0; t < N; t++) {
-      T xo[n], uo[m], kk[m][n + 1];
-#pragma unroll
-      for (int j = 0; j < n; j++) xo[j] = xo_n[j];
-#pragma unroll
-      for (int a = 0; a < m; a++) {
-        uo[a] = uo_n[a];
-#pragma unroll
-        for (int j = 0; j <= n; j++) kk[a][j] = kk_n[a][j];
-      }
-      if (t + 1 < N) load_step(t + 1);
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
         for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
         u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
-        Un[iu(a, t)] = u[a];
       }
+      if (t + 1 < N) load_step(t + 1);
+#pragma unroll
+      for (int a = 0; a < m; a++) Un[iu(a, t)] = u[a];
       Sys::trig(x, tr);
 #pragma unroll
       for (int q = 0; q < NT; q++) TRn[ix(q, t)] = tr[q];

@@ -155,13 +155,11 @@ template <class T> struct Bicycle4 {
     v[4] = dt * dt * tr[0] / T(2); // B[0][0]
     v[5] = dt * dt * tr[1] / T(2); // B[1][0]
   }
-  static __device__ __forceinline__ int var_idx(int v) {
+  // flat index into F (row-major n x (n+m)) of varying entry v
+  static constexpr int var_idx_c(int v) {
     constexpr int W = n + m;
-    const int idx[NVAR] = {0 * W + 2, 0 * W + 3, 1 * W + 2, 1 * W + 3, 0 * W + n, 1 * W + n};
-    int r = idx[0];
-#pragma unroll
-    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
-    return r;
+    constexpr int idx[NVAR] = {0 * W + 2, 0 * W + 3, 1 * W + 2, 1 * W + 3, 0 * W + n, 1 * W + n};
+    return idx[v];
   }
   template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
     if (j < n) return (i == j) ? T(1) : T(0);
@@ -223,13 +221,10 @@ template <class T> struct Bicycle6 {
     v[4] = w * tr[0];              // A[1][3]
     v[5] = dt * dt * tr[1] / T(2); // A[1][4]
   }
-  static __device__ __forceinline__ int var_idx(int v) {
+  static constexpr int var_idx_c(int v) {
     constexpr int W = n + m;
-    const int idx[NVAR] = {0 * W + 2, 0 * W + 3, 0 * W + 4, 1 * W + 2, 1 * W + 3, 1 * W + 4};
-    int r = idx[0];
-#pragma unroll
-    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
-    return r;
+    constexpr int idx[NVAR] = {0 * W + 2, 0 * W + 3, 0 * W + 4, 1 * W + 2, 1 * W + 3, 1 * W + 4};
+    return idx[v];
   }
   template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
     if (j < n) {
@@ -332,9 +327,9 @@ template <class T> struct Quad12 {
       v[33 + j] = az;
     }
   }
-  static __device__ __forceinline__ int var_idx(int v) {
+  static constexpr int var_idx_c(int v) {
     constexpr int W = n + m;
-    const int idx[NVAR] = {
+    constexpr int idx[NVAR] = {
         3 * W + 3,  3 * W + 4,  3 * W + 10, 3 * W + 11, 4 * W + 3,  4 * W + 10, 4 * W + 11,
         5 * W + 3,  5 * W + 4,  5 * W + 10, 5 * W + 11, 6 * W + 3,  6 * W + 4,  6 * W + 5,
         7 * W + 3,  7 * W + 4,  7 * W + 5,  8 * W + 3,  8 * W + 4,  9 * W + 10, 9 * W + 11,
@@ -342,10 +337,7 @@ template <class T> struct Quad12 {
         6 * W + n + 0, 6 * W + n + 1, 6 * W + n + 2, 6 * W + n + 3,
         7 * W + n + 0, 7 * W + n + 1, 7 * W + n + 2, 7 * W + n + 3,
         8 * W + n + 0, 8 * W + n + 1, 8 * W + n + 2, 8 * W + n + 3};
-    int r = idx[0];
-#pragma unroll
-    for (int q = 1; q < NVAR; q++) r = (v == q) ? idx[q] : r;
-    return r;
+    return idx[v];
   }
   template <class Cfg> static __device__ __forceinline__ T jac_const(const Cfg& c, int i, int j) {
     const T dt = c.dt;

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "i2lqr_systems.hpp"
 
 namespace i2lqr {
@@ -48,7 +50,39 @@ template <class T> struct IterArgs {
   T* k;           // [B][m][N] out or null
   int32_t* iters;  // [B] out or null
   int32_t* status; // [B] out or null
+  unsigned long long* dbg;  // diagnostic builds only: [B][8] phase cycle sums; null otherwise
 };
+
+// Diagnostic build only (-DI2LQR_STAMPS, tools/stamp_build.sh): per-phase cycle shares of one
+// wave, accumulated in scalar registers and written to a debug buffer no other code reads.
+#ifdef I2LQR_STAMPS
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0
+#define STAMP_BEGIN()                                                            \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#define STAMP_END(slot)                                                          \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    st_acc[slot] += st_t1 - st_t0;                                               \
+    st_t0 = st_t1;                                                               \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN()
+#define STAMP_END(slot)
+#endif
+
+template <int Begin, int End, class F> __device__ __forceinline__ void static_for_i(F&& f) {
+  if constexpr (Begin < End) {
+    f(std::integral_constant<int, Begin>{});
+    static_for_i<Begin + 1, End>(f);
+  }
+}
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -108,6 +142,9 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
   T* const S;   // this problem's LDS slice
   const int sl; // lane index inside the problem's lane group
   const int N;
+#ifdef I2LQR_STAMPS
+  mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#endif
 
   __device__ Worker(const Cfg& c_, T* smem, int lane)
       : c(c_), L(c_.N), S(smem + (lane / LANES) * Layout<Sys>(c_.N).total), sl(lane % LANES),
@@ -396,8 +433,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
     constexpr int NA = n + 1;                               // width of [Vxx | Vx], [K | k]
     constexpr int P1N = W * NA, P2N = W * W, P4N = n * NA;  // elements per phase
     constexpr int P1P = (P1N + LANES - 1) / LANES, P2P = (P2N + LANES - 1) / LANES,
-                  P4P = (P4N + LANES - 1) / LANES, VP = (Sys::NVAR + LANES - 1) / LANES,
-                  GP = (W + LANES - 1) / LANES;
+                  P4P = (P4N + LANES - 1) / LANES, GP = (W + LANES - 1) / LANES;
     // constant pattern of F = [A | B]; the state-dependent entries are refreshed every step
     for (int e = sl; e < n * W; e += LANES) S[L.F + e] = Sys::jac_const(c, e / W, e % W);
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150
@@ -415,102 +451,138 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       }
       S[L.Va + e] = v;
     }
-    // fixed lane roles
-    int var_at[VP];
-#pragma unroll
-    for (int r = 0; r < VP; r++) var_at[r] = Sys::var_idx(sl + r * LANES);
+    // Fixed lane roles.  Every phase is written branch-free: each lane's LDS addresses (and the
+    // weights of optional terms) are computed once here, so that inside the horizon loop all
+    // reads of a phase are issued unconditionally up front and waited for once; lanes without
+    // an element in a phase read a valid dummy address and only skip the final store.
     int p1_f[P1P], p1_v[P1P];    // column a of F, column j of [Vxx|Vx]
+    bool p1_on[P1P];
 #pragma unroll
     for (int r = 0; r < P1P; r++) {
-      const int e = sl + r * LANES, a = e / NA, j = e - a * NA;
+      const int e0 = sl + r * LANES;
+      p1_on[r] = e0 < P1N;
+      const int e = p1_on[r] ? e0 : 0, a = e / NA, j = e - a * NA;
       p1_f[r] = L.F + a;
       p1_v[r] = L.Va + j;
     }
-    int p2_t[P2P], p2_f[P2P], p2_kind[P2P];  // row a of T1, column b of F, which l-term
+    // P2: H[a][b] = lconst + [extra term] + T1[a][:] . F[:, b]
+    int p2_t[P2P], p2_f[P2P], p2_x[P2P], p2_xs[P2P];
+    bool p2_on[P2P], p2_xon[P2P];
     T p2_const[P2P];
 #pragma unroll
     for (int r = 0; r < P2P; r++) {
-      const int e = sl + r * LANES, a = e / W, b = e - a * W;
+      const int e0 = sl + r * LANES;
+      const int e = e0 < P2N ? e0 : 0, a = e / W, b = e - a * W;
+      p2_on[r] = e0 < P2N && !(a < n && b >= n);  // Qxu is never used by the reference
       p2_t[r] = L.T1 + a * NA;
       p2_f[r] = L.F + b;
-      // kind: -1 unused (Qxu / out of range), 0 plain, 1 obstacle block (a,b < 2), 2 luu diagonal
-      int kind = 0;
-      if (e >= P2N || (a < n && b >= n)) kind = -1;
-      else if (a < 2 && b < 2) kind = 1;
-      else if (a >= n && a == b) kind = 2;
-      p2_kind[r] = kind;
+      // optional term: obstacle block (a, b < 2; control/ilqr_helper.py:51) or the input barrier
+      // on the diagonal of l_uu (:28)
+      p2_xon[r] = (a < 2 && b < 2) || (a >= n && a == b);
+      p2_x[r] = (a >= n && a == b) ? L.luu + (a - n) : L.ob + 2 + ((a < 2 && b < 2) ? a + b : 0);
+      p2_xs[r] = (a >= n && a == b) ? m : 5;
       T lc = T(0);
       if constexpr (HASQR) {
-        if (e < P2N && a < n && b < n) lc = T(2) * c.Q[a * n + b];
-        if (e < P2N && a >= n && b >= n) lc = T(2) * c.R[(a - n) * m + (b - n)];
+        if (a < n && b < n) lc = T(2) * c.Q[a * n + b];       // l_xx = 2Q, :30
+        if (a >= n && b >= n) lc = T(2) * c.R[(a - n) * m + (b - n)];  // l_uu = 2R, :28
       }
       p2_const[r] = lc;
     }
+    // g[a] = l[a] + T1[a][n]:  l_x obstacle part (a < 2), l_u (a >= n)
+    int g_x[GP], g_xs[GP], g_t[GP];
+    bool g_on[GP], g_xon[GP];
+#pragma unroll
+    for (int r = 0; r < GP; r++) {
+      const int a0 = sl + r * LANES;
+      g_on[r] = a0 < W;
+      const int a = g_on[r] ? a0 : 0;
+      g_xon[r] = a < 2 || a >= n;
+      g_x[r] = (a >= n) ? L.lu + (a - n) : L.ob + (a < 2 ? a : 0);
+      g_xs[r] = (a >= n) ? m : 5;
+      g_t[r] = L.T1 + a * NA + n;
+    }
+    // P34: element (i, j) of [Vxx | Vx]
+    int p4_gi[P4P], p4_gj[P4P], p4_gjs[P4P], p4_q[P4P];
+    bool p4_on[P4P];
+#pragma unroll
+    for (int r = 0; r < P4P; r++) {
+      const int e0 = sl + r * LANES;
+      p4_on[r] = e0 < P4N;
+      const int e = p4_on[r] ? e0 : 0, i = e / NA, j = e - i * NA;
+      p4_gi[r] = L.H + n * W + i;                            // Qux[:, i], stride W
+      p4_gj[r] = (j < n) ? L.H + n * W + j : L.g + n;        // Qux[:, j] or Qu
+      p4_gjs[r] = (j < n) ? W : 1;
+      p4_q[r] = (j < n) ? L.H + i * W + j : L.g + i;         // Qxx[i][j] or Qx[i]
+    }
+    // P0: the state-dependent entries of F = [A | B] at (x_{t+1}, u_t)
+    // (control/iterative_ilqr.py:92-99).  Issued for step t-1 inside the last phase of step t:
+    // nothing there reads F, so the refresh costs no LDS round trip of its own.
+    T rf_xe[n], rf_u[m], rf_tr[NT];
+    auto refresh_load = [&](int t) {  // the LDS reads of the refresh, issued early
+#pragma unroll
+      for (int i = 0; i < n; i++) rf_xe[i] = S[Xo + (t + 1) * n + i];
+#pragma unroll
+      for (int a = 0; a < m; a++) rf_u[a] = S[Uo + t * m + a];
+#pragma unroll
+      for (int q = 0; q < NT; q++) rf_tr[q] = S[L.trg + t * NT + q];
+    };
+    auto refresh_store = [&]() {
+      // every lane holds all NVAR values; lane 0 stores them at their compile-time positions
+      // (a lane-indexed select over the array would be demoted to scratch memory by the compiler)
+      T jv[Sys::NVAR];
+      Sys::jac_var(c, rf_xe, rf_u, rf_tr, jv);
+      if (sl == 0) {
+        static_for_i<0, Sys::NVAR>([&](auto q_) {
+          constexpr int q = decltype(q_)::value;
+          S[L.F + Sys::var_idx_c(q)] = jv[q];
+        });
+      }
+    };
+    wave_sync();  // F's constant pattern is in place before the first refresh writes into it
+    refresh_load(N - 1);
+    refresh_store();
     wave_sync();
 
     for (int t = N - 1; t >= 0; t--) {
-      // P0: refresh F at (x_{t+1}, u_t): control/iterative_ilqr.py:92-99
-      {
-        T xe[n], u[m], tr[NT], jv[Sys::NVAR];
-#pragma unroll
-        for (int i = 0; i < n; i++) xe[i] = S[Xo + (t + 1) * n + i];
-#pragma unroll
-        for (int a = 0; a < m; a++) u[a] = S[Uo + t * m + a];
-#pragma unroll
-        for (int q = 0; q < NT; q++) tr[q] = S[L.trg + t * NT + q];
-        Sys::jac_var(c, xe, u, tr, jv);
-#pragma unroll
-        for (int r = 0; r < VP; r++) {
-          const int v = sl + r * LANES;
-          if (v < Sys::NVAR) S[L.F + var_at[r]] = pick<T, Sys::NVAR>(jv, v);
-        }
-      }
-      wave_sync();
+      STAMP_BEGIN();
       // P1: T1 = F^T [Vxx | Vx]   ((n+m) x (n+1)); f.T @ V of control/iterative_ilqr.py:112-116
 #pragma unroll
       for (int r = 0; r < P1P; r++) {
-        if (sl + r * LANES < P1N) {
-          T acc = T(0);
+        T acc = T(0);
 #pragma unroll
-          for (int i = 0; i < n; i++) acc = t_fma(S[p1_f[r] + i * W], S[p1_v[r] + i * NA], acc);
-          S[L.T1 + sl + r * LANES] = acc;
-        }
+        for (int i = 0; i < n; i++) acc = t_fma(S[p1_f[r] + i * W], S[p1_v[r] + i * NA], acc);
+        if (p1_on[r]) S[L.T1 + sl + r * LANES] = acc;
       }
       wave_sync();
+      STAMP_END(1);
       // P2: H = L + T1[:, :n] F  ((n+m) x (n+m): Qxx | . ; Qux | Quu),  g = l + T1[:, n]
 #pragma unroll
       for (int r = 0; r < P2P; r++) {
-        if (p2_kind[r] >= 0) {
-          T acc = T(0);
+        const T extra = S[p2_x[r] + t * p2_xs[r]];
+        T acc = T(0);
 #pragma unroll
-          for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + i * W], acc);
-          T l = p2_const[r];  // 2Q / 2R: control/ilqr_helper.py:28, :30
-          const int e = sl + r * LANES, a = e / W, b = e - a * W;
-          if (p2_kind[r] == 1) l += S[L.ob + t * 5 + 2 + a + b];   // obstacle block, :51
-          if (p2_kind[r] == 2) l += S[L.luu + t * m + (a - n)];    // input barrier, :28
-          S[L.H + e] = l + acc;
-        }
+        for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + i * W], acc);
+        const T l = p2_const[r] + (p2_xon[r] ? extra : T(0));
+        if (p2_on[r]) S[L.H + sl + r * LANES] = l + acc;
       }
 #pragma unroll
       for (int r = 0; r < GP; r++) {
-        const int a = sl + r * LANES;
-        if (a < W) {
-          T l;
-          if (a < n) {  // l_x = 2Q dX[:, t] (+ obstacle): control/ilqr_helper.py:29, :50
-            l = T(0);
-            if constexpr (HASQR) {
+        const T extra = S[g_x[r] + t * g_xs[r]];
+        const T t1n = S[g_t[r]];
+        T l = g_xon[r] ? extra : T(0);
+        if constexpr (HASQR) {
+          // l_x = 2Q dX[:, t]: control/ilqr_helper.py:29
+          const int a = sl + r * LANES;
+          if (a < n) {
 #pragma unroll
-              for (int q = 0; q < n; q++)
-                l += T(2) * c.Q[a * n + q] * (S[Xo + t * n + q] - c.xtarget[q]);
-            }
-            if (a < 2) l += S[L.ob + t * 5 + a];
-          } else {
-            l = S[L.lu + t * m + (a - n)];
+            for (int q = 0; q < n; q++)
+              l += T(2) * c.Q[a * n + q] * (S[Xo + t * n + q] - c.xtarget[q]);
           }
-          S[L.g + a] = l + S[L.T1 + a * NA + n];
         }
+        if (g_on[r]) S[L.g + sl + r * LANES] = l + t1n;
       }
       wave_sync();
+      STAMP_END(2);
       // P3+P4 fused: every lane inverts Quu (m x m, redundantly) and forms the two gain columns
       // it needs itself:  [K | k] = -Quu_inv [Qux | Qu]  (control/iterative_ilqr.py:118-126),
       //   [Vxx | Vx] = [Qxx | Qx] - (K^T Quu) [K | k]  with the UNregularised Quu (:128-129).
@@ -519,43 +591,52 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       for (int a = 0; a < m; a++)
 #pragma unroll
         for (int b = 0; b < m; b++) Quu[a * m + b] = S[L.H + (n + a) * W + (n + b)];
+      T Gi[P4P][m], Gj[P4P][m], Qv[P4P];
+#pragma unroll
+      for (int r = 0; r < P4P; r++) {
+#pragma unroll
+        for (int b = 0; b < m; b++) {
+          Gi[r][b] = S[p4_gi[r] + b * W];
+          Gj[r][b] = S[p4_gj[r] + b * p4_gjs[r]];
+        }
+        Qv[r] = S[p4_q[r]];
+      }
+      refresh_load(t > 0 ? t - 1 : 0);  // reads of the next step's Jacobian refresh
       quu_inverse(Quu, lamb, Qinv);
+      STAMP_END(3);
 #pragma unroll
       for (int r = 0; r < P4P; r++) {
         const int e = sl + r * LANES;
-        if (e < P4N) {
-          const int i = e / NA, j = e - i * NA;
-          T Ki[m], Kj[m];
+        T Ki[m], Kj[m];
 #pragma unroll
-          for (int a = 0; a < m; a++) {
-            T ai = T(0), aj = T(0);
-#pragma unroll
-            for (int b = 0; b < m; b++) {
-              const T gi = S[L.H + (n + b) * W + i];
-              const T gj = (j < n) ? S[L.H + (n + b) * W + j] : S[L.g + n + b];
-              ai = t_fma(Qinv[a * m + b], gi, ai);
-              aj = t_fma(Qinv[a * m + b], gj, aj);
-            }
-            Ki[a] = -ai;
-            Kj[a] = -aj;
-          }
-          if (i == 0) {  // lanes of the first row publish column j of [K | k]
-#pragma unroll
-            for (int a = 0; a < m; a++) S[L.Kk + (t * m + a) * NA + j] = Kj[a];
-          }
-          T acc = T(0);
+        for (int a = 0; a < m; a++) {
+          T ai = T(0), aj = T(0);
 #pragma unroll
           for (int b = 0; b < m; b++) {
-            T ktq = T(0);
-#pragma unroll
-            for (int a = 0; a < m; a++) ktq = t_fma(Ki[a], Quu[a * m + b], ktq);
-            acc = t_fma(ktq, Kj[b], acc);
+            ai = t_fma(Qinv[a * m + b], Gi[r][b], ai);
+            aj = t_fma(Qinv[a * m + b], Gj[r][b], aj);
           }
-          const T qv = (j < n) ? S[L.H + i * W + j] : S[L.g + i];
-          S[L.Va + e] = qv - acc;
+          Ki[a] = -ai;
+          Kj[a] = -aj;
         }
+        if (e < NA) {  // lanes of the first row (i == 0) publish column j = e of [K | k]
+#pragma unroll
+          for (int a = 0; a < m; a++) S[L.Kk + (t * m + a) * NA + e] = Kj[a];
+        }
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) {
+          T ktq = T(0);
+#pragma unroll
+          for (int a = 0; a < m; a++) ktq = t_fma(Ki[a], Quu[a * m + b], ktq);
+          acc = t_fma(ktq, Kj[b], acc);
+        }
+        if (p4_on[r]) S[L.Va + e] = Qv[r] - acc;
       }
+      STAMP_END(4);
+      refresh_store();  // (at t == 0 this rewrites step 0's entries: harmless, F is not read again)
       wave_sync();
+      STAMP_END(5);
     }
   }
 
@@ -567,15 +648,30 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
     for (int i = 0; i < n; i++) x[i] = S[Xo + i];
     publish<n>(Xn, x);
     T cost = T(0);
+    // The nominal state / input / gains of a step are consumed at its very start (the feedback
+    // law); the reads for step t+1 are issued right after, into the same registers, so their LDS
+    // latency hides under the rest of the serial step (trig, dynamics, publish).
+    T xo[n], uo[m], kk[m][n + 1];
+    auto load_step = [&](int t) {
+#pragma unroll
+      for (int j = 0; j < n; j++) xo[j] = S[Xo + t * n + j];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        uo[a] = S[Uo + t * m + a];
+#pragma unroll
+        for (int j = 0; j <= n; j++) kk[a][j] = S[L.Kk + (t * m + a) * (n + 1) + j];
+      }
+    };
+    load_step(0);
     for (int t = 0; t < N; t++) {
 #pragma unroll
       for (int a = 0; a < m; a++) {
-        const T* kk = S + L.Kk + (t * m + a) * (n + 1);
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kk[j], x[j] - S[Xo + t * n + j], acc);
-        u[a] = clip(S[Uo + t * m + a] + kk[n] + acc, -c.u_max[a], c.u_max[a]);
+        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
+        u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
       }
+      load_step(t + 1 < N ? t + 1 : t);
       publish<m>(Un + t * m, u);
       Sys::step(c, x, u, xn);
       publish<n>(Xn + (t + 1) * n, xn);
@@ -631,9 +727,26 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   while (it < a.n_iters) {
     const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
     const int Xn = cur ? L.X0 : L.X1, Un = cur ? L.U0 : L.U1;
+#ifdef I2LQR_STAMPS
+    STAMP_DECL;
+    STAMP_BEGIN();
+#endif
     w.prep(Xo, Uo, ob);
+#ifdef I2LQR_STAMPS
+    STAMP_END(0);
+#endif
     w.backward(Xo, Uo, xT, lamb);
+#ifdef I2LQR_STAMPS
+    STAMP_BEGIN();
+#endif
     const T cost_new = w.forward(Xo, Uo, Xn, Un, xT);
+#ifdef I2LQR_STAMPS
+    STAMP_END(6);
+    if (a.dbg && w.sl == 0) {
+      for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] += st_acc[q] + w.st_acc[q];
+      for (int q = 0; q < 8; q++) w.st_acc[q] = 0;
+    }
+#endif
     it++;
     // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
     if (cost_new < cost) {

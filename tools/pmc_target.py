@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Run ONE kernel configuration a few times — the target of `rocprofv3 --pmc ...` runs
+(counters are collected in their own passes, never together with the traces)."""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="config2")
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--dtype", default="f64")
+ap.add_argument("--layout", default="wave")
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--launches", type=int, default=5)
+args = ap.parse_args()
+cfg = workloads.config_for(args.workload, args.dtype)
+cfg.layout = 1 if args.layout == "lane" else 0
+solver = BatchedILQR(cfg)
+host = workloads.make_batch(cfg, args.batch)
+dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
+bufs = []
+for _ in range(args.launches):
+    buf = solver.alloc(args.batch)
+    for key in ("X", "U", "x_term", "lamb"):
+        buf[key].copy_(dev(host[key]))
+    buf["obs"] = dev(host["obs"])
+    bufs.append(buf)
+torch.cuda.synchronize()
+for buf in bufs:
+    solver.iterate(buf, args.iters)
+torch.cuda.synchronize()
+print("done", args)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Phase cycle shares of the wave kernel from the diagnostic (stamped) build."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+
+from ilqr_iterative_tasks_amd import _abi, workloads
+
+_abi.LIB_PATH = ROOT / "tools" / "_diag" / "libi2lqr_stamps.so"
+from ilqr_iterative_tasks_amd import BatchedILQR
+
+B, iters = 1024, 10
+cfg = workloads.config_for("config2", sys.argv[1] if len(sys.argv) > 1 else "f64")
+solver = BatchedILQR(cfg)
+host = workloads.make_batch(cfg, B)
+buf = solver.alloc(B)
+for key in ("X", "U", "x_term", "lamb"):
+    buf[key].copy_(torch.as_tensor(host[key]).to(solver.device, solver.dtype))
+buf["obs"] = torch.as_tensor(host["obs"]).to(solver.device, solver.dtype)
+dbg = torch.zeros(B, 8, dtype=torch.int64, device=solver.device)
+solver.lib.i2lqr_set_workspace(solver._handle, C.c_void_p(dbg.data_ptr()), dbg.numel() * 8)
+solver.iterate(buf, iters)
+torch.cuda.synchronize()
+d = dbg.double().mean(0).cpu().numpy() / iters
+names = ["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
+tot = d.sum()
+for nm, v in zip(names, d):
+    print(f"{nm:20s} {v:9.0f} cycles/iteration  {100 * v / tot:5.1f} %")
+print(f"{'sum':20s} {tot:9.0f} cycles/iteration")
