@@ -216,8 +216,6 @@ template <class T, class Sys> struct LaneLaunch {
     T* p = (T*)h->ws;
     a.wsX = p; p += B * (int64_t)(n * (N + 1));
     a.wsU = p; p += B * (int64_t)(m * N);
-    a.wsTR0 = p; p += B * (int64_t)(NT * (N + 1));
-    a.wsTR1 = p; p += B * (int64_t)(NT * (N + 1));
     a.wsK = p; p += B * (int64_t)(m * n * N);
     a.wsk = p;
   }
@@ -247,10 +245,10 @@ template <class T, class Sys> struct LaneLaunch {
     carve(h, B, a);
     if (c.flags)
       hipLaunchKernelGGL((k_lane_rollout<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
-                         (T*)X, (T*)U, (const T*)x_term, (T*)cost, a.wsTR0);
+                         (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     else
       hipLaunchKernelGGL((k_lane_rollout<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
-                         (T*)X, (T*)U, (const T*)x_term, (T*)cost, a.wsTR0);
+                         (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -263,11 +261,11 @@ template <class T, class Sys> struct LaneLaunch {
     if (c.flags)
       hipLaunchKernelGGL((k_lane_backward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
-                         (const T*)obs, (T*)K, (T*)k, a.wsTR0);
+                         (const T*)obs, (T*)K, (T*)k);
     else
       hipLaunchKernelGGL((k_lane_backward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
-                         (const T*)obs, (T*)K, (T*)k, a.wsTR0);
+                         (const T*)obs, (T*)K, (T*)k);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -281,11 +279,11 @@ template <class T, class Sys> struct LaneLaunch {
     if (c.flags)
       hipLaunchKernelGGL((k_lane_forward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
-                         (T*)Xn, (T*)Un, (T*)cost_new, a.wsTR0);
+                         (T*)Xn, (T*)Un, (T*)cost_new);
     else
       hipLaunchKernelGGL((k_lane_forward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
-                         (T*)Xn, (T*)Un, (T*)cost_new, a.wsTR0);
+                         (T*)Xn, (T*)Un, (T*)cost_new);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }

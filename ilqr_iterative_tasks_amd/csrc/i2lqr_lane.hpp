@@ -7,6 +7,8 @@
 // the per-step trig cache stream through HBM in the BATCH-MINOR layout
 //     X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  lamb[B]  obs[6][B]
 // so a wavefront's access to one (component, t) is one fully coalesced 512-byte (fp64) row.
+// sin/cos of the heading are recomputed where needed (35 instructions) instead of being cached
+// in HBM: the kernel is bandwidth-bound, not instruction-bound, at large batch.
 // This is the HBM-bound form of the algorithm: per iteration and problem it moves X, U, K, k once
 // in each direction (SURVEY.md §8(d) algorithmic bytes).
 //
@@ -36,14 +38,14 @@ template <class T> struct LaneArgs {
   int n_iters, early_exit;
   T* X; T* U; const T* x_term; T* lamb; const T* obs; T* cost; T* K; T* k;
   int32_t* iters; int32_t* status;
-  // workspace (batch-minor): candidate trajectory, two trig caches, gains if K == null
-  T* wsX; T* wsU; T* wsTR0; T* wsTR1; T* wsK; T* wsk;
+  // workspace (batch-minor): candidate trajectory, gains if K == null
+  T* wsX; T* wsU; T* wsK; T* wsk;
 };
 
 // words of T the workspace needs for B problems
 template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int N, int64_t B) {
-  constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
-  return B * (int64_t)(n * (N + 1) + m * N + 2 * NT * (N + 1) + m * n * N + m * N);
+  constexpr int n = Sys::n, m = Sys::m;
+  return B * (int64_t)(n * (N + 1) + m * N + m * n * N + m * N);
 }
 
 template <class T, class Sys, bool HASQR> struct LaneWorker {
@@ -115,8 +117,8 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     }
   }
 
-  // -- nominal rollout + cost (control/iterative_ilqr.py:32-48); also fills the trig cache ------
-  __device__ __forceinline__ T rollout(T* X, T* U, T* TR, const T (&xT)[n]) const {
+  // -- nominal rollout + cost (control/iterative_ilqr.py:32-48) --------------------------------
+  __device__ __forceinline__ T rollout(T* X, T* U, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = X[ix(i, 0)];
@@ -128,8 +130,6 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
         U[iu(a, t)] = u[a];
       }
       Sys::trig(x, tr);
-#pragma unroll
-      for (int q = 0; q < NT; q++) TR[ix(q, t)] = tr[q];
       Sys::step_tr(c, x, u, tr, xn);
 #pragma unroll
       for (int i = 0; i < n; i++) X[ix(i, t + 1)] = xn[i];
@@ -137,9 +137,6 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
     }
-    Sys::trig(x, tr);
-#pragma unroll
-    for (int q = 0; q < NT; q++) TR[ix(q, N)] = tr[q];
     cost = cost + terminal_cost(x, xT);
     return cost;
   }
@@ -174,9 +171,9 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
     T disc = hd * hd + bq * cc;
     disc = disc < T(0) ? T(0) : disc;
-    const T s = t_sqrt(disc);
+    const T s = t_sqrt_fast(disc);
     T l1 = (mean >= T(0)) ? mean + s : mean - s;
-    T l2 = (l1 != T(0)) ? (a * d - bq * cc) / l1 : T(0);
+    T l2 = (l1 != T(0)) ? (a * d - bq * cc) * t_rcp(l1) : T(0);
     if (s == T(0)) { l1 = mean; l2 = mean; }
     const T w[2] = {l1, l2};
     T vx[2], vy[2], sc[2];
@@ -192,7 +189,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
       vx[e] = ex;
       vy[e] = ey;
-      sc[e] = T(1) / (nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
+      sc[e] = t_rcp(nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
     }
     inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
     inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
@@ -201,8 +198,8 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
-  // Reads the nominal (X, U, TR), writes the gains to gK[m][n][N][B], gk[m][N][B].
-  __device__ __forceinline__ void backward(const T* X, const T* U, const T* TR, const T (&xT)[n],
+  // Reads the nominal (X, U), writes the gains to gK[m][n][N][B], gk[m][N][B].
+  __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk) const {
     T Va[n][n + 1];  // [Vxx | Vx]
     {
@@ -226,24 +223,20 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     }
     // Software pipeline: the trajectory inputs of a step are consumed at its start (Jacobian
     // entries, barrier terms); the loads of step t-1 are then issued into the same registers, so
-    // the HBM latency hides under the Riccati arithmetic of step t.
-    constexpr int NXT = HASQR ? n : 2;  // x_t is only needed for the obstacle (x, y) unless Q != 0
-    T xe[n], u[m], tr[NT], xt[NXT];
-    auto load_step = [&](int t) {
+    // the HBM latency hides under the Riccati arithmetic of step t.  X[:, t] is read ONCE: it is
+    // x_t of step t (obstacle / stage terms) and the evaluation state x_{t+1} of step t-1.
+    T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t
 #pragma unroll
-      for (int i = 0; i < n; i++) xe[i] = X[ix(i, t + 1)];
+    for (int i = 0; i < n; i++) xe[i] = X[ix(i, N)];
 #pragma unroll
-      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+    for (int i = 0; i < n; i++) xp[i] = X[ix(i, N - 1)];
 #pragma unroll
-      for (int q = 0; q < NT; q++) tr[q] = TR[ix(q, t + 1)];
-#pragma unroll
-      for (int i = 0; i < NXT; i++) xt[i] = X[ix(i, t)];
-    };
-    load_step(N - 1);
+    for (int a = 0; a < m; a++) u[a] = U[iu(a, N - 1)];
     for (int t = N - 1; t >= 0; t--) {
-      T jv[NV], o[5];
+      T jv[NV], o[5], tr[NT];
+      Sys::trig(xe, tr);  // the same values the rollout used for the dynamics of step t+1
       Sys::jac_var(c, xe, u, tr, jv);
-      obstacle(ob, xt[0], xt[1], t, o);
+      obstacle(ob, xp[0], xp[1], t, o);
       // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
       T lu[m], luu[m];
 #pragma unroll
@@ -265,11 +258,18 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
         T l = T(0);
         if constexpr (HASQR) {
 #pragma unroll
-          for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xt[r] - c.xtarget[r]);
+          for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xp[r] - c.xtarget[r]);
         }
         lxq[a] = l;
       }
-      if (t > 0) load_step(t - 1);
+#pragma unroll
+      for (int i = 0; i < n; i++) xe[i] = xp[i];
+      if (t > 0) {
+#pragma unroll
+        for (int i = 0; i < n; i++) xp[i] = X[ix(i, t - 1)];
+#pragma unroll
+        for (int a = 0; a < m; a++) u[a] = U[iu(a, t - 1)];
+      }
 
       // Row by row: T1[a][:] = (F^T [Vxx|Vx])[a][:], then H[a][:] = L[a][:] + T1[a][:n] F
       T Qa[n][n + 1];   // [Qxx | Qx]
@@ -360,9 +360,11 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     }
   }
 
-  // -- forward pass: control/iterative_ilqr.py:133-160; fills the candidate's trig cache --------
+  // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
+  // (Re-rolling the nominal states instead of reading X back was tried: it saves n words per step
+  // but the second dynamics step raises register pressure and was slower at every batch size.)
   __device__ __forceinline__ T forward(const T* X, const T* U, const T* gK, const T* gk, T* Xn,
-                                       T* Un, T* TRn, const T (&xT)[n]) const {
+                                       T* Un, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) {
@@ -398,8 +400,6 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 #pragma unroll
       for (int a = 0; a < m; a++) Un[iu(a, t)] = u[a];
       Sys::trig(x, tr);
-#pragma unroll
-      for (int q = 0; q < NT; q++) TRn[ix(q, t)] = tr[q];
       Sys::step_tr(c, x, u, tr, xn);
 #pragma unroll
       for (int i = 0; i < n; i++) Xn[ix(i, t + 1)] = xn[i];
@@ -407,9 +407,6 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
     }
-    Sys::trig(x, tr);
-#pragma unroll
-    for (int q = 0; q < NT; q++) TRn[ix(q, N)] = tr[q];
     cost = cost + terminal_cost(x, xT);
     return cost;
   }
@@ -452,23 +449,22 @@ __global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys
   T* gK = a.K ? a.K : a.wsK;
   T* gk = a.K ? a.k : a.wsk;
   // per-lane trajectory buffers: "cur" holds the nominal, "nxt" receives the candidate
-  T *Xc = a.X, *Uc = a.U, *TRc = a.wsTR0;
-  T *Xn = a.wsX, *Un = a.wsU, *TRn = a.wsTR1;
+  T *Xc = a.X, *Uc = a.U;
+  T *Xn = a.wsX, *Un = a.wsU;
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
-  T cost = w.rollout(Xc, Uc, TRc, xT);
+  T cost = w.rollout(Xc, Uc, xT);
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
   while (it < a.n_iters) {
-    w.backward(Xc, Uc, TRc, xT, ob, lamb, gK, gk);
-    const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, TRn, xT);
+    w.backward(Xc, Uc, xT, ob, lamb, gK, gk);
+    const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, xT);
     it++;
     if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
       T* tp;
       tp = Xc; Xc = Xn; Xn = tp;
       tp = Uc; Uc = Un; Un = tp;
-      tp = TRc; TRc = TRn; TRn = tp;
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
@@ -500,8 +496,7 @@ __global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys
 
 template <class T, class Sys, bool HASQR>
 __global__ __launch_bounds__(64) void k_lane_rollout(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
-                                                     T* X, T* U, const T* x_term, T* cost,
-                                                     T* wsTR) {
+                                                     T* X, T* U, const T* x_term, T* cost) {
   constexpr int n = Sys::n;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
@@ -509,15 +504,14 @@ __global__ __launch_bounds__(64) void k_lane_rollout(const DevCfg<T, Sys::n, Sys
   T xT[n];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
-  cost[b] = w.rollout(X, U, wsTR, xT);
+  cost[b] = w.rollout(X, U, xT);
 }
 
 template <class T, class Sys, bool HASQR>
 __global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                       const T* X, const T* U, const T* x_term,
-                                                      const T* lamb, const T* obs, T* K, T* k,
-                                                      T* wsTR) {
-  constexpr int n = Sys::n, NT = Sys::NTRIG;
+                                                      const T* lamb, const T* obs, T* K, T* k) {
+  constexpr int n = Sys::n;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   LaneWorker<T, Sys, HASQR> w(c, B, b);
@@ -526,23 +520,14 @@ __global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sy
   for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
 #pragma unroll
   for (int q = 0; q < 6; q++) ob[q] = obs ? obs[(int64_t)q * B + b] : T(q == 5 ? -1 : 1);
-  // trig cache of the given nominal
-  for (int t = 0; t <= c.N; t++) {
-    T x[n], tr[NT];
-#pragma unroll
-    for (int i = 0; i < n; i++) x[i] = X[w.ix(i, t)];
-    Sys::trig(x, tr);
-#pragma unroll
-    for (int q = 0; q < NT; q++) wsTR[w.ix(q, t)] = tr[q];
-  }
-  w.backward(X, U, wsTR, xT, ob, lamb[b], K, k);
+  w.backward(X, U, xT, ob, lamb[b], K, k);
 }
 
 template <class T, class Sys, bool HASQR>
 __global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                      const T* X, const T* U, const T* x_term,
                                                      const T* K, const T* k, T* Xn, T* Un,
-                                                     T* cost_new, T* wsTR) {
+                                                     T* cost_new) {
   constexpr int n = Sys::n;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
@@ -550,7 +535,7 @@ __global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys
   T xT[n];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
-  cost_new[b] = w.forward(X, U, K, k, Xn, Un, wsTR, xT);
+  cost_new[b] = w.forward(X, U, K, k, Xn, Un, xT);
 }
 
 }  // namespace i2lqr

@@ -90,6 +90,32 @@ template <class T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
 template <class T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+// Reciprocal / square root for the 2x2 regularised inverse: hardware seed (v_rcp_f64 / v_rsq_f64)
+// + two Newton steps — <= ~2 ulp on normal-range operands, a third of the instructions of the
+// IEEE-exact division / sqrt expansions.  Zero, infinite and NaN operands behave like 1/x, sqrt(x).
+template <class T> __device__ __forceinline__ T t_rcp(T x);
+template <> __device__ __forceinline__ double t_rcp<double>(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  const double r2 = __builtin_fma(r, e, r);
+  return (r2 == r2) ? r2 : r;  // x = 0 / inf: keep the seed's inf / 0 instead of the NaN of 0 * inf
+}
+template <> __device__ __forceinline__ float t_rcp<float>(float x) { return 1.0f / x; }
+template <class T> __device__ __forceinline__ T t_sqrt_fast(T x);
+template <> __device__ __forceinline__ double t_sqrt_fast<double>(double x) {
+  if (!(x > 1.0e-290) || !(x < 1.0e290)) return __builtin_sqrt(x);  // 0, tiny, huge, NaN
+  const double y = __builtin_amdgcn_rsq(x);       // ~ x^-1/2
+  double g = x * y;                               // ~ sqrt(x)
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+template <> __device__ __forceinline__ float t_sqrt_fast<float>(float x) { return sqrtf(x); }
 // The library is built with -ffp-contract=off so that one source expression rounds the same way
 // in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
 // the dot products of the Riccati step ask for the fused multiply-add explicitly.

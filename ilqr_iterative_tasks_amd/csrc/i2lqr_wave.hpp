@@ -344,9 +344,9 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
       T disc = hd * hd + b * cc;
       disc = disc < T(0) ? T(0) : disc;
-      const T s = t_sqrt(disc);
+      const T s = t_sqrt_fast(disc);
       T l1 = (mean >= T(0)) ? mean + s : mean - s;
-      T l2 = (l1 != T(0)) ? (a * d - b * cc) / l1 : T(0);
+      T l2 = (l1 != T(0)) ? (a * d - b * cc) * t_rcp(l1) : T(0);
       if (s == T(0)) { l1 = mean; l2 = mean; }
       const T w[2] = {l1, l2};
       T vx[2], vy[2], sc[2];
@@ -361,7 +361,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
         if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
         vx[e] = ex;
         vy[e] = ey;
-        sc[e] = T(1) / (nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
+        sc[e] = t_rcp(nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
       }
       inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
       inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
