@@ -93,11 +93,19 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     host = workloads.make_batch(cfg, B, offset=rank * B)
     sets = make_step_buffers(solver, host, steps + warmup, torch)
     qfun = torch.zeros(B, dtype=torch.int32, device=solver.device)
-    cost_it = torch.zeros(B, dtype=solver.dtype, device=solver.device)
+    # one cost vector per step: the exchange of step i (all-gather + arg-min) runs on a side
+    # stream and overlaps the solve of step i+1 (the steps are independent candidate batches)
+    cost_its = [torch.zeros(B, dtype=solver.dtype, device=solver.device)
+                for _ in range(steps + warmup)]
+    main_stream = torch.cuda.current_stream()
+    grouped = dist.is_available() and dist.is_initialized()
+    comm_stream = torch.cuda.Stream() if grouped else None
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    picks = []
 
-    def step(buf, i_timed=None):
+    def step(i_set, i_timed=None):
+        buf, cost_it = sets[i_set], cost_its[i_set]
         if i_timed is not None:
             ev0[i_timed].record()
         solver.iterate(buf, args.iters)
@@ -105,24 +113,31 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             ev1[i_timed].record()
         if with_tail:
             solver.relax_cost(buf["X"], buf["x_term"], qfun, 0, 55, cost_it)
-            cost_all = dist_mod.allgather_costs(cost_it)
-            solver.argmin(cost_all)
+            if comm_stream is None:
+                picks.append(solver.argmin(cost_it))
+            else:
+                ready = torch.cuda.Event()
+                ready.record(main_stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ready)
+                    cost_all = dist_mod.allgather_costs(cost_it)
+                    picks.append(solver.argmin(cost_all))
 
     for i in range(warmup):
-        step(sets[i])
+        step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(sets[warmup + i], i)
-    torch.cuda.synchronize()
-    if world > 1:
+        step(warmup + i, i)
+    torch.cuda.synchronize()  # both streams: every step's exchange and pick is complete
+    if grouped:
         dist.barrier()
         torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([seconds], dtype=torch.float64, device=solver.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
@@ -255,8 +270,8 @@ def main():
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -368,61 +368,123 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       inv[2] = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
       inv[3] = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
     } else {
-      T Sm[m * m], V[m * m];
+      // Symmetrised Quu.  Fast path (the only one taken in practice: l_uu carries the strictly
+      // positive input-barrier curvature): if Quu is positive definite no eigenvalue is clamped
+      // and inv = (Quu + lamb I)^-1, computed by Cholesky.  Otherwise: cyclic Jacobi, clamp, add.
+      T Sm[m * m];
 #pragma unroll
       for (int i = 0; i < m; i++)
 #pragma unroll
-        for (int j = 0; j < m; j++) {
-          Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
-          V[i * m + j] = (i == j) ? T(1) : T(0);
+        for (int j = 0; j < m; j++) Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
+      // Cholesky of Sm (positive-definiteness test) and of Sm + lamb I, lower triangles
+      T Lp[m * m], Lr[m * m];
+      bool pd = true;
+#pragma unroll
+      for (int j = 0; j < m; j++) {
+        T dp = Sm[j * m + j], dr = Sm[j * m + j] + lamb;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+          dp -= Lp[j * m + k] * Lp[j * m + k];
+          dr -= Lr[j * m + k] * Lr[j * m + k];
         }
-      for (int sweep = 0; sweep < 12; sweep++) {
+        pd = pd && (dp > T(0));
+        const T sp = t_sqrt(dp > T(0) ? dp : T(1)), sr = t_sqrt(dr > T(0) ? dr : T(1));
+        Lp[j * m + j] = sp;
+        Lr[j * m + j] = sr;
+        const T ip = T(1) / sp, ir = T(1) / sr;
 #pragma unroll
-        for (int p = 0; p < m - 1; p++)
+        for (int i = j + 1; i < m; i++) {
+          T vp = Sm[i * m + j], vr = Sm[i * m + j];
 #pragma unroll
-          for (int q = p + 1; q < m; q++) {
-            const T apq = Sm[p * m + q];
-            const T app = Sm[p * m + p], aqq = Sm[q * m + q];
-            // rotation angle; apq == 0 gives the identity rotation
-            const T tau = (aqq - app) / (T(2) * apq);
-            T tt = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
-            tt = (apq == T(0)) ? T(0) : tt;
-            const T cs = T(1) / t_sqrt(T(1) + tt * tt), sn = tt * cs;
+          for (int k = 0; k < j; k++) {
+            vp -= Lp[i * m + k] * Lp[j * m + k];
+            vr -= Lr[i * m + k] * Lr[j * m + k];
+          }
+          Lp[i * m + j] = vp * ip;
+          Lr[i * m + j] = vr * ir;
+        }
+      }
+      if (pd) {
+        // inverse of the lower factor, then inv = Lr^-T Lr^-1
+        T Li[m * m];
 #pragma unroll
-            for (int k = 0; k < m; k++) {
-              const T skp = Sm[k * m + p], skq = Sm[k * m + q];
-              Sm[k * m + p] = cs * skp - sn * skq;
-              Sm[k * m + q] = sn * skp + cs * skq;
+        for (int i = 0; i < m; i++)
+#pragma unroll
+          for (int j = 0; j < m; j++) Li[i * m + j] = T(0);
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+          Li[j * m + j] = T(1) / Lr[j * m + j];
+#pragma unroll
+          for (int i = j + 1; i < m; i++) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = j; k < i; k++) acc += Lr[i * m + k] * Li[k * m + j];
+            Li[i * m + j] = -acc / Lr[i * m + i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < m; i++)
+#pragma unroll
+          for (int j = 0; j < m; j++) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = (i > j ? i : j); k < m; k++) acc += Li[k * m + i] * Li[k * m + j];
+            inv[i * m + j] = acc;
+          }
+      } else {
+        T V[m * m];
+#pragma unroll
+        for (int i = 0; i < m; i++)
+#pragma unroll
+          for (int j = 0; j < m; j++) V[i * m + j] = (i == j) ? T(1) : T(0);
+        for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+          for (int p = 0; p < m - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < m; q++) {
+              const T apq = Sm[p * m + q];
+              const T app = Sm[p * m + p], aqq = Sm[q * m + q];
+              // rotation angle; apq == 0 gives the identity rotation
+              const T tau = (aqq - app) / (T(2) * apq);
+              T tt = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
+              tt = (apq == T(0)) ? T(0) : tt;
+              const T cs = T(1) / t_sqrt(T(1) + tt * tt), sn = tt * cs;
+#pragma unroll
+              for (int k = 0; k < m; k++) {
+                const T skp = Sm[k * m + p], skq = Sm[k * m + q];
+                Sm[k * m + p] = cs * skp - sn * skq;
+                Sm[k * m + q] = sn * skp + cs * skq;
+              }
+#pragma unroll
+              for (int k = 0; k < m; k++) {
+                const T spk = Sm[p * m + k], sqk = Sm[q * m + k];
+                Sm[p * m + k] = cs * spk - sn * sqk;
+                Sm[q * m + k] = sn * spk + cs * sqk;
+              }
+#pragma unroll
+              for (int k = 0; k < m; k++) {
+                const T vkp = V[k * m + p], vkq = V[k * m + q];
+                V[k * m + p] = cs * vkp - sn * vkq;
+                V[k * m + q] = sn * vkp + cs * vkq;
+              }
             }
+        }
+        T wr[m];
 #pragma unroll
-            for (int k = 0; k < m; k++) {
-              const T spk = Sm[p * m + k], sqk = Sm[q * m + k];
-              Sm[p * m + k] = cs * spk - sn * sqk;
-              Sm[q * m + k] = sn * spk + cs * sqk;
-            }
+        for (int e = 0; e < m; e++) {
+          const T we = Sm[e * m + e];
+          wr[e] = T(1) / ((we < T(0) ? T(0) : we) + lamb);
+        }
 #pragma unroll
-            for (int k = 0; k < m; k++) {
-              const T vkp = V[k * m + p], vkq = V[k * m + q];
-              V[k * m + p] = cs * vkp - sn * vkq;
-              V[k * m + q] = sn * vkp + cs * vkq;
-            }
+        for (int i = 0; i < m; i++)
+#pragma unroll
+          for (int j = 0; j < m; j++) {
+            T acc = T(0);
+#pragma unroll
+            for (int e = 0; e < m; e++) acc += V[i * m + e] * wr[e] * V[j * m + e];
+            inv[i * m + j] = acc;
           }
       }
-      T wr[m];
-#pragma unroll
-      for (int e = 0; e < m; e++) {
-        const T we = Sm[e * m + e];
-        wr[e] = T(1) / ((we < T(0) ? T(0) : we) + lamb);
-      }
-#pragma unroll
-      for (int i = 0; i < m; i++)
-#pragma unroll
-        for (int j = 0; j < m; j++) {
-          T acc = T(0);
-#pragma unroll
-          for (int e = 0; e < m; e++) acc += V[i * m + e] * wr[e] * V[j * m + e];
-          inv[i * m + j] = acc;
-        }
     }
   }
 

@@ -20,7 +20,10 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (torchrun exports RANK / WORLD_SIZE) the process group is created even for
+    # a world of one, so the single-GPU box exercises the same collective code path
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -44,7 +47,7 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
     full vector in shard order.  Equal shards use a single all_gather_into_tensor (one RCCL
     ncclAllGather, B/world elements per rank); ragged shards are padded with +inf to the largest
     shard and compacted afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return cost_local
     world = dist.get_world_size(group)
     n_local = cost_local.numel()
