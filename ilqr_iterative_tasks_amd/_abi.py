@@ -148,6 +148,10 @@ EXPORTS = {
     "i2lqr_relax_cost": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "i2lqr_argmin_workspace_bytes": (C.c_int64, [C.c_int64]),
     "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "i2lqr_select_candidates": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
+                                          C.c_int32, _P, _P, _P, _P]),
+    "i2lqr_init_candidates": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P, _P, _P]),
+    "i2lqr_pick_best": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -53,9 +53,14 @@ def _plant_step(x, u, dt):
 
 class iLqr(ControlBase):
     def __init__(self, ilqr_param, obstacle=None, system_param=None, solver=None,
-                 lamb_mode="chained", verbose=False):
+                 lamb_mode="chained", verbose=False, device_rounds=False):
         ControlBase.__init__(self)
         assert lamb_mode in ("chained", "independent")
+        # device_rounds: run the three outer rounds (select / solve / relaxed cost / pick) on the
+        # GPU with one read-back per control step (control/device_round.py; independent lamb)
+        assert not device_rounds or lamb_mode == "independent"
+        self.device_rounds = device_rounds
+        self._rounds = None
         self.ilqr_param = ilqr_param
         self.system_param = system_param
         self.ss = []
@@ -184,6 +189,18 @@ class iLqr(ControlBase):
             self.u = self.u_pred[:, 0]
             self.u_old = self.u_pred[:, 1:]
             self.num_horizon = self.num_horizon - 1
+        elif self.device_rounds and self.num_horizon > 1:
+            if self._rounds is None:
+                from .device_round import DeviceRounds
+                self._rounds = DeviceRounds()
+            laps = list(range(min_iter, self.iter))
+            self.u_pred, self.x_pred, (best_loc, best_time), idx = self._rounds.run(self, laps)
+            self.u = self.u_pred[:, 0]
+            self.x_terminal_guess = self.x_pred[:, -1]
+            self.u_old = self.u_pred[:, 1:]
+            best_iter = best_loc + min_iter
+            if (idx[best_loc][best_time] + 1) > (self.ss[best_iter].shape[1] - 1):
+                self.num_horizon = self.num_horizon - 1
         else:
             for it in range(p.max_outloop_iter):
                 candidates = []

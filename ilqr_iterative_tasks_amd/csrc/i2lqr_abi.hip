@@ -11,6 +11,7 @@
 
 #include "../../include/i2lqr.h"
 #include "i2lqr_lane.hpp"
+#include "i2lqr_select.hpp"
 #include "i2lqr_wave.hpp"
 
 using namespace i2lqr;
@@ -630,6 +631,72 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
     hipLaunchKernelGGL((k_argmin_final<float>), dim3(1), dim3(256), 0, s, blocks, part, best_idx,
                        (float*)best_cost);
   }
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int i2lqr_select_candidates(i2lqr_handle* h, int32_t L, int32_t Tmax, const void* ss,
+                            const int32_t* T, const int32_t* qfun, const void* x_guess,
+                            int32_t guess_stride, int32_t k, int32_t* idx, void* x_term,
+                            int32_t* qf, void* stream) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return fail(I2LQR_ERR_UNSUPPORTED, "controller-round kernels need the problem-major layout");
+  if (L < 0 || Tmax < 1 || Tmax > 1024 || k < 1 || k > Tmax || guess_stride < 1)
+    return fail(I2LQR_ERR_INVALID, "need L >= 0, 1 <= k <= Tmax <= 1024, guess_stride >= 1");
+  if (L == 0) return I2LQR_OK;
+  if (!ss || !T || !qfun || !x_guess || !idx || !x_term || !qf)
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_select_candidates<double>), dim3(L), dim3(128), 0, s, h->cfg.n, Tmax, k,
+                       (const double*)ss, T, qfun, (const double*)x_guess, guess_stride, idx,
+                       (double*)x_term, qf);
+  else
+    hipLaunchKernelGGL((k_select_candidates<float>), dim3(L), dim3(128), 0, s, h->cfg.n, Tmax, k,
+                       (const float*)ss, T, qfun, (const float*)x_guess, guess_stride, idx,
+                       (float*)x_term, qf);
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int i2lqr_init_candidates(i2lqr_handle* h, int64_t B, const void* x0, double lamb0, void* X,
+                          void* U, void* lamb, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return fail(I2LQR_ERR_UNSUPPORTED, "controller-round kernels need the problem-major layout");
+  if (B == 0) return I2LQR_OK;
+  if (!x0 || !X || !U || !lamb) return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = h->cfg.n, m = h->cfg.m, N = h->cfg.N;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_init_candidates<double>), dim3((unsigned)B), dim3(64), 0, s, B, n, m, N,
+                       (const double*)x0, lamb0, (double*)X, (double*)U, (double*)lamb);
+  else
+    hipLaunchKernelGGL((k_init_candidates<float>), dim3((unsigned)B), dim3(64), 0, s, B, n, m, N,
+                       (const float*)x0, (float)lamb0, (float*)X, (float*)U, (float*)lamb);
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, const void* X,
+                    const void* U, int32_t* best, void* x_pred, void* u_pred, void* stream) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return fail(I2LQR_ERR_UNSUPPORTED, "controller-round kernels need the problem-major layout");
+  if (L < 1 || k < 1) return fail(I2LQR_ERR_INVALID, "need L >= 1 and k >= 1");
+  if (!cost_it || !X || !U || !best || !x_pred || !u_pred)
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = h->cfg.n, m = h->cfg.m, N = h->cfg.N;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_pick_best<double>), dim3(1), dim3(64), 0, s, L, k, n, m, N,
+                       (const double*)cost_it, (const double*)X, (const double*)U, best,
+                       (double*)x_pred, (double*)u_pred);
+  else
+    hipLaunchKernelGGL((k_pick_best<float>), dim3(1), dim3(64), 0, s, L, k, n, m, N,
+                       (const float*)cost_it, (const float*)X, (const float*)U, best,
+                       (float*)x_pred, (float*)u_pred);
   HIP_TRY(hipGetLastError());
   return I2LQR_OK;
 }

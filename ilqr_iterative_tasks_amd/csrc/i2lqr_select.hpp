@@ -1,0 +1,127 @@
+// GPU-side candidate selection and pick of the i2LQR controller round: with
+// these two kernels the three outer rounds of iLqr.calc_input (utils/base.py:384-478) chain on the
+// device — select -> solve -> relaxed cost -> pick -> next round's guess — with one host
+// read-back per control step instead of three.  Sizes are tiny (<= 16 candidates, <= 128 safe-set
+// columns): one workgroup each, no tuning needed; they exist to remove host round trips.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace i2lqr {
+
+// k nearest safe-set columns in the 1-norm for each of L laps, and the gather of the candidates:
+// replaces iLqr.select_close_ss (utils/base.py:332-341: argsort of the column-wise 1-norm, first
+// k) and the candidate set-up x_terminal = ss[id][:, j], cost_terminal = Qfun[id][j] (:411-412).
+//   ss     [L][n][Tmax]  safe-set states, component-major, time contiguous, padded to Tmax
+//   T      [L]           valid columns per lap
+//   qfun   [L][Tmax]     cost-to-go in steps
+//   xg     x_guess, element i at xg[i * xg_stride]
+// out: idx[L][k], x_term[L*k][n] (problem-major), qf[L*k].  Ties resolve to the lower column
+// (a stable argsort; numpy's default sort is not stable, exact ties do not occur in practice).
+// One workgroup of 128 threads per lap; Tmax <= 1024.
+template <class T>
+__global__ __launch_bounds__(128) void k_select_candidates(int n, int Tmax, int k, const T* ss,
+                                                           const int32_t* Tl, const int32_t* qfun,
+                                                           const T* xg, int xg_stride,
+                                                           int32_t* idx, T* x_term, int32_t* qf) {
+  __shared__ double dist[1024];
+  __shared__ double red_v[128];
+  __shared__ int red_i[128];
+  const int lap = blockIdx.x, tid = threadIdx.x;
+  const int Tn = Tl[lap];
+  const T* S = ss + (int64_t)lap * n * Tmax;
+  for (int j = tid; j < Tmax; j += 128) {
+    double d = INFINITY;
+    if (j < Tn) {
+      d = 0.0;
+      for (int i = 0; i < n; i++) d += fabs((double)S[i * Tmax + j] - (double)xg[i * xg_stride]);
+      if (!(d == d)) d = INFINITY;  // NaN sorts last
+    }
+    dist[j] = d;
+  }
+  __syncthreads();
+  for (int r = 0; r < k; r++) {
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < Tmax; j += 128) {
+      const double d = dist[j];
+      if (d < bv || (d == bv && j < bi)) { bv = d; bi = j; }
+    }
+    red_v[tid] = bv;
+    red_i[tid] = bi;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double ov = red_v[tid + s];
+        const int oi = red_i[tid + s];
+        if (ov < red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) {
+          red_v[tid] = ov;
+          red_i[tid] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    const int j = red_i[0] < Tn ? red_i[0] : (Tn - 1);  // fewer than k finite columns: repeat last
+    if (tid == 0) {
+      idx[lap * k + r] = j;
+      qf[lap * k + r] = qfun[(int64_t)lap * Tmax + j];
+      dist[j] = INFINITY;  // remove from the next round (kept INFINITY if already)
+    }
+    if (tid < n) x_term[(int64_t)(lap * k + r) * n + tid] = S[tid * Tmax + j];
+    __syncthreads();
+  }
+}
+
+// The pick of utils/base.py:462-469: `cost_list.index(min(cost_list))` on a list of L lists
+// (Python compares lists lexicographically), then the first minimum inside that lap's list; the
+// winner's trajectory becomes u_pred / x_pred.  cost_it[L][k], X[L*k][n][N+1], U[L*k][m][N]
+// (problem-major).  out: best[2] = {lap position, candidate position}, x_pred[n][N+1],
+// u_pred[m][N].  One workgroup.
+template <class T>
+__global__ __launch_bounds__(64) void k_pick_best(int L, int k, int n, int m, int N,
+                                                  const T* cost_it, const T* X, const T* U,
+                                                  int32_t* best, T* x_pred, T* u_pred) {
+  __shared__ int s_best[2];
+  if (threadIdx.x == 0) {
+    // Python list ordering: first differing element decides; NaN compares false both ways,
+    // which Python's list comparison treats as "not less" -> keep the earlier list
+    int bl = 0;
+    for (int l = 1; l < L; l++) {
+      bool less = false;
+      for (int c = 0; c < k; c++) {
+        const T a = cost_it[l * k + c], b = cost_it[bl * k + c];
+        if (a == b) continue;
+        less = a < b;
+        break;
+      }
+      if (less) bl = l;
+    }
+    int bc = 0;
+    for (int c = 1; c < k; c++)
+      if (cost_it[bl * k + c] < cost_it[bl * k + bc]) bc = c;
+    s_best[0] = bl;
+    s_best[1] = bc;
+    best[0] = bl;
+    best[1] = bc;
+  }
+  __syncthreads();
+  const int64_t w = (int64_t)s_best[0] * k + s_best[1];
+  for (int e = threadIdx.x; e < n * (N + 1); e += 64) x_pred[e] = X[w * n * (N + 1) + e];
+  for (int e = threadIdx.x; e < m * N; e += 64) u_pred[e] = U[w * m * N + e];
+}
+
+// broadcast x0 into X[:, :, 0] and zero / reset the per-candidate in/out state for one round:
+// uvar = 0, xvar[:, 0] = x (utils/base.py:405-408), lamb = lamb0 (:393)
+template <class T>
+__global__ void k_init_candidates(int64_t B, int n, int m, int N, const T* x0, T lamb0, T* X, T* U,
+                                  T* lamb) {
+  const int64_t b = blockIdx.x;
+  for (int e = threadIdx.x; e < n * (N + 1); e += blockDim.x) {
+    const int i = e / (N + 1), t = e - i * (N + 1);
+    X[b * n * (N + 1) + e] = (t == 0) ? x0[i] : T(0);
+  }
+  for (int e = threadIdx.x; e < m * N; e += blockDim.x) U[b * m * N + e] = T(0);
+  if (threadIdx.x == 0) lamb[b] = lamb0;
+}
+
+}  // namespace i2lqr

@@ -213,6 +213,45 @@ class BatchedILQR:
                 int(max_relax_iter), self._ptr(cost_it, (B,), name="cost_it"), self._stream()))
         return cost_it
 
+    # -- controller round on the device (problem-major layout) -----------------------------------
+    def select_candidates(self, ss, T, qfun, x_guess, guess_stride: int, k: int, idx, x_term, qf):
+        """utils/base.py:332-341 + :411-412 for L laps: ss[L,n,Tmax], T[L] int32, qfun[L,Tmax]
+        int32; x_guess element i at x_guess.data_ptr() + i*guess_stride.  Fills idx[L,k] int32,
+        x_term[L*k,n], qf[L*k] int32."""
+        L, n, Tmax = ss.shape
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_select_candidates(
+                self._handle, L, Tmax, self._ptr(ss, (L, self.n, Tmax), name="ss"),
+                self._ptr(T, (L,), torch.int32, name="T"),
+                self._ptr(qfun, (L, Tmax), torch.int32, name="qfun"),
+                C.c_void_p(x_guess.data_ptr()), int(guess_stride), int(k),
+                self._ptr(idx, (L, k), torch.int32, name="idx"),
+                self._ptr(x_term, (L * k, self.n), name="x_term"),
+                self._ptr(qf, (L * k,), torch.int32, name="qf"), self._stream()))
+
+    def init_candidates(self, x0, lamb0: float, buf: dict):
+        """uvar = 0, xvar[:, 0] = x0, lamb = lamb0 (utils/base.py:393, :405-408) for every problem
+        of `buf`."""
+        B = buf["X"].shape[0]
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_init_candidates(
+                self._handle, B, self._ptr(x0, (self.n,), name="x0"), float(lamb0),
+                self._ptr(buf["X"], self.shape("X", B), name="X"),
+                self._ptr(buf["U"], self.shape("U", B), name="U"),
+                self._ptr(buf["lamb"], (B,), name="lamb"), self._stream()))
+
+    def pick_best(self, L: int, k: int, cost_it, X, U, best, x_pred, u_pred):
+        """utils/base.py:462-469 on the device; best[2] int32, x_pred[n,N+1], u_pred[m,N]."""
+        B = L * k
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_pick_best(
+                self._handle, L, k, self._ptr(cost_it, (B,), name="cost_it"),
+                self._ptr(X, (B, self.n, self.N + 1), name="X"),
+                self._ptr(U, (B, self.m, self.N), name="U"),
+                self._ptr(best, (2,), torch.int32, name="best"),
+                self._ptr(x_pred, (self.n, self.N + 1), name="x_pred"),
+                self._ptr(u_pred, (self.m, self.N), name="u_pred"), self._stream()))
+
     def argmin(self, cost_it):
         """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1])."""
         B = cost_it.shape[0]

@@ -197,6 +197,29 @@ int64_t i2lqr_argmin_workspace_bytes(int64_t B);
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
                  void* best_cost, void* workspace, void* stream);
 
+/*
+ * Controller round on the device (problem-major layout).
+ *
+ * i2lqr_select_candidates — replaces iLqr.select_close_ss (utils/base.py:332-341) and the
+ * candidate set-up (:405-412) for L laps at once: the k nearest safe-set columns to x_guess in the
+ * 1-norm (ascending, ties to the lower column), their states as x_term and their cost-to-go.
+ *   ss[L][n][Tmax] (`real`, component-major, time contiguous, padded), T[L], qfun[L][Tmax] (int32),
+ *   x_guess: element i at x_guess[i * guess_stride]  (so X_pred[:, N] can be passed in place).
+ *   out: idx[L][k] (int32), x_term[L*k][n], qf[L*k] (int32).   Tmax <= 1024, k <= Tmax.
+ * i2lqr_init_candidates — uvar = 0, xvar[:, 0] = x0, lamb = lamb0 for B candidates (:393, :405-408).
+ * i2lqr_pick_best — the pick of utils/base.py:462-469 on cost_it[L][k] (lexicographic over the
+ *   laps' lists, then first minimum); copies the winner's X, U to x_pred[n][N+1], u_pred[m][N];
+ *   best[2] = {lap position, candidate position} (int32, device).
+ */
+int i2lqr_select_candidates(i2lqr_handle* h, int32_t L, int32_t Tmax, const void* ss,
+                            const int32_t* T, const int32_t* qfun, const void* x_guess,
+                            int32_t guess_stride, int32_t k, int32_t* idx, void* x_term,
+                            int32_t* qf, void* stream);
+int i2lqr_init_candidates(i2lqr_handle* h, int64_t B, const void* x0, double lamb0, void* X,
+                          void* U, void* lamb, void* stream);
+int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, const void* X,
+                    const void* U, int32_t* best, void* x_pred, void* u_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
