@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=[None, "f64", "f32"])
     ap.add_argument("--iters", type=int, default=10, help="fused iLQR iterations per step")
-    ap.add_argument("--layout", default="auto", choices=["auto", "wave", "lane"],
+    ap.add_argument("--layout", default="auto", choices=["auto", "wave", "lane", "tiled"],
                     help="kernel family: wave = one problem per wavefront (problem-major), lane = "
                          "one problem per lane (batch-minor); auto picks by batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,10 +53,20 @@ def parse_args():
 LANE_THRESHOLD = 4096  # per-GPU batch from which the one-problem-per-lane kernels win
 
 
-def pick_layout(args, B):
+TILED_THRESHOLD_F64 = 131072  # from here the tiled rows beat the batch-wide rows (fp64)
+LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
+
+
+def pick_layout(args, B, dtype="f64"):
+    """wave: one problem per wavefront (latency path); lane / tiled: one problem per lane over
+    batch-minor rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
     if args.layout != "auto":
         return args.layout
-    return "lane" if B >= LANE_THRESHOLD else "wave"
+    if B < LANE_THRESHOLD or B % 64:
+        return "wave" if B < LANE_THRESHOLD else "lane"
+    if dtype == "f32" or B >= TILED_THRESHOLD_F64:
+        return "tiled"
+    return "lane"
 
 
 def make_step_buffers(solver, host, n_sets, torch):
@@ -88,7 +98,8 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     import torch.distributed as dist
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    cfg.layout = 1 if pick_layout(args, B) == "lane" else 0
+    layout = pick_layout(args, B, "f64" if cfg.dtype == 0 else "f32")
+    cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     host = workloads.make_batch(cfg, B, offset=rank * B)
     sets = make_step_buffers(solver, host, steps + warmup, torch)
@@ -146,9 +157,10 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
     solver.close()
     return dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps,
-                kernel="k_lane_iterate" if cfg.layout == 1 else "k_iterate",
-                layout="batch-minor (one problem per lane)" if cfg.layout == 1
-                else "problem-major (one problem per wavefront)")
+                kernel="k_iterate" if layout == "wave" else "k_lane_iterate",
+                layout={"wave": "problem-major (one problem per wavefront)",
+                        "lane": "batch-minor (one problem per lane)",
+                        "tiled": "batch-tiled x64 (one problem per lane)"}[layout])
 
 
 def cpu_baseline(cfg, B, iters, budget_s):

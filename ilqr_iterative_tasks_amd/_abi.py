@@ -18,7 +18,7 @@ MAX_HORIZON = 64
 OBS_WORDS = 6
 
 F64, F32 = 0, 1
-LAYOUT_PROBLEM_MAJOR, LAYOUT_BATCH_MINOR = 0, 1
+LAYOUT_PROBLEM_MAJOR, LAYOUT_BATCH_MINOR, LAYOUT_BATCH_TILED = 0, 1, 2
 SYS_BICYCLE4, SYS_BICYCLE6, SYS_QUAD12 = 0, 1, 2
 SYSTEM_DIMS = {SYS_BICYCLE4: (4, 2), SYS_BICYCLE6: (6, 2), SYS_QUAD12: (12, 4)}
 SYSTEM_NAMES = {"bicycle4": SYS_BICYCLE4, "bicycle6": SYS_BICYCLE6, "quad12": SYS_QUAD12}

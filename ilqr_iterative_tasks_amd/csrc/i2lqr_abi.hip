@@ -192,7 +192,7 @@ template <class T, class Sys> struct Launch {
 };
 
 // Batch-minor layout: one problem per lane (i2lqr_lane.hpp); m == 2 systems.
-template <class T, class Sys> struct LaneLaunch {
+template <class T, class Sys, bool TILED> struct LaneLaunch {
   static constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
   using Cfg = DevCfg<T, n, m>;
   static unsigned grid(int64_t B) { return (unsigned)((B + 63) / 64); }
@@ -205,6 +205,9 @@ template <class T, class Sys> struct LaneLaunch {
     return I2LQR_OK;
   }
   static int need_ws(i2lqr_handle* h, int64_t B) {
+    if (TILED && (B & 63))
+      return fail(I2LQR_ERR_INVALID, "the batch-tiled layout needs a batch that is a multiple of "
+                  "64 (got %lld)", (long long)B);
     const int64_t need = ws_bytes(h->cfg.N, B);
     if (!h->ws || h->ws_bytes < need)
       return fail(I2LQR_ERR_INVALID, "workspace of %lld B registered, batch %lld needs %lld B "
@@ -232,9 +235,9 @@ template <class T, class Sys> struct LaneLaunch {
     a.iters = iters; a.status = status;
     carve(h, B, a);
     if (c.flags)
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, a);
     else
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, a);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -245,10 +248,10 @@ template <class T, class Sys> struct LaneLaunch {
     LaneArgs<T> a;
     carve(h, B, a);
     if (c.flags)
-      hipLaunchKernelGGL((k_lane_rollout<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_rollout<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     else
-      hipLaunchKernelGGL((k_lane_rollout<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_rollout<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
@@ -260,11 +263,11 @@ template <class T, class Sys> struct LaneLaunch {
     LaneArgs<T> a;
     carve(h, B, a);
     if (c.flags)
-      hipLaunchKernelGGL((k_lane_backward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_backward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
                          (const T*)obs, (T*)K, (T*)k);
     else
-      hipLaunchKernelGGL((k_lane_backward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_backward<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
                          (const T*)obs, (T*)K, (T*)k);
     HIP_TRY(hipGetLastError());
@@ -278,11 +281,11 @@ template <class T, class Sys> struct LaneLaunch {
     LaneArgs<T> a;
     carve(h, B, a);
     if (c.flags)
-      hipLaunchKernelGGL((k_lane_forward<T, Sys, true>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_forward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
                          (T*)Xn, (T*)Un, (T*)cost_new);
     else
-      hipLaunchKernelGGL((k_lane_forward<T, Sys, false>), dim3(grid(B)), dim3(64), 0, s, c, B,
+      hipLaunchKernelGGL((k_lane_forward<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
                          (T*)Xn, (T*)Un, (T*)cost_new);
     HIP_TRY(hipGetLastError());
@@ -296,13 +299,28 @@ template <class T, class Sys> struct LaneLaunch {
     const int sid_ = (h)->cfg.system_id;                                                      \
     if ((h)->cfg.layout == I2LQR_LAYOUT_BATCH_MINOR) {                                        \
       if ((h)->cfg.dtype == I2LQR_F64) {                                                      \
-        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<double, Bicycle4<double>>::CALL;    \
-        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<double, Bicycle6<double>>::CALL;    \
+        if (sid_ == I2LQR_SYS_BICYCLE4)                                                       \
+          return LaneLaunch<double, Bicycle4<double>, false>::CALL;                           \
+        if (sid_ == I2LQR_SYS_BICYCLE6)                                                       \
+          return LaneLaunch<double, Bicycle6<double>, false>::CALL;                           \
       } else {                                                                                \
-        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>>::CALL;      \
-        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>>::CALL;      \
+        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, false>::CALL; \
+        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, false>::CALL; \
       }                                                                                       \
       return fail(I2LQR_ERR_UNSUPPORTED, "system %d is not built for the batch-minor layout", \
+                  sid_);                                                                      \
+    }                                                                                         \
+    if ((h)->cfg.layout == I2LQR_LAYOUT_BATCH_TILED) {                                        \
+      if ((h)->cfg.dtype == I2LQR_F64) {                                                      \
+        if (sid_ == I2LQR_SYS_BICYCLE4)                                                       \
+          return LaneLaunch<double, Bicycle4<double>, true>::CALL;                            \
+        if (sid_ == I2LQR_SYS_BICYCLE6)                                                       \
+          return LaneLaunch<double, Bicycle6<double>, true>::CALL;                            \
+      } else {                                                                                \
+        if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, true>::CALL; \
+        if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, true>::CALL; \
+      }                                                                                       \
+      return fail(I2LQR_ERR_UNSUPPORTED, "system %d is not built for the batch-tiled layout", \
                   sid_);                                                                      \
     }                                                                                         \
     if ((h)->cfg.dtype == I2LQR_F64) {                                                        \
@@ -480,7 +498,8 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
     return fail(I2LQR_ERR_INVALID, "horizon %d outside [1, %d]", cfg->N, I2LQR_MAX_HORIZON);
   if (cfg->dtype != I2LQR_F64 && cfg->dtype != I2LQR_F32)
     return fail(I2LQR_ERR_INVALID, "unknown dtype %d", cfg->dtype);
-  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR && cfg->layout != I2LQR_LAYOUT_BATCH_MINOR)
+  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR && cfg->layout != I2LQR_LAYOUT_BATCH_MINOR &&
+      cfg->layout != I2LQR_LAYOUT_BATCH_TILED)
     return fail(I2LQR_ERR_INVALID, "unknown layout %d", cfg->layout);
   if (!(cfg->dt > 0) || !(cfg->lamb_factor > 1) || cfg->max_iter < 0)
     return fail(I2LQR_ERR_INVALID, "need dt > 0, lamb_factor > 1, max_iter >= 0");
@@ -511,7 +530,8 @@ int i2lqr_destroy(i2lqr_handle* h) {
 }
 
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
-  if (!h || B < 0 || h->cfg.layout != I2LQR_LAYOUT_BATCH_MINOR) return 0;
+  if (!h || B < 0 || h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) return 0;
+  if (h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED) B = (B + 63) / 64 * 64;
   const int64_t sz = h->cfg.dtype == I2LQR_F64 ? 8 : 4;
   const int N = h->cfg.N;
   switch (h->cfg.system_id) {
@@ -591,7 +611,7 @@ int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_te
   if (outer_iter < 0 || max_relax_iter < 1)
     return fail(I2LQR_ERR_INVALID, "need outer_iter >= 0 and max_relax_iter >= 1");
   const unsigned grid = (unsigned)((B + 255) / 256);
-  const int bm = h->cfg.layout == I2LQR_LAYOUT_BATCH_MINOR;
+  const int bm = h->cfg.layout;  // 0 problem-major, 1 batch-minor, 2 batch-tiled
   hipStream_t s = (hipStream_t)stream;
   if (h->cfg.dtype == I2LQR_F64)
     hipLaunchKernelGGL((k_relax_cost<double>), dim3(grid), dim3(256), 0, s, B, h->cfg.n, h->cfg.N,

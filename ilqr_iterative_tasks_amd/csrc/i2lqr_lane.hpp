@@ -48,6 +48,21 @@ template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int
   return B * (int64_t)(n * (N + 1) + m * N + m * n * N + m * N);
 }
 
+// Batch-minor ("rows of B") vs batch-tiled ("tiles of 64 problems, rows of 64") addressing.  In
+// the tiled layout all rows of a wavefront's 64 problems are contiguous (one ~0.7 MB region at
+// n=6, N=20, fp64): DRAM-page and TLB friendly at very large B.  Each array of `rows` rows is
+// re-based to the wavefront's tile, after which the kernels index it as a batch of 64.
+template <bool TILED> struct LaneView {
+  int64_t Bs;  // row stride
+  int64_t bl;  // this lane's index inside a row
+  int64_t tile;
+  __device__ LaneView(int64_t B, int64_t b)
+      : Bs(TILED ? 64 : B), bl(TILED ? (b & 63) : b), tile(TILED ? (b >> 6) : 0) {}
+  template <class P> __device__ __forceinline__ P* rebase(P* p, int rows) const {
+    return (TILED && p) ? p + tile * (int64_t)rows * 64 : p;
+  }
+};
+
 template <class T, class Sys, bool HASQR> struct LaneWorker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG, NV = Sys::NVAR;
   using Cfg = DevCfg<T, n, m>;
@@ -432,25 +447,32 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 // ---------------------------------------------------------------------------------------------
 // Kernels: 64-thread workgroups (one wavefront), one problem per lane.
 // ---------------------------------------------------------------------------------------------
-template <class T, class Sys, bool HASQR>
-__global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys::m> c,
-                                                     const LaneArgs<T> a) {
+// fp32 fits two waves per SIMD (<= 256 registers) with a few spilled words; fp64 needs ~450
+// registers for the unrolled Riccati step and runs one wave per SIMD.
+template <class T, class Sys, bool HASQR, bool TILED>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
+    const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
-  LaneWorker<T, Sys, HASQR> w(c, a.B, b);
   const int N = c.N;
+  const LaneView<TILED> v(a.B, b);
+  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const T* gxt = v.rebase(a.x_term, n);
+  const T* gob = v.rebase(a.obs, 6);
   T xT[n], ob[6];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = a.x_term[(int64_t)i * a.B + b];
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
 #pragma unroll
-  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[(int64_t)q * a.B + b] : T(q == 5 ? -1 : 1);
+  for (int q = 0; q < 6; q++) ob[q] = gob ? gob[(int64_t)q * v.Bs + v.bl] : T(q == 5 ? -1 : 1);
   T lamb = a.lamb[b];
-  T* gK = a.K ? a.K : a.wsK;
-  T* gk = a.K ? a.k : a.wsk;
+  T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
+  T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
   // per-lane trajectory buffers: "cur" holds the nominal, "nxt" receives the candidate
-  T *Xc = a.X, *Uc = a.U;
-  T *Xn = a.wsX, *Un = a.wsU;
+  T* const X0 = v.rebase(a.X, n * (N + 1));
+  T* const U0 = v.rebase(a.U, m * N);
+  T *Xc = X0, *Uc = U0;
+  T *Xn = v.rebase(a.wsX, n * (N + 1)), *Un = v.rebase(a.wsU, m * N);
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
@@ -484,9 +506,10 @@ __global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys
     }
   }
   if (!t_isfinite(cost_ret)) status = 4;
-  if (Xc != a.X) {  // the accepted trajectory sits in the workspace: copy it out
-    for (int e = 0; e < n * (N + 1); e++) a.X[(int64_t)e * a.B + b] = Xc[(int64_t)e * a.B + b];
-    for (int e = 0; e < m * N; e++) a.U[(int64_t)e * a.B + b] = Uc[(int64_t)e * a.B + b];
+  if (Xc != X0) {  // the accepted trajectory sits in the workspace: copy it out
+    for (int e = 0; e < n * (N + 1); e++)
+      X0[(int64_t)e * v.Bs + v.bl] = Xc[(int64_t)e * v.Bs + v.bl];
+    for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
   }
   a.lamb[b] = lamb;
   a.cost[b] = cost_ret;
@@ -494,48 +517,59 @@ __global__ __launch_bounds__(64) void k_lane_iterate(const DevCfg<T, Sys::n, Sys
   if (a.status) a.status[b] = status;
 }
 
-template <class T, class Sys, bool HASQR>
+template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(64) void k_lane_rollout(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                      T* X, T* U, const T* x_term, T* cost) {
-  constexpr int n = Sys::n;
+  constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  const LaneView<TILED> v(B, b);
+  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const T* gxt = v.rebase(x_term, n);
   T xT[n];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
-  cost[b] = w.rollout(X, U, xT);
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
+  cost[b] = w.rollout(v.rebase(X, n * (c.N + 1)), v.rebase(U, m * c.N), xT);
 }
 
-template <class T, class Sys, bool HASQR>
+template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                       const T* X, const T* U, const T* x_term,
                                                       const T* lamb, const T* obs, T* K, T* k) {
-  constexpr int n = Sys::n;
+  constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  const int N = c.N;
+  const LaneView<TILED> v(B, b);
+  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const T* gxt = v.rebase(x_term, n);
+  const T* gob = v.rebase(obs, 6);
   T xT[n], ob[6];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
 #pragma unroll
-  for (int q = 0; q < 6; q++) ob[q] = obs ? obs[(int64_t)q * B + b] : T(q == 5 ? -1 : 1);
-  w.backward(X, U, xT, ob, lamb[b], K, k);
+  for (int q = 0; q < 6; q++) ob[q] = gob ? gob[(int64_t)q * v.Bs + v.bl] : T(q == 5 ? -1 : 1);
+  w.backward(v.rebase(X, n * (N + 1)), v.rebase(U, m * N), xT, ob, lamb[b],
+             v.rebase(K, m * n * N), v.rebase(k, m * N));
 }
 
-template <class T, class Sys, bool HASQR>
+template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys::m> c, int64_t B,
                                                      const T* X, const T* U, const T* x_term,
                                                      const T* K, const T* k, T* Xn, T* Un,
                                                      T* cost_new) {
-  constexpr int n = Sys::n;
+  constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  LaneWorker<T, Sys, HASQR> w(c, B, b);
+  const int N = c.N;
+  const LaneView<TILED> v(B, b);
+  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const T* gxt = v.rebase(x_term, n);
   T xT[n];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = x_term[(int64_t)i * B + b];
-  cost_new[b] = w.forward(X, U, K, k, Xn, Un, xT);
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
+  cost_new[b] = w.forward(v.rebase(X, n * (N + 1)), v.rebase(U, m * N), v.rebase(K, m * n * N),
+                          v.rebase(k, m * N), v.rebase(Xn, n * (N + 1)), v.rebase(Un, m * N), xT);
 }
 
 }  // namespace i2lqr

@@ -933,9 +933,18 @@ __global__ void k_relax_cost(int64_t B, int n, int N, int batch_minor, const T* 
   if (b >= B) return;
   double ss = 0.0;
   for (int i = 0; i < n; i++) {
-    const double xN = batch_minor ? (double)X[((int64_t)i * (N + 1) + N) * B + b]
-                                  : (double)X[b * (int64_t)(n * (N + 1)) + i * (N + 1) + N];
-    const double xt = batch_minor ? (double)x_term[(int64_t)i * B + b] : (double)x_term[b * n + i];
+    double xN, xt;  // batch_minor: 0 problem-major, 1 batch-minor, 2 batch-tiled (tiles of 64)
+    if (batch_minor == 2) {
+      const int64_t tile = b >> 6, l = b & 63;
+      xN = (double)X[(tile * (int64_t)(n * (N + 1)) + (int64_t)i * (N + 1) + N) * 64 + l];
+      xt = (double)x_term[(tile * n + i) * 64 + l];
+    } else if (batch_minor == 1) {
+      xN = (double)X[((int64_t)i * (N + 1) + N) * B + b];
+      xt = (double)x_term[(int64_t)i * B + b];
+    } else {
+      xN = (double)X[b * (int64_t)(n * (N + 1)) + i * (N + 1) + N];
+      xt = (double)x_term[b * n + i];
+    }
     const double d = xN - xt;
     ss += d * d;
   }

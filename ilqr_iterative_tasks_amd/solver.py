@@ -10,6 +10,8 @@ Tensor layouts (cfg.layout):
     X[B, n, N+1]   U[B, m, N]   K[B, m, n, N]   k[B, m, N]   x_term[B, n]   lamb[B]   obs[B, 6]
   batch-minor (batch index fastest) — one problem per lane kernels, the large-batch path:
     X[n, N+1, B]   U[m, N, B]   K[m, n, N, B]   k[m, N, B]   x_term[n, B]   lamb[B]   obs[6, B]
+  batch-tiled (batch-minor inside tiles of 64 problems; B % 64 == 0) — same kernels:
+    X[B/64, n, N+1, 64]   U[B/64, m, N, 64]   K[B/64, m, n, N, 64]   ...   lamb[B] (flat)
 `to_native()` / `to_problem_major()` convert between the two.
 """
 from __future__ import annotations
@@ -43,6 +45,7 @@ class BatchedILQR:
         self._handle = handle
         self._argmin_ws = None
         self.batch_minor = cfg.layout == _abi.LAYOUT_BATCH_MINOR
+        self.batch_tiled = cfg.layout == _abi.LAYOUT_BATCH_TILED
         self._ws = None  # scratch of the batch-minor kernels (registered on the handle)
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -85,20 +88,33 @@ class BatchedILQR:
         core = {"X": (n, N + 1), "U": (m, N), "K": (m, n, N), "k": (m, N), "x_term": (n,),
                 "obs": (OBS_WORDS,), "lamb": (), "cost": (), "iters": (), "status": (),
                 "qfun": (), "cost_it": ()}[name]
+        if self.batch_tiled and core:
+            if B % 64:
+                raise ValueError(f"batch-tiled layout needs B % 64 == 0, got {B}")
+            return (B // 64,) + core + (64,)
         return core + (B,) if self.batch_minor else (B,) + core
 
     def to_native(self, t: torch.Tensor) -> torch.Tensor:
         """problem-major [B, ...] tensor -> this solver's layout (contiguous)."""
-        if not self.batch_minor or t.dim() == 1:
+        if t.dim() == 1 or not (self.batch_minor or self.batch_tiled):
             return t.contiguous()
+        if self.batch_tiled:
+            if t.shape[0] % 64:
+                raise ValueError(f"batch-tiled layout needs B % 64 == 0, got {t.shape[0]}")
+            return t.reshape(t.shape[0] // 64, 64, *t.shape[1:]).movedim(1, -1).contiguous()
         return t.movedim(0, -1).contiguous()
 
     def to_problem_major(self, t: torch.Tensor) -> torch.Tensor:
-        if not self.batch_minor or t.dim() == 1:
+        if t.dim() == 1 or not (self.batch_minor or self.batch_tiled):
             return t
+        if self.batch_tiled:
+            u = t.movedim(-1, 1)
+            return u.reshape(u.shape[0] * 64, *u.shape[2:]).contiguous()
         return t.movedim(-1, 0).contiguous()
 
     def batch_of(self, X: torch.Tensor) -> int:
+        if self.batch_tiled:
+            return X.shape[0] * 64
         return X.shape[-1] if self.batch_minor else X.shape[0]
 
     def ensure_workspace(self, B: int) -> None:

@@ -24,6 +24,10 @@
  *    Layout I2LQR_LAYOUT_BATCH_MINOR: the batch index is the fastest axis
  *        X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  obs[6][B]
  *    (one problem per lane; used by the throughput kernels).
+ *    Layout I2LQR_LAYOUT_BATCH_TILED: batch-minor inside tiles of 64 problems, tiles outermost
+ *        X[B/64][n][N+1][64]  U[B/64][m][N][64]  K[B/64][m][n][N][64]  k[B/64][m][N][64]
+ *        x_term[B/64][n][64]  obs[B/64][6][64];  lamb, cost, iters, status stay flat [B].
+ *    B must be a multiple of 64.  Same kernels; every wavefront's rows are contiguous in HBM.
  *  - obs record = {x, y, width, height, spd, moving_option}; moving_option 0 = static,
  *    1 = moving up (+y), 2 = moving left (-x) (utils/base.py:23-34, control/ilqr_helper.py:34-43);
  *    moving_option < 0 disables the obstacle for that problem (the reference's `obstacle is None`).
@@ -47,7 +51,7 @@ extern "C" {
 /* cfg.dtype */
 enum { I2LQR_F64 = 0, I2LQR_F32 = 1 };
 /* cfg.layout */
-enum { I2LQR_LAYOUT_PROBLEM_MAJOR = 0, I2LQR_LAYOUT_BATCH_MINOR = 1 };
+enum { I2LQR_LAYOUT_PROBLEM_MAJOR = 0, I2LQR_LAYOUT_BATCH_MINOR = 1, I2LQR_LAYOUT_BATCH_TILED = 2 };
 /* cfg.system_id: the plant model (reference: systems/kinetic_bicycle.py:10-52 for BICYCLE4) */
 enum {
   I2LQR_SYS_BICYCLE4 = 0, /* reference plant: [x,y,v,theta], [accel,delta]            n=4  m=2 */

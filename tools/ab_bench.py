@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of the fused iterate kernel across layouts / dtypes / batches in ONE
+process (cdna guide §5.4 rule 24): variants x rounds, median and min per variant."""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+
+from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="config2")
+ap.add_argument("--variants", default="lane:f64:65536,tiled:f64:65536")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--iters", type=int, default=10)
+args = ap.parse_args()
+
+LAY = {"wave": 0, "lane": 1, "tiled": 2}
+runs = []
+for v in args.variants.split(","):
+    layout, dtype, B = v.split(":")
+    B = int(B)
+    cfg = workloads.config_for(args.workload, dtype)
+    cfg.layout = LAY[layout]
+    solver = BatchedILQR(cfg)
+    host = workloads.make_batch(cfg, B)
+    dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
+    buf = solver.alloc(B)
+    for key in ("X", "U", "x_term", "lamb"):
+        buf[key].copy_(dev(host[key]))
+    buf["obs"] = dev(host["obs"])
+    init = {k: buf[k].clone() for k in ("X", "U", "lamb")}
+    runs.append((v, solver, buf, init, B, []))
+
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for r in range(args.rounds + 1):
+    for v, solver, buf, init, B, times in runs:
+        for k in init:
+            buf[k].copy_(init[k])
+        torch.cuda.synchronize()
+        e0.record()
+        solver.iterate(buf, args.iters)
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0:
+            times.append(e0.elapsed_time(e1))
+for v, solver, buf, init, B, times in runs:
+    t = np.array(times)
+    print(f"{v:24s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  -> "
+          f"{B * args.iters / np.median(t) / 1e3:8.1f} M it/s (median)  "
+          f"{B * args.iters / t.min() / 1e3:8.1f} (best)")

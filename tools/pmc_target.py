@@ -19,7 +19,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--launches", type=int, default=5)
 args = ap.parse_args()
 cfg = workloads.config_for(args.workload, args.dtype)
-cfg.layout = 1 if args.layout == "lane" else 0
+cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[args.layout]
 solver = BatchedILQR(cfg)
 host = workloads.make_batch(cfg, args.batch)
 dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))

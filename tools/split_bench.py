@@ -33,7 +33,7 @@ def main():
     args = ap.parse_args()
     for layout, dtype in [(l, d) for l in args.layouts.split(",") for d in args.dtypes.split(",")]:
         cfg = workloads.config_for(args.workload, dtype)
-        cfg.layout = 1 if layout == "lane" else 0
+        cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[layout]
         solver = BatchedILQR(cfg)
         for B in [int(b) for b in args.batches.split(",")]:
             host = workloads.make_batch(cfg, B)
