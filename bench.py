@@ -163,6 +163,31 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                         "tiled": "batch-tiled x64 (one problem per lane)"}[layout])
 
 
+def run_solve(args, cfg, B, torch, reps=3):
+    from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+    cfg = cfg.copy()
+    layout = pick_layout(args, B, "f64" if cfg.dtype == 0 else "f32")
+    cfg.layout = LAYOUT_ID[layout]
+    solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
+    host = workloads.make_batch(cfg, B)
+    sets = make_step_buffers(solver, host, reps + 1, torch)
+    solver.solve(sets[0])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        solver.solve(sets[1 + i])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    it = sets[1]["iters"].double()
+    executed = float(it.sum())
+    solver.close()
+    return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
+            "iterations_mean": executed / B, "iterations_max": int(it.max()),
+            "kernel": "k_iterate" if layout == "wave" else "k_lane_iterate"}
+
+
 def cpu_baseline(cfg, B, iters, budget_s):
     """The CPU oracle (a port of the reference algorithm, oracle/ilqr_oracle.c, OpenMP over the
     batch) on the host cores of this box: same synthetic workload, same fixed iteration count,
@@ -279,6 +304,11 @@ def main():
             extra[name] = {"iterations_per_s": r["iterations"] / r["seconds"],
                            "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
                            "achieved_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS}
+        # solve to termination (reference exits: 1..150 iterations per problem): executed
+        # iterations per second — lanes that finish early idle until their wavefront's slowest
+        # problem is done, so this is below the fixed-count rate
+        extra["solve_to_termination_B65536_f64"] = run_solve(args, workloads.config_for(
+            args.workload, "f64"), 65536, torch)
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))

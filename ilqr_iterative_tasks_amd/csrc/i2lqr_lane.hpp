@@ -34,12 +34,17 @@ template <int Begin, int End, class F> __device__ __forceinline__ void static_fo
 }
 
 template <class T> struct LaneArgs {
-  int64_t B;
+  int64_t B;                 // row stride (capacity) of every array; also the batch unless `count`
   int n_iters, early_exit;
   T* X; T* U; const T* x_term; T* lamb; const T* obs; T* cost; T* K; T* k;
   int32_t* iters; int32_t* status;
   // workspace (batch-minor): candidate trajectory, gains if K == null
   T* wsX; T* wsU; T* wsK; T* wsk;
+  // chunked solve (solve_compacting): the live batch size is read from device memory, the
+  // iteration counter continues from iters[b], and a problem that is still running when the
+  // chunk ends gets status RUNNING unless it has reached max_total iterations
+  const int32_t* count;
+  int resume, max_total;
 };
 
 // words of T the workspace needs for B problems
@@ -454,7 +459,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
     const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+  const int64_t live = a.count ? (int64_t)*a.count : a.B;
+  if (b >= live) return;
   const int N = c.N;
   const LaneView<TILED> v(a.B, b);
   LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
@@ -477,9 +483,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
   T cost = w.rollout(Xc, Uc, xT);
+  const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
-  while (it < a.n_iters) {
+  while (it < a.n_iters && it0 + it < a.max_total) {
     w.backward(Xc, Uc, xT, ob, lamb, gK, gk);
     const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, xT);
     it++;
@@ -505,7 +512,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
       }
     }
   }
-  if (!t_isfinite(cost_ret)) status = 4;
+  // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
+  if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
+  if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
   if (Xc != X0) {  // the accepted trajectory sits in the workspace: copy it out
     for (int e = 0; e < n * (N + 1); e++)
       X0[(int64_t)e * v.Bs + v.bl] = Xc[(int64_t)e * v.Bs + v.bl];
@@ -513,8 +522,67 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   }
   a.lamb[b] = lamb;
   a.cost[b] = cost_ret;
-  if (a.iters) a.iters[b] = it;
+  if (a.iters) a.iters[b] = it0 + it;
   if (a.status) a.status[b] = status;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compaction step of the chunked solve.  Problems of the source set that have terminated are
+// scattered to the caller's arrays at their original index (unless the source IS the caller's
+// arrays); the survivors are packed densely into the destination work set, so the next chunk's
+// wavefronts are full again.  Order inside the destination is arbitrary (atomic slot counter,
+// wave-aggregated by the compiler): every problem is independent, results do not depend on it.
+// ---------------------------------------------------------------------------------------------
+template <class T> struct LaneSet {   // one set of per-problem arrays, batch-minor, row stride B
+  T* X; T* U; T* x_term; T* obs; T* lamb; T* cost; T* K; T* k;
+  int32_t* iters; int32_t* status; int32_t* orig;
+  int64_t B;
+};
+
+template <class T, bool USER_TILED>
+__global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneSet<T> src,
+                                                      int src_is_user, const int32_t* count_in,
+                                                      LaneSet<T> dst, int32_t* count_out,
+                                                      LaneSet<T> usr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t live = count_in ? (int64_t)*count_in : src.B;
+  if (i >= live) return;
+  const int rx = n * (N + 1), ru = m * N, rK = m * n * N;
+  // address of (row, problem) in the caller's layout / in a batch-minor work set
+  auto uaddr = [&](int rows, int row, int64_t p) -> int64_t {
+    if (USER_TILED) return ((p >> 6) * rows + row) * 64 + (p & 63);
+    return (int64_t)row * usr.B + p;
+  };
+  auto saddr = [&](int rows, int row, int64_t p) -> int64_t {
+    if (src_is_user) return uaddr(rows, row, p);
+    return (int64_t)row * src.B + p;
+  };
+  const int st = src.status[i];
+  if (st != 0) {
+    if (src_is_user) return;  // already in place
+    const int64_t o = src.orig[i];
+    for (int r = 0; r < rx; r++) usr.X[uaddr(rx, r, o)] = src.X[(int64_t)r * src.B + i];
+    for (int r = 0; r < ru; r++) usr.U[uaddr(ru, r, o)] = src.U[(int64_t)r * src.B + i];
+    if (usr.K) {
+      for (int r = 0; r < rK; r++) usr.K[uaddr(rK, r, o)] = src.K[(int64_t)r * src.B + i];
+      for (int r = 0; r < ru; r++) usr.k[uaddr(ru, r, o)] = src.k[(int64_t)r * src.B + i];
+    }
+    usr.lamb[o] = src.lamb[i];
+    usr.cost[o] = src.cost[i];
+    if (usr.iters) usr.iters[o] = src.iters[i];
+    if (usr.status) usr.status[o] = st;
+    return;
+  }
+  if (!dst.X) return;  // final pass: nothing survives (every problem has a terminal status)
+  const int64_t j = atomicAdd(count_out, 1);
+  for (int r = 0; r < rx; r++) dst.X[(int64_t)r * dst.B + j] = src.X[saddr(rx, r, i)];
+  for (int r = 0; r < ru; r++) dst.U[(int64_t)r * dst.B + j] = src.U[saddr(ru, r, i)];
+  for (int r = 0; r < n; r++) dst.x_term[(int64_t)r * dst.B + j] = src.x_term[saddr(n, r, i)];
+  if (src.obs)
+    for (int r = 0; r < 6; r++) dst.obs[(int64_t)r * dst.B + j] = src.obs[saddr(6, r, i)];
+  dst.lamb[j] = src.lamb[i];
+  dst.iters[j] = src.iters[i];
+  dst.orig[j] = src_is_user ? (int32_t)i : src.orig[i];
 }
 
 template <class T, class Sys, bool HASQR, bool TILED>

@@ -617,21 +617,29 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       }
       wave_sync();
       STAMP_END(1);
-      // P2: H = L + T1[:, :n] F  ((n+m) x (n+m): Qxx | . ; Qux | Quu),  g = l + T1[:, n]
+      // P2: H = L + T1[:, :n] F  ((n+m) x (n+m): Qxx | . ; Qux | Quu),  g = l + T1[:, n].
+      // All LDS reads of the phase (H and g operands) are issued before the first store.
+      T g_extra[GP], g_t1n[GP];
+#pragma unroll
+      for (int r = 0; r < GP; r++) {
+        g_extra[r] = S[g_x[r] + t * g_xs[r]];
+        g_t1n[r] = S[g_t[r]];
+      }
+      T h_val[P2P];
 #pragma unroll
       for (int r = 0; r < P2P; r++) {
         const T extra = S[p2_x[r] + t * p2_xs[r]];
         T acc = T(0);
 #pragma unroll
         for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + i * W], acc);
-        const T l = p2_const[r] + (p2_xon[r] ? extra : T(0));
-        if (p2_on[r]) S[L.H + sl + r * LANES] = l + acc;
+        h_val[r] = (p2_const[r] + (p2_xon[r] ? extra : T(0))) + acc;
       }
 #pragma unroll
+      for (int r = 0; r < P2P; r++)
+        if (p2_on[r]) S[L.H + sl + r * LANES] = h_val[r];
+#pragma unroll
       for (int r = 0; r < GP; r++) {
-        const T extra = S[g_x[r] + t * g_xs[r]];
-        const T t1n = S[g_t[r]];
-        T l = g_xon[r] ? extra : T(0);
+        T l = g_xon[r] ? g_extra[r] : T(0);
         if constexpr (HASQR) {
           // l_x = 2Q dX[:, t]: control/ilqr_helper.py:29
           const int a = sl + r * LANES;
@@ -641,7 +649,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
               l += T(2) * c.Q[a * n + q] * (S[Xo + t * n + q] - c.xtarget[q]);
           }
         }
-        if (g_on[r]) S[L.g + sl + r * LANES] = l + t1n;
+        if (g_on[r]) S[L.g + sl + r * LANES] = l + g_t1n[r];
       }
       wave_sync();
       STAMP_END(2);
