@@ -191,13 +191,20 @@ template <class T, class Sys> struct Launch {
   }
 };
 
+constexpr int64_t kCompactMinBatch = 4096;  // solve() switches to the chunked form from here
+
 // Batch-minor layout: one problem per lane (i2lqr_lane.hpp); m == 2 systems.
 template <class T, class Sys, bool TILED> struct LaneLaunch {
   static constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
   using Cfg = DevCfg<T, n, m>;
   static unsigned grid(int64_t B) { return (unsigned)((B + 63) / 64); }
+  // Workspace (bytes) for B problems: candidate trajectory + gains scratch (every call), and for
+  // the chunked solve two compacted work sets, scratch iters/status and the two slot counters.
+  static int64_t set_words(int N) { return (int64_t)(n * (N + 1) + m * N + n + 6 + 2); }
   static int64_t ws_bytes(int N, int64_t B) {
-    return lane_workspace_words<Sys>(N, B) * (int64_t)sizeof(T);
+    const int64_t Bp = TILED ? (B + 63) / 64 * 64 : B;
+    const int64_t words = lane_workspace_words<Sys>(N, Bp) + 2 * set_words(N) * Bp;
+    return words * (int64_t)sizeof(T) + (2 * 3 + 2) * Bp * 4 + 64;
   }
   static int prepare(i2lqr_handle* h) {
     h->lanes = 1;
@@ -215,29 +222,134 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
                   (long long)B, (long long)need);
     return I2LQR_OK;
   }
-  static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a) {
+  struct Carved {
+    LaneSet<T> set[2];
+    int32_t* uiters;
+    int32_t* ustatus;
+    int32_t* count;  // [2]
+  };
+  static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a, Carved* cv = nullptr) {
     const int N = h->cfg.N;
     T* p = (T*)h->ws;
     a.wsX = p; p += B * (int64_t)(n * (N + 1));
     a.wsU = p; p += B * (int64_t)(m * N);
     a.wsK = p; p += B * (int64_t)(m * n * N);
-    a.wsk = p;
+    a.wsk = p; p += B * (int64_t)(m * N);
+    a.count = nullptr;
+    a.resume = 0;
+    a.max_total = 0x7fffffff;
+    if (!cv) return;
+    for (int q = 0; q < 2; q++) {
+      LaneSet<T>& st = cv->set[q];
+      st.B = B;
+      st.X = p; p += B * (int64_t)(n * (N + 1));
+      st.U = p; p += B * (int64_t)(m * N);
+      st.x_term = p; p += B * n;
+      st.obs = p; p += B * 6;
+      st.lamb = p; p += B;
+      st.cost = p; p += B;
+      st.K = a.wsK;
+      st.k = a.wsk;
+    }
+    int32_t* ip = (int32_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    for (int q = 0; q < 2; q++) {
+      cv->set[q].iters = ip; ip += B;
+      cv->set[q].status = ip; ip += B;
+      cv->set[q].orig = ip; ip += B;
+    }
+    cv->uiters = ip; ip += B;
+    cv->ustatus = ip; ip += B;
+    cv->count = ip;
   }
+  template <bool TL>
+  static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
+    if (c.flags)
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+    else
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+  }
+
+  // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per
+  // problem, so a wavefront of 64 problems would otherwise idle on its slowest lane.  The batch
+  // is solved in chunks of 2, 2, 4, 8, ... iterations; after every chunk the terminated problems
+  // are scattered to the caller's arrays and the survivors are packed into a dense work set
+  // (k_lane_compact).  No host synchronisation: the live count stays in device memory and
+  // surplus wavefronts exit at once.  Results are bit-identical to the plain launch.
+  static int solve_compacting(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term,
+                              void* lamb, const void* obs, void* cost, void* K, void* k,
+                              int32_t* iters, int32_t* status, hipStream_t s) {
+    if (int rc = need_ws(h, B)) return rc;
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    const int N = h->cfg.N, max_iter = h->cfg.max_iter;
+    LaneArgs<T> a0;
+    Carved cv;
+    carve(h, B, a0, &cv);
+    LaneSet<T> usr;
+    usr.B = B;
+    usr.X = (T*)X; usr.U = (T*)U; usr.x_term = (T*)x_term; usr.obs = (T*)obs;
+    usr.lamb = (T*)lamb; usr.cost = (T*)cost; usr.K = (T*)K; usr.k = (T*)k;
+    usr.iters = iters ? iters : cv.uiters;
+    usr.status = status ? status : cv.ustatus;
+    usr.orig = nullptr;
+    if (!obs) { cv.set[0].obs = nullptr; cv.set[1].obs = nullptr; }
+    // chunk 0 runs in place on the caller's arrays
+    int done = 0, len = 2;
+    a0.B = B; a0.n_iters = len; a0.early_exit = 1;
+    a0.X = usr.X; a0.U = usr.U; a0.x_term = usr.x_term; a0.lamb = usr.lamb; a0.obs = usr.obs;
+    a0.cost = usr.cost; a0.K = usr.K; a0.k = usr.k; a0.iters = usr.iters; a0.status = usr.status;
+    a0.max_total = max_iter;
+    launch_iterate<TILED>(c, a0, B, s);
+    done += len;
+    const unsigned cgrid = (unsigned)((B + 255) / 256);
+    int cur = 0;  // work set that receives the survivors
+    bool src_user = true;
+    const int32_t* count_in = nullptr;
+    LaneSet<T> src = usr;
+    while (done < max_iter) {
+      HIP_TRY(hipMemsetAsync(cv.count + cur, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
+                         src_user ? 1 : 0, count_in, cv.set[cur], cv.count + cur, usr);
+      len = (done < 4) ? 2 : done;  // 2, 2, 4, 8, 16, ...
+      if (done + len > max_iter) len = max_iter - done;
+      LaneArgs<T> a = a0;
+      const LaneSet<T>& w = cv.set[cur];
+      a.X = w.X; a.U = w.U; a.x_term = w.x_term; a.lamb = w.lamb; a.obs = w.obs; a.cost = w.cost;
+      a.K = nullptr; a.k = nullptr;  // gains of work sets go to the scratch buffer (w.K == wsK)
+      a.iters = w.iters; a.status = w.status;
+      a.count = cv.count + cur; a.resume = 1; a.n_iters = len;
+      launch_iterate<false>(c, a, B, s);
+      done += len;
+      src = w;
+      src_user = false;
+      count_in = cv.count + cur;
+      cur ^= 1;
+    }
+    // every remaining problem has a terminal status now: scatter them all
+    if (!src_user) {
+      LaneSet<T> none;
+      std::memset(&none, 0, sizeof(none));
+      hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src, 0,
+                         count_in, none, cv.count + cur, usr);
+    }
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+
   static int iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
                      const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
                      int32_t* iters, int32_t* status, hipStream_t s) {
+    if (early_exit && B >= kCompactMinBatch && n_iters > 4 && n_iters == h->cfg.max_iter)
+      return solve_compacting(h, B, X, U, x_term, lamb, obs, cost, K, k, iters, status, s);
     if (int rc = need_ws(h, B)) return rc;
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
     LaneArgs<T> a;
+    carve(h, B, a);
     a.B = B; a.n_iters = n_iters; a.early_exit = early_exit;
     a.X = (T*)X; a.U = (T*)U; a.x_term = (const T*)x_term; a.lamb = (T*)lamb;
     a.obs = (const T*)obs; a.cost = (T*)cost; a.K = (T*)K; a.k = (T*)k;
     a.iters = iters; a.status = status;
-    carve(h, B, a);
-    if (c.flags)
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, a);
-    else
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, a);
+    a.max_total = n_iters;
+    launch_iterate<TILED>(c, a, B, s);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -531,12 +643,20 @@ int i2lqr_destroy(i2lqr_handle* h) {
 
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
   if (!h || B < 0 || h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) return 0;
-  if (h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED) B = (B + 63) / 64 * 64;
-  const int64_t sz = h->cfg.dtype == I2LQR_F64 ? 8 : 4;
+  const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
   const int N = h->cfg.N;
+  const bool f64 = h->cfg.dtype == I2LQR_F64;
   switch (h->cfg.system_id) {
-    case I2LQR_SYS_BICYCLE4: return lane_workspace_words<Bicycle4<double>>(N, B) * sz;
-    case I2LQR_SYS_BICYCLE6: return lane_workspace_words<Bicycle6<double>>(N, B) * sz;
+    case I2LQR_SYS_BICYCLE4:
+      if (f64) return tiled ? LaneLaunch<double, Bicycle4<double>, true>::ws_bytes(N, B)
+                            : LaneLaunch<double, Bicycle4<double>, false>::ws_bytes(N, B);
+      return tiled ? LaneLaunch<float, Bicycle4<float>, true>::ws_bytes(N, B)
+                   : LaneLaunch<float, Bicycle4<float>, false>::ws_bytes(N, B);
+    case I2LQR_SYS_BICYCLE6:
+      if (f64) return tiled ? LaneLaunch<double, Bicycle6<double>, true>::ws_bytes(N, B)
+                            : LaneLaunch<double, Bicycle6<double>, false>::ws_bytes(N, B);
+      return tiled ? LaneLaunch<float, Bicycle6<float>, true>::ws_bytes(N, B)
+                   : LaneLaunch<float, Bicycle6<float>, false>::ws_bytes(N, B);
     default: return 0;
   }
 }
