@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -77,6 +78,7 @@ struct i2lqr_handle {
   int device;
   void* ws;         // caller-owned scratch of the batch-minor kernels
   int64_t ws_bytes;
+  int64_t compact_min_batch;  // > 0: i2lqr_solve uses the chunked, compacting form from this batch
 };
 
 namespace {
@@ -190,8 +192,6 @@ template <class T, class Sys> struct Launch {
     return I2LQR_OK;
   }
 };
-
-constexpr int64_t kCompactMinBatch = 4096;  // solve() switches to the chunked form from here
 
 // Batch-minor layout: one problem per lane (i2lqr_lane.hpp); m == 2 systems.
 template <class T, class Sys, bool TILED> struct LaneLaunch {
@@ -338,7 +338,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static int iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
                      const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
                      int32_t* iters, int32_t* status, hipStream_t s) {
-    if (early_exit && B >= kCompactMinBatch && n_iters > 4 && n_iters == h->cfg.max_iter)
+    if (early_exit && h->compact_min_batch > 0 && B >= h->compact_min_batch && n_iters > 4 &&
+        n_iters == h->cfg.max_iter)
       return solve_compacting(h, B, X, U, x_term, lamb, obs, cost, K, k, iters, status, s);
     if (int rc = need_ws(h, B)) return rc;
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
@@ -625,6 +626,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->cfg = *cfg;
   h->ws = nullptr;
   h->ws_bytes = 0;
+  h->compact_min_batch = 0;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
   if (rc != I2LQR_OK) {
@@ -659,6 +661,14 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
                    : LaneLaunch<float, Bicycle6<float>, false>::ws_bytes(N, B);
     default: return 0;
   }
+}
+
+int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR && min_batch > 0)
+    return fail(I2LQR_ERR_UNSUPPORTED, "compaction applies to the batch-minor / batch-tiled layouts");
+  h->compact_min_batch = min_batch;
+  return I2LQR_OK;
 }
 
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes) {

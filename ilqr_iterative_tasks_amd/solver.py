@@ -126,6 +126,11 @@ class BatchedILQR:
             self._check(self.lib.i2lqr_set_workspace(self._handle, C.c_void_p(self._ws.data_ptr()),
                                                      self._ws.numel()))
 
+    def set_compaction(self, min_batch: int) -> None:
+        """Opt into the chunked, compacting form of solve() from `min_batch` problems (lane
+        layouts; off by default — see include/i2lqr.h)."""
+        self._check(self.lib.i2lqr_set_compaction(self._handle, int(min_batch)))
+
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,
                            device=self.device)

@@ -133,6 +133,16 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B);
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
+ * Opt-in chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
+ * problems the solve runs in chunks of 2, 2, 4, 8, ... iterations and packs the still-running
+ * problems into dense work sets between chunks (no host synchronisation; results bit-identical
+ * to the single launch).  min_batch <= 0 (default) disables it.  Measured on MI355X at n=6, N=20:
+ * no gain up to 2^20 problems — the single launch is HBM-bound and its cost already scales with
+ * the lanes that are still running — so it stays off by default.
+ */
+int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
+
+/*
  * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.
  * In: X[.,:,0] = x0, U.  Out: U clipped in place, X[.,:,1..N], cost[B] (stage cost to xtarget +
  * terminal cost to x_term; barrier terms are NOT part of the cost, as in the reference).

@@ -317,14 +317,15 @@ def test_tiled_layout_is_bit_identical_to_batch_minor(torch_mod, dtype):
 @pytest.mark.parametrize("lay,dtype,gains", [("lane", "f64", True), ("lane", "f32", False),
                                              ("tiled", "f64", False), ("tiled", "f32", True)])
 def test_chunked_compacting_solve_is_bit_identical_to_plain(torch_mod, lay, dtype, gains):
-    """From 4096 problems i2lqr_solve runs in chunks of 2, 2, 4, 8, ... iterations and packs the
-    surviving problems between chunks (k_lane_compact).  Every output must equal, bit for bit,
-    the plain single-launch solve (taken here on sub-batches of 2048, below the threshold), and
-    the iteration counts must match the oracle's."""
+    """Opt-in chunked solve (i2lqr_set_compaction): chunks of 2, 2, 4, 8, ... iterations with the
+    surviving problems packed between chunks (k_lane_compact).  Every output must equal, bit for
+    bit, the plain single-launch solve (taken here on sub-batches of 2048, below the threshold),
+    and the iteration counts must match the oracle's."""
     torch = torch_mod
     from ilqr_iterative_tasks_amd import workloads
     solver, cfg = make_solver("bicycle6", 20, dtype, dt=0.25, layout=lay)
     B, sub = 8192, 2048
+    solver.set_compaction(4096)
     host = workloads.make_batch(cfg, B)
     host["lamb"] = 10.0 ** np.random.default_rng(1).integers(-3, 3, B).astype(float)
     big = solver.solve(dev_batch(solver, host, want_gains=gains))

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Solve-to-termination timing (reference exits, 1..150 iterations per problem)."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+
+for spec in sys.argv[1:]:
+    layout, dtype, B = spec.split(":")
+    B = int(B)
+    cfg = workloads.config_for("config2", dtype)
+    cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[layout]
+    solver = BatchedILQR(cfg)
+    host = workloads.make_batch(cfg, B)
+    dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
+    buf = solver.alloc(B, want_gains=False)
+    init = {}
+    for key in ("X", "U", "x_term", "lamb"):
+        buf[key].copy_(dev(host[key]))
+    buf["obs"] = dev(host["obs"])
+    init = {k: buf[k].clone() for k in ("X", "U", "lamb")}
+    ts = []
+    for r in range(4):
+        for k in init:
+            buf[k].copy_(init[k])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        solver.solve(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    it = buf["iters"].double()
+    ms = min(ts[1:])
+    print(f"{spec:22s} {ms:9.3f} ms  iterations mean {float(it.mean()):5.2f} max {int(it.max()):3d}  "
+          f"-> {float(it.sum()) / ms / 1e3:8.1f} M executed it/s, {B / ms / 1e3:7.2f} M problems/s")
+    solver.close()
