@@ -618,6 +618,20 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
     return fail(I2LQR_ERR_INVALID, "need dt > 0, lamb_factor > 1, max_iter >= 0");
   for (int a = 0; a < m; a++)
     if (!(cfg->u_max[a] > 0)) return fail(I2LQR_ERR_INVALID, "u_max[%d] must be > 0", a);
+  if (cfg->layout != I2LQR_LAYOUT_PROBLEM_MAJOR) {
+    // the one-problem-per-lane kernels store only the upper triangles of the value function
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < i; j++)
+        if (cfg->Q[i * I2LQR_MAX_N + j] != cfg->Q[j * I2LQR_MAX_N + i] ||
+            cfg->Qt[i * I2LQR_MAX_N + j] != cfg->Qt[j * I2LQR_MAX_N + i])
+          return fail(I2LQR_ERR_UNSUPPORTED, "the batch-minor / batch-tiled layouts need "
+                      "symmetric Q and Qterminal (use the problem-major layout otherwise)");
+    for (int a = 0; a < m; a++)
+      for (int b = 0; b < a; b++)
+        if (cfg->R[a * I2LQR_MAX_M + b] != cfg->R[b * I2LQR_MAX_M + a])
+          return fail(I2LQR_ERR_UNSUPPORTED, "the batch-minor / batch-tiled layouts need a "
+                      "symmetric R (use the problem-major layout otherwise)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(I2LQR_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");

@@ -219,9 +219,16 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
   // Reads the nominal (X, U), writes the gains to gK[m][n][N][B], gk[m][N][B].
+  // SYM: V_xx, Q_xx and Q_uu are symmetric in exact arithmetic (the reference never re-symmetrises
+  // them, so its copies differ by round-off, ~1e-16 relative).  The lane kernels keep only the
+  // upper triangles: a quarter fewer multiply-adds and ~30 fewer live doubles per lane, which is
+  // what lets the unrolled step stay in registers.  Cost weights must be symmetric (checked in
+  // i2lqr_create for these layouts).  The one-problem-per-wavefront kernels keep the full blocks.
+  static constexpr bool SYM = true;
+
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk) const {
-    T Va[n][n + 1];  // [Vxx | Vx]
+    T Va[n][n + 1];  // [Vxx | Vx]; with SYM only Va[i][j >= i] and the last column are live
     {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
@@ -304,13 +311,16 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
           bool first = true;
           static_for<0, n>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            f_acc<i, a>(acc, first, Va[i][j], jv);
+            const T vij = (!SYM || j == n || i <= j) ? Va[i][j] : Va[j][i];
+            f_acc<i, a>(acc, first, vij, jv);
           });
           t1[j] = acc;
         }
         static_for<0, W>([&](auto b_) {
           constexpr int bcol = decltype(b_)::value;
-          if constexpr (!(a < n && bcol >= n)) {  // Qxu is never used by the reference
+          // Qxu is never used by the reference; with SYM neither are the lower triangles
+          if constexpr (!(a < n && bcol >= n) && !(SYM && a < n && bcol < a) &&
+                        !(SYM && a >= n && bcol >= n && bcol < a)) {
             T acc = T(0);
             bool first = true;
             static_for<0, n>([&](auto i_) {
@@ -342,6 +352,12 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 
       // gains [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
       T Qinv[m * m], Kk[m][n + 1];
+      if constexpr (SYM) {
+#pragma unroll
+        for (int a = 1; a < m; a++)
+#pragma unroll
+          for (int bb = 0; bb < a; bb++) Quu[a * m + bb] = Quu[bb * m + a];
+      }
       quu_inverse(Quu, lamb, Qinv);
 #pragma unroll
       for (int a = 0; a < m; a++)
@@ -370,7 +386,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
           ktq[bb] = acc;
         }
 #pragma unroll
-        for (int j = 0; j <= n; j++) {
+        for (int j = (SYM ? i : 0); j <= n; j++) {
           T acc = T(0);
 #pragma unroll
           for (int bb = 0; bb < m; bb++) acc = t_fma(ktq[bb], Kk[bb][j], acc);
