@@ -53,7 +53,6 @@ def parse_args():
 LANE_THRESHOLD = 4096  # per-GPU batch from which the one-problem-per-lane kernels win
 
 
-TILED_THRESHOLD_F64 = 131072  # from here the tiled rows beat the batch-wide rows (fp64)
 LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
 
 
@@ -62,11 +61,9 @@ def pick_layout(args, B, dtype="f64"):
     batch-minor rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
     if args.layout != "auto":
         return args.layout
-    if B < LANE_THRESHOLD or B % 64:
-        return "wave" if B < LANE_THRESHOLD else "lane"
-    if dtype == "f32" or B >= TILED_THRESHOLD_F64:
-        return "tiled"
-    return "lane"
+    if B < LANE_THRESHOLD:
+        return "wave"
+    return "lane" if B % 64 else "tiled"
 
 
 def make_step_buffers(solver, host, n_sets, torch):

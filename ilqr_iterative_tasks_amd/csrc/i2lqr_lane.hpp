@@ -161,6 +161,26 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     return cost;
   }
 
+  // Re-roll the nominal states X[:, 1..N] from the (already clipped) nominal inputs: restores the
+  // trajectory after a rejected step, whose candidate was written over it in place.  Bit-identical
+  // to what rollout() / an accepted forward() stored (same code, same inputs).
+  __device__ __forceinline__ void restore_states(T* X, const T* U) const {
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = X[ix(i, 0)];
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+      Sys::trig(x, tr);
+      Sys::step_tr(c, x, u, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        X[ix(i, t + 1)] = xn[i];
+        x[i] = xn[i];
+      }
+    }
+  }
+
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
   __device__ __forceinline__ void obstacle(const T (&ob)[6], T px, T py, int t, T (&o)[5]) const {
 #pragma unroll
@@ -490,11 +510,23 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   T lamb = a.lamb[b];
   T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
   T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
-  // per-lane trajectory buffers: "cur" holds the nominal, "nxt" receives the candidate
+  // Two buffer schemes, chosen per precision from interleaved same-device measurements
+  // (tools/ab_bench.py):
+  //  fp64 — states in ONE buffer (the caller's X): the forward pass writes the candidate states
+  //    over the nominal ones in place (each x_t is loaded one step ahead of being overwritten) and
+  //    a rejected step re-rolls the nominal states from the nominal inputs (bit-identical); only
+  //    the inputs (m N words) are double-buffered per lane.  With X double-buffered per lane,
+  //    divergent accept/reject decisions split every 512-byte row access of a wavefront over two
+  //    buffers: +38 % HBM traffic per iteration (rocprofv3 FETCH_SIZE / WRITE_SIZE,
+  //    tools/pmc_iters.sh); in place: +16 % iterations/s at 65536 problems, +6 % at 2^20.
+  //  fp32 — X and U both double-buffered with per-lane "which buffer" pointers: the rows are half
+  //    as wide, the kernel is less bandwidth-bound and the re-roll costs more than it saves
+  //    (in place was 10-12 % slower).
+  constexpr bool INPLACE = sizeof(T) == 8;
   T* const X0 = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Xc = X0, *Uc = U0;
-  T *Xn = v.rebase(a.wsX, n * (N + 1)), *Un = v.rebase(a.wsU, m * N);
+  T *Xn = INPLACE ? X0 : v.rebase(a.wsX, n * (N + 1)), *Un = v.rebase(a.wsU, m * N);
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
@@ -507,9 +539,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
     const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, xT);
     it++;
     if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
-      T* tp;
-      tp = Xc; Xc = Xn; Xn = tp;
-      tp = Uc; Uc = Un; Un = tp;
+      T* tp = Uc; Uc = Un; Un = tp;
+      if constexpr (!INPLACE) { tp = Xc; Xc = Xn; Xn = tp; }
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
@@ -520,6 +551,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
         if (status == 0) status = 1;
       }
     } else {  // control/iterative_ilqr.py:81-84
+      if constexpr (INPLACE) w.restore_states(Xc, Uc);
       lamb *= c.lamb_factor;
       cost_ret = cost;
       if (lamb > c.max_lamb) {
@@ -531,9 +563,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
   if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
   if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
-  if (Xc != X0) {  // the accepted trajectory sits in the workspace: copy it out
+  if (Xc != X0) {  // the accepted states sit in the workspace: copy them out
     for (int e = 0; e < n * (N + 1); e++)
       X0[(int64_t)e * v.Bs + v.bl] = Xc[(int64_t)e * v.Bs + v.bl];
+  }
+  if (Uc != U0) {  // likewise the inputs
     for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
   }
   a.lamb[b] = lamb;

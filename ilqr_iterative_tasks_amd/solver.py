@@ -30,9 +30,9 @@ class I2lqrError(RuntimeError):
 
 
 class BatchedILQR:
-    def __init__(self, cfg: I2lqrConfig, device: str | torch.device = "cuda:0"):
+    def __init__(self, cfg: I2lqrConfig, device: str | torch.device = "cuda:0", lib_path=None):
         self._handle = None  # set first so __del__ is safe if loading fails
-        self.lib = _abi.load_library()
+        self.lib = _abi.load_library(lib_path)  # lib_path: A/B builds in tools/ only
         if not torch.cuda.is_available():
             raise I2lqrError("no HIP device visible: BatchedILQR has no CPU fallback")
         self.device = torch.device(device)

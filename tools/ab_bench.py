@@ -21,11 +21,13 @@ args = ap.parse_args()
 LAY = {"wave": 0, "lane": 1, "tiled": 2}
 runs = []
 for v in args.variants.split(","):
-    layout, dtype, B = v.split(":")
+    parts = v.split(":")
+    layout, dtype, B = parts[:3]
+    lib_path = parts[3] if len(parts) > 3 else None  # e.g. tools/_diag/libold.so
     B = int(B)
     cfg = workloads.config_for(args.workload, dtype)
     cfg.layout = LAY[layout]
-    solver = BatchedILQR(cfg)
+    solver = BatchedILQR(cfg, lib_path=lib_path)
     host = workloads.make_batch(cfg, B)
     dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
     buf = solver.alloc(B)

@@ -18,8 +18,8 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   run calib $ctr $ROOT/tools/pmc_calib.py
   run wave_f64_B1024 $ctr $ROOT/tools/pmc_target.py --layout wave --batch 1024 --dtype f64
   run lane_f64_B65536 $ctr $ROOT/tools/pmc_target.py --layout lane --batch 65536 --dtype f64
-  run lane_f32_B65536 $ctr $ROOT/tools/pmc_target.py --layout lane --batch 65536 --dtype f32
-  run lane_f64_B1048576 $ctr $ROOT/tools/pmc_target.py --layout lane --batch 1048576 --dtype f64 --launches 2
+  run tiled_f32_B65536 $ctr $ROOT/tools/pmc_target.py --layout tiled --batch 65536 --dtype f32
+  run tiled_f64_B1048576 $ctr $ROOT/tools/pmc_target.py --layout tiled --batch 1048576 --dtype f64 --launches 2
 done
 python3 $ROOT/tools/summarise_pmc.py "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"

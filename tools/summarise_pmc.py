@@ -35,8 +35,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             known = (1 << 28) * elem
             calib[(ctr, elem)] = known / (avg(v) * 1024.0)
 summary["calibration_known_over_reported"] = {f"{k[0]}_{k[1]}B_per_lane": v for k, v in calib.items()}
-for name, elem in (("wave_f64_B1024", 8), ("lane_f64_B65536", 8), ("lane_f32_B65536", 4),
-                   ("lane_f64_B1048576", 8)):
+for name, elem in (("wave_f64_B1024", 8), ("lane_f64_B65536", 8), ("tiled_f32_B65536", 4),
+                   ("tiled_f64_B1048576", 8)):
     rec = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         res = per_kernel(f"{out}/{name}_{ctr}/**/*counter_collection.csv")
