@@ -238,6 +238,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.count = nullptr;
     a.resume = 0;
     a.max_total = 0x7fffffff;
+    // fp64: the gains of the first steps stay in LDS — as many steps as keep the register-limited
+    // four wavefronts per CU resident in the 160 KiB (36 KiB each: 5 steps at n=6, m=2).  fp32 is
+    // not on the HBM roof at these sizes and measured 7 % slower with it at 65536 problems: off.
+    const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
+    a.lds_steps = sizeof(T) == 8 ? (36 * 1024) / per_step : 0;
+    if (a.lds_steps > N) a.lds_steps = N;
+    a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
     if (!cv) return;
     for (int q = 0; q < 2; q++) {
       LaneSet<T>& st = cv->set[q];
@@ -263,10 +270,12 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   }
   template <bool TL>
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
+    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T);
     if (c.flags)
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
     else
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), lds, s, c,
+                         a);
   }
 
   // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per

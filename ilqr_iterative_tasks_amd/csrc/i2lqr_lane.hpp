@@ -45,6 +45,8 @@ template <class T> struct LaneArgs {
   // chunk ends gets status RUNNING unless it has reached max_total iterations
   const int32_t* count;
   int resume, max_total;
+  int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
+  int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
 };
 
 // words of T the workspace needs for B problems
@@ -74,8 +76,29 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   const Cfg& c;
   const int N;
   const int64_t B, b;  // batch size, this lane's problem
+  // Gains of the first `lds_steps` horizon steps stay in LDS: the backward pass produces them
+  // last and the forward pass consumes them first, so they never need to travel through HBM
+  // (flushed once at kernel exit for the caller).  Word (t, q) of lane l sits at
+  // lds[(t * m (n+1) + q) * 64 + l]: consecutive lanes on consecutive words, conflict-free.
+  T* lds = nullptr;
+  int lds_steps = 0;
 
   __device__ LaneWorker(const Cfg& c_, int64_t B_, int64_t b_) : c(c_), N(c_.N), B(B_), b(b_) {}
+  __device__ __forceinline__ T& lds_gain(int t, int q) const {
+    return lds[(t * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
+  }
+  // write the LDS-resident gains of this lane to HBM (kernel exit)
+  __device__ __forceinline__ void flush_gains(T* gK, T* gk) const {
+    for (int t = 0; t < lds_steps && t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+#pragma unroll
+        for (int j = 0; j < n; j++)
+          gK[(((int64_t)a * n + j) * N + t) * B + b] = lds_gain(t, a * (n + 1) + j);
+        gk[iu(a, t)] = lds_gain(t, a * (n + 1) + n);
+      }
+    }
+  }
 
   // batch-minor addressing
   __device__ __forceinline__ int64_t ix(int comp, int t) const {  // X-like [comp][N+1][B]
@@ -388,11 +411,18 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
           for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], G[bb][j], acc);
           Kk[a][j] = -acc;
         }
+      if (t < lds_steps) {
 #pragma unroll
-      for (int a = 0; a < m; a++) {
+        for (int a = 0; a < m; a++)
 #pragma unroll
-        for (int j = 0; j < n; j++) gK[(((int64_t)a * n + j) * N + t) * B + b] = Kk[a][j];
-        gk[iu(a, t)] = Kk[a][n];
+          for (int j = 0; j <= n; j++) lds_gain(t, a * (n + 1) + j) = Kk[a][j];
+      } else {
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+#pragma unroll
+          for (int j = 0; j < n; j++) gK[(((int64_t)a * n + j) * N + t) * B + b] = Kk[a][j];
+          gk[iu(a, t)] = Kk[a][n];
+        }
       }
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
 #pragma unroll
@@ -417,40 +447,62 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   }
 
   // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
-  // (Re-rolling the nominal states instead of reading X back was tried: it saves n words per step
-  // but the second dynamics step raises register pressure and was slower at every batch size.)
+  // REROLL: the nominal states x_t that the feedback law needs are re-rolled from the nominal
+  // inputs next to the candidate (bit-identical to the stored X: same code, same inputs) instead
+  // of being read back — n (N+1) words less HBM traffic per iteration for one more dynamics step
+  // per horizon step.  Pays where the kernel sits on the HBM roof (fp64).
+  template <bool REROLL>
   __device__ __forceinline__ T forward(const T* X, const T* U, const T* gK, const T* gk, T* Xn,
                                        T* Un, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
+    T xo[n], uo[m], kk[m][n + 1];
 #pragma unroll
     for (int i = 0; i < n; i++) {
       x[i] = X[ix(i, 0)];
-      Xn[ix(i, 0)] = x[i];
+      xo[i] = x[i];
+      if (Xn != X) Xn[ix(i, 0)] = x[i];
     }
     T cost = T(0);
     // The nominal state / input / gains of a step are consumed at its very start (the feedback
     // law); the loads for step t+1 are issued right after, into the same registers, so the HBM
     // latency hides under the rest of the serial step.
-    T xo[n], uo[m], kk[m][n + 1];
     auto load_step = [&](int t) {
+      if constexpr (!REROLL) {
 #pragma unroll
-      for (int j = 0; j < n; j++) xo[j] = X[ix(j, t)];
+        for (int j = 0; j < n; j++) xo[j] = X[ix(j, t)];
+      }
 #pragma unroll
-      for (int a = 0; a < m; a++) {
-        uo[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) uo[a] = U[iu(a, t)];
+      if (t < lds_steps) {
 #pragma unroll
-        for (int j = 0; j < n; j++) kk[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
-        kk[a][n] = gk[iu(a, t)];
+        for (int a = 0; a < m; a++)
+#pragma unroll
+          for (int j = 0; j <= n; j++) kk[a][j] = lds_gain(t, a * (n + 1) + j);
+      } else {
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+#pragma unroll
+          for (int j = 0; j < n; j++) kk[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
+          kk[a][n] = gk[iu(a, t)];
+        }
       }
     };
     load_step(0);
     for (int t = 0; t < N; t++) {
+      T uon[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
         for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
         u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        uon[a] = uo[a];
+      }
+      if constexpr (REROLL) {  // nominal state of step t+1, before its registers are reloaded
+        Sys::trig(xo, tr);
+        Sys::step_tr(c, xo, uon, tr, xn);
+#pragma unroll
+        for (int i = 0; i < n; i++) xo[i] = xn[i];
       }
       if (t + 1 < N) load_step(t + 1);
 #pragma unroll
@@ -500,6 +552,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   const int N = c.N;
   const LaneView<TILED> v(a.B, b);
   LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  extern __shared__ __align__(16) unsigned char lane_smem[];
+  w.lds = reinterpret_cast<T*>(lane_smem);
+  w.lds_steps = a.lds_steps;
   const T* gxt = v.rebase(a.x_term, n);
   const T* gob = v.rebase(a.obs, 6);
   T xT[n], ob[6];
@@ -536,7 +591,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   T cost_ret = cost;
   while (it < a.n_iters && it0 + it < a.max_total) {
     w.backward(Xc, Uc, xT, ob, lamb, gK, gk);
-    const T cost_new = w.forward(Xc, Uc, gK, gk, Xn, Un, xT);
+    const T cost_new = (INPLACE && a.reroll)
+                           ? w.template forward<true>(Xc, Uc, gK, gk, Xn, Un, xT)
+                           : w.template forward<false>(Xc, Uc, gK, gk, Xn, Un, xT);
     it++;
     if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
       T* tp = Uc; Uc = Un; Un = tp;
@@ -563,6 +620,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
   if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
   if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
+  w.flush_gains(gK, gk);
   if (Xc != X0) {  // the accepted states sit in the workspace: copy them out
     for (int e = 0; e < n * (N + 1); e++)
       X0[(int64_t)e * v.Bs + v.bl] = Xc[(int64_t)e * v.Bs + v.bl];
@@ -686,7 +744,7 @@ __global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys
   T xT[n];
 #pragma unroll
   for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
-  cost_new[b] = w.forward(v.rebase(X, n * (N + 1)), v.rebase(U, m * N), v.rebase(K, m * n * N),
+  cost_new[b] = w.template forward<false>(v.rebase(X, n * (N + 1)), v.rebase(U, m * N), v.rebase(K, m * n * N),
                           v.rebase(k, m * N), v.rebase(Xn, n * (N + 1)), v.rebase(Un, m * N), xT);
 }
 
