@@ -185,6 +185,16 @@ def run_solve(args, cfg, B, torch, reps=3):
             "kernel": "k_iterate" if layout == "wave" else "k_lane_iterate"}
 
 
+def load_traffic(key):
+    """HBM bytes per launch from the committed PMC summary (tools/collect_pmc.sh), or None."""
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        rec = json.loads(tf.read_text()).get(key)
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, B, iters, budget_s):
     """The CPU oracle (a port of the reference algorithm, oracle/ilqr_oracle.c, OpenMP over the
     batch) on the host cores of this box: same synthetic workload, same fixed iteration count,
@@ -251,14 +261,7 @@ def main():
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
 
-    traffic = None
-    tf = ROOT / "profiles" / "pmc_traffic.json"
-    if tf.exists():
-        try:
-            rec = json.loads(tf.read_text()).get(f"{args.workload}:{dtype}:B{B}:it{args.iters}")
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
-        except Exception:
-            traffic = None
+    traffic = load_traffic(f"{args.workload}:{dtype}:B{B}:it{args.iters}")
 
     out = {
         "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"
@@ -299,8 +302,10 @@ def main():
             eb_bytes = workloads.algorithmic_bytes_per_iteration(ecfg)
             ach = eb_bytes * eb * args.iters / (r["kernel_ms"] * 1e-3) / 1e9
             extra[name] = {"iterations_per_s": r["iterations"] / r["seconds"],
-                           "kernel": r["kernel"], "kernel_ms": r["kernel_ms"],
-                           "achieved_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS}
+                           "kernel": r["kernel"], "layout": r["layout"],
+                           "kernel_ms": r["kernel_ms"], "achieved_GBs": ach,
+                           "hbm_frac": ach / HBM_PEAK_GBS,
+                           "traffic": load_traffic(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
         # problem is done, so this is below the fixed-count rate

@@ -359,6 +359,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.obs = (const T*)obs; a.cost = (T*)cost; a.K = (T*)K; a.k = (T*)k;
     a.iters = iters; a.status = status;
     a.max_total = n_iters;
+    if (early_exit) a.reroll = 0;  // solve() is bound by its slowest problem's latency, not HBM
     launch_iterate<TILED>(c, a, B, s);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
