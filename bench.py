@@ -277,7 +277,7 @@ def main():
         "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}] ({args.workload}): "
+        "config": {"workload": f"BASELINE.json configs[{int(args.workload[-1]) - 1}] ({args.workload}): "
                                f"{wl['system']} n={cfg.n} m={cfg.m} N={cfg.N} dt={cfg.dt}",
                    "batch_per_gpu": B, "global_batch": B * world, "layout": res["layout"],
                    "iterations_per_step": args.iters,

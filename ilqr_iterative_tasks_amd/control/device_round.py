@@ -15,10 +15,16 @@ from .params import config_from_params, obstacle_record
 
 
 class DeviceRounds:
-    def __init__(self, device="cuda:0"):
+    """use_graph=True captures the 15 launches of a control step (3 rounds x select / init / solve
+    / relaxed cost / pick) into one hipGraph per (configuration, safe set) and replays it: the
+    launches are back to back with no Python in between."""
+
+    def __init__(self, device="cuda:0", use_graph=True):
         self.device = torch.device(device)
+        self.use_graph = use_graph
         self._solvers = {}
         self._ss_key = None
+        self._plans = {}
 
     def _solver(self, cfg) -> BatchedILQR:
         import ctypes as C
@@ -46,6 +52,62 @@ class DeviceRounds:
             self.device)
         self._ss_key = key
 
+    def _plan(self, ctrl, laps, solver, cfg):
+        """Static buffers + (optionally) the captured graph for one (config, safe set, obstacle
+        on/off) combination."""
+        import ctypes as C
+        p = ctrl.ilqr_param
+        L, k, n, m, N = len(laps), int(p.num_ss_points), cfg.n, cfg.m, cfg.N
+        key = (bytes(C.string_at(C.byref(cfg), C.sizeof(cfg))), self._ss_key, L, k,
+               ctrl.obstacle is not None)
+        if key in self._plans:
+            return self._plans[key]
+        if len(self._plans) > 64:
+            self._plans.clear()
+        B = L * k
+        dev, dt = self.device, solver.dtype
+        pl = dict(buf=solver.alloc(B, want_gains=False), x0=torch.zeros(n, dtype=dt, device=dev),
+                  idx=torch.zeros(L, k, dtype=torch.int32, device=dev),
+                  qf=torch.zeros(B, dtype=torch.int32, device=dev),
+                  cost_it=torch.zeros(B, dtype=dt, device=dev),
+                  best=torch.zeros(2, dtype=torch.int32, device=dev),
+                  x_pred=torch.zeros(n, N + 1, dtype=dt, device=dev),
+                  u_pred=torch.zeros(m, N, dtype=dt, device=dev), graph=None, L=L, k=k)
+        if ctrl.obstacle is not None:
+            pl["buf"]["obs"] = torch.zeros(B, 6, dtype=dt, device=dev)
+        lamb0, max_relax = float(p.lamb), int(p.max_relax_iter)
+        ss, T, qfun = self.ss, self.T, self.qfun
+
+        def launches():
+            buf = pl["buf"]
+            for it in range(3):  # the reference breaks its outer loop at iter == 2 (:472-478)
+                if it == 0:
+                    guess, stride = pl["x0"], 1                      # self.x (:399)
+                else:
+                    guess, stride = pl["x_pred"][:, N:], N + 1       # self.x_pred[:, -1] (:401)
+                solver.select_candidates(ss, T, qfun, guess, stride, k, pl["idx"], buf["x_term"],
+                                         pl["qf"])
+                solver.init_candidates(pl["x0"], lamb0, buf)
+                solver.solve(buf)
+                solver.relax_cost(buf["X"], buf["x_term"], pl["qf"], it, max_relax, pl["cost_it"])
+                solver.pick_best(L, k, pl["cost_it"], buf["X"], buf["U"], pl["best"],
+                                 pl["x_pred"], pl["u_pred"])
+
+        pl["launches"] = launches
+        if self.use_graph:
+            try:
+                launches()  # warm-up outside capture
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    launches()
+                pl["graph"] = g
+            except Exception:  # capture not possible: stay eager
+                pl["graph"] = None
+                torch.cuda.synchronize(self.device)
+        self._plans[key] = pl
+        return pl
+
     def run(self, ctrl, laps):
         """Three rounds for controller `ctrl` over safe-set laps `laps`.  Returns host
         (u_pred[m,N], x_pred[n,N+1], best (lap position, candidate position), idx[L,k] of the
@@ -55,30 +117,15 @@ class DeviceRounds:
                                  np.zeros(4), layout=_abi.LAYOUT_PROBLEM_MAJOR)
         solver = self._solver(cfg)
         self._upload_safe_set(ctrl, laps)
-        L, k, n, m, N = len(laps), int(p.num_ss_points), cfg.n, cfg.m, cfg.N
-        B = L * k
-        dev, dt = self.device, solver.dtype
-        buf = solver.alloc(B, want_gains=False)
+        pl = self._plan(ctrl, laps, solver, cfg)
+        dt = solver.dtype
+        pl["x0"].copy_(torch.as_tensor(np.asarray(ctrl.x, float)).to(dt), non_blocking=True)
         if ctrl.obstacle is not None:
-            buf["obs"] = torch.as_tensor(np.tile(obstacle_record(ctrl.obstacle), (B, 1))).to(dev, dt)
-        x0 = torch.as_tensor(np.asarray(ctrl.x, float)).to(dev, dt)
-        idx = torch.zeros(L, k, dtype=torch.int32, device=dev)
-        qf = torch.zeros(B, dtype=torch.int32, device=dev)
-        cost_it = torch.zeros(B, dtype=dt, device=dev)
-        best = torch.zeros(2, dtype=torch.int32, device=dev)
-        x_pred = torch.zeros(n, N + 1, dtype=dt, device=dev)
-        u_pred = torch.zeros(m, N, dtype=dt, device=dev)
-        for it in range(3):  # the reference breaks its outer loop at iter == 2 (:472-478)
-            if it == 0:
-                guess, stride = x0, 1                      # self.x (:399)
-            else:
-                guess, stride = x_pred[:, N:], N + 1       # self.x_pred[:, -1] (:401)
-            solver.select_candidates(self.ss, self.T, self.qfun, guess, stride, k, idx,
-                                     buf["x_term"], qf)
-            solver.init_candidates(x0, float(p.lamb), buf)
-            solver.solve(buf)
-            solver.relax_cost(buf["X"], buf["x_term"], qf, it, int(p.max_relax_iter), cost_it)
-            solver.pick_best(L, k, cost_it, buf["X"], buf["U"], best, x_pred, u_pred)
-        out = (u_pred.double().cpu().numpy(), x_pred.double().cpu().numpy(),
-               tuple(int(v) for v in best.cpu().numpy()), idx.cpu().numpy())
-        return out
+            rec = torch.as_tensor(np.tile(obstacle_record(ctrl.obstacle), (pl["L"] * pl["k"], 1)))
+            pl["buf"]["obs"].copy_(rec.to(dt), non_blocking=True)
+        if pl["graph"] is not None:
+            pl["graph"].replay()
+        else:
+            pl["launches"]()
+        return (pl["u_pred"].double().cpu().numpy(), pl["x_pred"].double().cpu().numpy(),
+                tuple(int(v) for v in pl["best"].cpu().numpy()), pl["idx"].cpu().numpy())
