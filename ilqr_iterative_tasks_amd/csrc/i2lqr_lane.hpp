@@ -231,6 +231,16 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
                                               T (&inv)[m * m]) const {
     static_assert(m == 2, "lane kernels are built for m == 2 systems");
     const T a = Quu[0], bq = Quu[1], cc = Quu[2], d = Quu[3];
+    // fast path: Quu positive definite -> inv = (Quu + lamb I)^-1 directly (see i2lqr_wave.hpp)
+    if (a > T(0) && a * d - bq * cc > T(0)) {
+      const T ar = a + lamb, dr = d + lamb;
+      const T r = t_rcp(ar * dr - bq * cc);
+      inv[0] = dr * r;
+      inv[1] = -bq * r;
+      inv[2] = -cc * r;
+      inv[3] = ar * r;
+      return;
+    }
     const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
     T disc = hd * hd + bq * cc;
     disc = disc < T(0) ? T(0) : disc;
