@@ -238,11 +238,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.count = nullptr;
     a.resume = 0;
     a.max_total = 0x7fffffff;
-    // fp64: the gains of the first steps stay in LDS — as many steps as keep the register-limited
-    // four wavefronts per CU resident in the 160 KiB (36 KiB each: 5 steps at n=6, m=2).  fp32 is
-    // not on the HBM roof at these sizes and measured 7 % slower with it at 65536 problems: off.
+    // The gains of the first steps stay in LDS: as many steps as keep the register-limited number
+    // of wavefronts per CU resident in the 160 KiB (fp64: 4 per CU x 36 KiB = 5 steps at n=6, m=2;
+    // fp32: 8 per CU x 17 KiB = 4 steps).
     const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-    a.lds_steps = sizeof(T) == 8 ? (36 * 1024) / per_step : 0;
+    a.lds_steps = ((sizeof(T) == 8 ? 36 : 17) * 1024) / per_step;
     if (a.lds_steps > N) a.lds_steps = N;
     a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
     if (!cv) return;

@@ -575,19 +575,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   T lamb = a.lamb[b];
   T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
   T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
-  // Two buffer schemes, chosen per precision from interleaved same-device measurements
-  // (tools/ab_bench.py):
-  //  fp64 — states in ONE buffer (the caller's X): the forward pass writes the candidate states
-  //    over the nominal ones in place (each x_t is loaded one step ahead of being overwritten) and
-  //    a rejected step re-rolls the nominal states from the nominal inputs (bit-identical); only
-  //    the inputs (m N words) are double-buffered per lane.  With X double-buffered per lane,
-  //    divergent accept/reject decisions split every 512-byte row access of a wavefront over two
-  //    buffers: +38 % HBM traffic per iteration (rocprofv3 FETCH_SIZE / WRITE_SIZE,
-  //    tools/pmc_iters.sh); in place: +16 % iterations/s at 65536 problems, +6 % at 2^20.
-  //  fp32 — X and U both double-buffered with per-lane "which buffer" pointers: the rows are half
-  //    as wide, the kernel is less bandwidth-bound and the re-roll costs more than it saves
-  //    (in place was 10-12 % slower).
-  constexpr bool INPLACE = sizeof(T) == 8;
+  // States live in ONE buffer (the caller's X): the forward pass writes the candidate states over
+  // the nominal ones in place (each x_t is loaded one step ahead of being overwritten) and a
+  // rejected step re-rolls the nominal states from the nominal inputs (bit-identical); only the
+  // inputs (m N words) are double-buffered per lane.  With X double-buffered per lane, divergent
+  // accept/reject decisions split every row access of a wavefront over two buffers: +38 % HBM
+  // traffic per iteration (rocprofv3 FETCH_SIZE / WRITE_SIZE, tools/pmc_iters.sh).  In place,
+  // measured on the same device (tools/ab_bench.py): fp64 +7..17 % iterations/s; fp32 +9..12 %
+  // once sin/cos are the short in-line versions (with the library sincosf the re-roll cost more
+  // than the traffic it saved).  The double-buffered form stays selectable for A/B runs.
+  constexpr bool INPLACE = true;
   T* const X0 = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Xc = X0, *Uc = U0;

@@ -25,7 +25,8 @@ template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf
 // sin and cos of one argument.  fp64: Cody-Waite reduction by pi/2 in three FMA steps (exact for
 // |x| < 2^20 pi/2) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]
 // (<= ~1 ulp each); about a third of the instructions of the general-range library routine, which
-// stays as the fallback for |x| >= 1e5.  fp32: the library routine.
+// stays as the fallback for |x| >= 1e5.  fp32: the same scheme in single precision (degree-7 /
+// degree-8 kernels, ~1 ulp, fallback for |x| >= 1e4).
 template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
   if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {
@@ -58,7 +59,28 @@ template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s
   *c = ((q + 1) & 2) ? -cv : cv;
 }
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
-  sincosf(x, s, c);
+  if (__builtin_expect(!(__builtin_fabsf(x) < 1.0e4f), 0)) {
+    sincosf(x, s, c);
+    return;
+  }
+  const float kf = __builtin_rintf(x * 6.36619772367581382433e-01f);
+  float r = __builtin_fmaf(-kf, 1.57079637050628662109375f, x);
+  r = __builtin_fmaf(-kf, -4.37113900018624283e-8f, r);
+  r = __builtin_fmaf(-kf, -1.71512468793638e-15f, r);
+  const int q = (int)kf;
+  const float z = r * r;
+  float ps = -1.9515295891e-4f;
+  ps = __builtin_fmaf(ps, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(ps * z, r, r);
+  float pc = 2.443315711809948e-5f;
+  pc = __builtin_fmaf(pc, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const bool swap = q & 1;
+  const float sv = swap ? cr : sr, cv = swap ? sr : cr;
+  *s = (q & 2) ? -sv : sv;
+  *c = ((q + 1) & 2) ? -cv : cv;
 }
 template <class T> __device__ __forceinline__ T t_exp(T x);
 // fp64 exp: x = k ln2 + r (Cody-Waite), degree-13 Horner on |r| <= ln2/2, v_ldexp (<= ~2 ulp;
@@ -85,7 +107,8 @@ template <> __device__ __forceinline__ double t_exp<double>(double x0) {
   const double e = __builtin_ldexp(p, (int)kf);
   return x0 < -745.14 ? 0.0 : (x0 > 709.79 ? __builtin_inf() : e);
 }
-template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+// fp32 exp: the hardware exp2 path (v_exp_f32), ~2 ulp
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
 template <class T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }

@@ -38,8 +38,11 @@ for v in args.variants.split(","):
     runs.append((v, solver, buf, init, B, []))
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+rng = np.random.default_rng(0)
 for r in range(args.rounds + 1):
-    for v, solver, buf, init, B, times in runs:
+    # a fresh order every round: what ran just before (cache / MALL state, clocks) is not
+    # systematically the same variant
+    for v, solver, buf, init, B, times in [runs[i] for i in rng.permutation(len(runs))]:
         for k in init:
             buf[k].copy_(init[k])
         torch.cuda.synchronize()
