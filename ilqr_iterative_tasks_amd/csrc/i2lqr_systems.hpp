@@ -295,13 +295,18 @@ template <class T> struct Quad12 {
   static constexpr int NVAR = 37;
   static constexpr int system_id = 2;
 
+  // {sin phi, cos phi, sin theta, cos theta, sin psi, cos psi}
+  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
+    t_sincos(xe[3], &tr[0], &tr[1]);
+    t_sincos(xe[4], &tr[2], &tr[3]);
+    t_sincos(xe[5], &tr[4], &tr[5]);
+  }
   template <class Cfg>
-  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
-                                              T (&xn)[n]) {
+  static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                                 const T (&tr)[NTRIG], T (&xn)[n]) {
     const T mass = c.sys_par[0], g = c.sys_par[1], arm = c.sys_par[2];
     const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5], ct = c.sys_par[6];
-    const T sph = t_sin(x[3]), cph = t_cos(x[3]), sth = t_sin(x[4]), cth = t_cos(x[4]);
-    const T sps = t_sin(x[5]), cps = t_cos(x[5]);
+    const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
     const T tth = sth / cth;
     const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
     const T p = x[9], q = x[10], r = x[11], dt = c.dt;
@@ -321,13 +326,12 @@ template <class T> struct Quad12 {
 #pragma unroll
     for (int i = 0; i < n; i++) xn[i] = x[i] + dt * f[i];
   }
-  static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
-    tr[0] = t_sin(xe[3]);
-    tr[1] = t_cos(xe[3]);
-    tr[2] = t_sin(xe[4]);
-    tr[3] = t_cos(xe[4]);
-    tr[4] = t_sin(xe[5]);
-    tr[5] = t_cos(xe[5]);
+  template <class Cfg>
+  static __device__ __forceinline__ void step(const Cfg& c, const T (&x)[n], const T (&u)[m],
+                                              T (&xn)[n]) {
+    T tr[NTRIG];
+    trig(x, tr);
+    step_tr(c, x, u, tr, xn);
   }
   template <class Cfg>
   static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&u)[m],

@@ -390,60 +390,69 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       for (int i = 0; i < m; i++)
 #pragma unroll
         for (int j = 0; j < m; j++) Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
-      // Cholesky of Sm (positive-definiteness test) and of Sm + lamb I, lower triangles
-      T Lp[m * m], Lr[m * m];
+      // Square-root-free LDL^T of Sm (positive-definiteness test: all pivots > 0) and of
+      // Sm + lamb I; unit lower factors Lp, Lr, pivots dp, dr (reciprocals ip, ir).
+      T Lp[m * m], Lr[m * m], ir[m];
       bool pd = true;
 #pragma unroll
       for (int j = 0; j < m; j++) {
         T dp = Sm[j * m + j], dr = Sm[j * m + j] + lamb;
+        T wp[m], wr[m];  // L_jk d_k
 #pragma unroll
         for (int k = 0; k < j; k++) {
-          dp -= Lp[j * m + k] * Lp[j * m + k];
-          dr -= Lr[j * m + k] * Lr[j * m + k];
+          wp[k] = Lp[j * m + k];
+          wr[k] = Lr[j * m + k];
+        }
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+          // Lp/Lr hold L_jk d_k below the diagonal until column j is finished (see below)
+          dp -= wp[k] * Lp[k * m + j];
+          dr -= wr[k] * Lr[k * m + j];
         }
         pd = pd && (dp > T(0));
-        const T sp = t_sqrt(dp > T(0) ? dp : T(1)), sr = t_sqrt(dr > T(0) ? dr : T(1));
-        Lp[j * m + j] = sp;
-        Lr[j * m + j] = sr;
-        const T ip = T(1) / sp, ir = T(1) / sr;
+        const T ipj = t_rcp(dp > T(0) ? dp : T(1));
+        ir[j] = t_rcp(dr > T(0) ? dr : T(1));
 #pragma unroll
         for (int i = j + 1; i < m; i++) {
           T vp = Sm[i * m + j], vr = Sm[i * m + j];
 #pragma unroll
           for (int k = 0; k < j; k++) {
-            vp -= Lp[i * m + k] * Lp[j * m + k];
-            vr -= Lr[i * m + k] * Lr[j * m + k];
+            vp -= Lp[i * m + k] * Lp[k * m + j];
+            vr -= Lr[i * m + k] * Lr[k * m + j];
           }
-          Lp[i * m + j] = vp * ip;
-          Lr[i * m + j] = vr * ir;
+          // lower triangle keeps W_ij = L_ij d_j, upper triangle keeps L_ij (transposed slot)
+          Lp[i * m + j] = vp;
+          Lr[i * m + j] = vr;
+          Lp[j * m + i] = vp * ipj;
+          Lr[j * m + i] = vr * ir[j];
         }
       }
       if (pd) {
-        // inverse of the lower factor, then inv = Lr^-T Lr^-1
+        // Li = Lr^-1 (unit lower), then inv = Li^T diag(ir) Li.  L_ij lives at Lr[j * m + i].
         T Li[m * m];
 #pragma unroll
         for (int i = 0; i < m; i++)
 #pragma unroll
-          for (int j = 0; j < m; j++) Li[i * m + j] = T(0);
+          for (int j = 0; j < m; j++) Li[i * m + j] = (i == j) ? T(1) : T(0);
 #pragma unroll
         for (int j = 0; j < m; j++) {
-          Li[j * m + j] = T(1) / Lr[j * m + j];
 #pragma unroll
           for (int i = j + 1; i < m; i++) {
             T acc = T(0);
 #pragma unroll
-            for (int k = j; k < i; k++) acc += Lr[i * m + k] * Li[k * m + j];
-            Li[i * m + j] = -acc / Lr[i * m + i];
+            for (int k = j; k < i; k++) acc += Lr[k * m + i] * Li[k * m + j];
+            Li[i * m + j] = -acc;
           }
         }
 #pragma unroll
         for (int i = 0; i < m; i++)
 #pragma unroll
-          for (int j = 0; j < m; j++) {
+          for (int j = i; j < m; j++) {
             T acc = T(0);
 #pragma unroll
-            for (int k = (i > j ? i : j); k < m; k++) acc += Li[k * m + i] * Li[k * m + j];
+            for (int k = j; k < m; k++) acc += Li[k * m + i] * ir[k] * Li[k * m + j];
             inv[i * m + j] = acc;
+            inv[j * m + i] = acc;
           }
       } else {
         T V[m * m];

@@ -13,8 +13,10 @@ from ilqr_iterative_tasks_amd import _abi, workloads
 _abi.LIB_PATH = ROOT / "tools" / "_diag" / "libi2lqr_stamps.so"
 from ilqr_iterative_tasks_amd import BatchedILQR
 
-B, iters = 1024, 10
-cfg = workloads.config_for("config2", sys.argv[1] if len(sys.argv) > 1 else "f64")
+B = 1024
+wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
+iters = 10 if wl == "config2" else 4
+cfg = workloads.config_for(wl, sys.argv[1] if len(sys.argv) > 1 else "f64")
 solver = BatchedILQR(cfg)
 host = workloads.make_batch(cfg, B)
 buf = solver.alloc(B)
