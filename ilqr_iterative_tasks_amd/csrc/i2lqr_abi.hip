@@ -79,6 +79,8 @@ struct i2lqr_handle {
   void* ws;         // caller-owned scratch of the batch-minor kernels
   int64_t ws_bytes;
   int64_t compact_min_batch;  // > 0: i2lqr_solve uses the chunked, compacting form from this batch
+  // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
+  int opt_defer, opt_reroll, opt_lds_steps;
 };
 
 namespace {
@@ -239,12 +241,20 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.resume = 0;
     a.max_total = 0x7fffffff;
     // The gains of the first steps stay in LDS: as many steps as keep the register-limited number
-    // of wavefronts per CU resident in the 160 KiB (fp64: 4 per CU x 36 KiB = 5 steps at n=6, m=2;
-    // fp32: 8 per CU x 17 KiB = 4 steps).
+    // of wavefronts per CU (one per SIMD, four per CU) resident in the 160 KiB: 36 KiB each, i.e.
+    // 5 steps in fp64 and 10 in fp32 at n=6, m=2.
     const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-    a.lds_steps = ((sizeof(T) == 8 ? 36 : 17) * 1024) / per_step;
+    a.lds_steps = (36 * 1024) / per_step;
     if (a.lds_steps > N) a.lds_steps = N;
     a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
+    a.defer = 1;  // the forward pass stores no states; accepted steps re-roll them (see i2lqr_lane.hpp)
+    a.dbg = nullptr;
+#ifdef I2LQR_STAMPS
+    if (const char* e = getenv("I2LQR_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+    if (h->opt_reroll >= 0) a.reroll = h->opt_reroll;
+    if (h->opt_defer >= 0) a.defer = h->opt_defer;
+    if (h->opt_lds_steps >= 0 && h->opt_lds_steps < a.lds_steps) a.lds_steps = h->opt_lds_steps;
     if (!cv) return;
     for (int q = 0; q < 2; q++) {
       LaneSet<T>& st = cv->set[q];
@@ -359,7 +369,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.obs = (const T*)obs; a.cost = (T*)cost; a.K = (T*)K; a.k = (T*)k;
     a.iters = iters; a.status = status;
     a.max_total = n_iters;
-    if (early_exit) a.reroll = 0;  // solve() is bound by its slowest problem's latency, not HBM
+    if (early_exit) {  // solve() is bound by its slowest problem's latency, not by HBM traffic
+      if (h->opt_reroll < 0) a.reroll = 0;
+      if (h->opt_defer < 0) a.defer = 0;
+    }
     launch_iterate<TILED>(c, a, B, s);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
@@ -651,6 +664,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->compact_min_batch = 0;
+  h->opt_defer = h->opt_reroll = h->opt_lds_steps = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
   if (rc != I2LQR_OK) {
@@ -692,6 +706,17 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch) {
   if (h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR && min_batch > 0)
     return fail(I2LQR_ERR_UNSUPPORTED, "compaction applies to the batch-minor / batch-tiled layouts");
   h->compact_min_batch = min_batch;
+  return I2LQR_OK;
+}
+
+int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return fail(I2LQR_ERR_INVALID, "null handle or option name");
+  if (value < -1 || value > 0x7fffffff) return fail(I2LQR_ERR_INVALID, "option value out of range");
+  const int v = (int)value;
+  if (!strcmp(name, "defer_states")) h->opt_defer = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "reroll_nominal")) h->opt_reroll = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
+  else return fail(I2LQR_ERR_INVALID, "unknown option '%s'", name);
   return I2LQR_OK;
 }
 

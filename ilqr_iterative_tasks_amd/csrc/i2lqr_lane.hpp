@@ -4,12 +4,11 @@
 // A/B Jacobians, Q_xx / Q_ux / Q_uu) live in that lane's registers with every loop fully
 // unrolled at compile time, so the sparsity pattern of [A | B] folds into the instruction stream
 // and all 64 lanes do useful arithmetic on every VALU instruction.  The trajectory, gains and
-// the per-step trig cache stream through HBM in the BATCH-MINOR layout
-//     X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  lamb[B]  obs[6][B]
-// so a wavefront's access to one (component, t) is one fully coalesced 512-byte (fp64) row.
-// sin/cos of the heading are recomputed where needed (35 instructions) instead of being cached
-// in HBM: the kernel is bandwidth-bound, not instruction-bound, at large batch.
-// This is the HBM-bound form of the algorithm: per iteration and problem it moves X, U, K, k once
+// gains stream through HBM in the BATCH-MINOR, TIME-MAJOR layout
+//     X[N+1][n][B]  U[N][m][B]  K[N][m][n][B]  k[N][m][B]  x_term[n][B]  lamb[B]  obs[6][B]
+// so a wavefront's access to one (t, component) is one fully coalesced 512-byte (fp64) row and
+// the words of one horizon step are adjacent rows.
+// This is the streaming form of the algorithm: per iteration and problem it moves X, U, K, k once
 // in each direction (SURVEY.md §8(d) algorithmic bytes).
 //
 // Reference being replaced: control/iterative_ilqr.py:7-160, control/ilqr_helper.py:9-150,
@@ -45,6 +44,8 @@ template <class T> struct LaneArgs {
   // chunk ends gets status RUNNING unless it has reached max_total iterations
   const int32_t* count;
   int resume, max_total;
+  unsigned long long* dbg;  // diagnostic builds only: [B/64][8] phase cycle sums
+  int defer;      // forward pass stores no states; an accepted step re-rolls them
   int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
   int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
 };
@@ -60,30 +61,56 @@ template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int
 // n=6, N=20, fp64): DRAM-page and TLB friendly at very large B.  Each array of `rows` rows is
 // re-based to the wavefront's tile, after which the kernels index it as a batch of 64.
 template <bool TILED> struct LaneView {
-  int64_t Bs;  // row stride
-  int64_t bl;  // this lane's index inside a row
-  int64_t tile;
-  __device__ LaneView(int64_t B, int64_t b)
-      : Bs(TILED ? 64 : B), bl(TILED ? (b & 63) : b), tile(TILED ? (b >> 6) : 0) {}
+  int64_t Bs;     // row stride
+  unsigned bl;    // this lane's index inside the wavefront's 64 columns of a row
+  int64_t tile;   // wavefront index (workgroups are one wavefront): uniform, lives in SGPRs
+  __device__ LaneView(int64_t B)
+      : Bs(TILED ? 64 : B), bl(threadIdx.x), tile(blockIdx.x) {}
+  // Re-base an array of `rows` rows to this wavefront's 64 problems.  The result is WAVE-UNIFORM
+  // (scalar registers); element (row, lane) is p[row * Bs + bl], which the compiler addresses as
+  // scalar base + per-lane 32-bit offset + immediate row offset.
   template <class P> __device__ __forceinline__ P* rebase(P* p, int rows) const {
-    return (TILED && p) ? p + tile * (int64_t)rows * 64 : p;
+    if (!p) return p;
+    return TILED ? p + tile * (int64_t)rows * 64 : p + tile * 64;
   }
 };
 
-template <class T, class Sys, bool HASQR> struct LaneWorker {
+#ifndef I2LQR_F64_WAVES
+#define I2LQR_F64_WAVES 1
+#endif
+#ifndef I2LQR_F32_WAVES
+#define I2LQR_F32_WAVES 1
+#endif
+template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG, NV = Sys::NVAR;
   using Cfg = DevCfg<T, n, m>;
   const Cfg& c;
   const int N;
-  const int64_t B, b;  // batch size, this lane's problem
+  const int64_t Bs_;    // row stride of the batch-minor layout (the tiled one is 64 at compile time)
+  const unsigned lane;  // this lane's column inside the wavefront's re-based rows
   // Gains of the first `lds_steps` horizon steps stay in LDS: the backward pass produces them
   // last and the forward pass consumes them first, so they never need to travel through HBM
   // (flushed once at kernel exit for the caller).  Word (t, q) of lane l sits at
   // lds[(t * m (n+1) + q) * 64 + l]: consecutive lanes on consecutive words, conflict-free.
   T* lds = nullptr;
   int lds_steps = 0;
+#ifdef I2LQR_STAMPS
+  mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#endif
 
-  __device__ LaneWorker(const Cfg& c_, int64_t B_, int64_t b_) : c(c_), N(c_.N), B(B_), b(b_) {}
+  __device__ LaneWorker(const Cfg& c_, int64_t Bs, unsigned lane_)
+      : c(c_), N(c_.N), Bs_(Bs), lane(lane_) {}
+  // Element (row, this lane) of a re-based (wave-uniform) array.  Rows are TIME-major:
+  //   X: t n + i    U, k: t m + a    K: (t m + a) n + j
+  // so the words of one horizon step are adjacent rows: one scalar base per step, immediate
+  // offsets per word, no per-access vector address arithmetic.
+  __device__ __forceinline__ int64_t stride() const { return TILED ? (int64_t)64 : Bs_; }
+  template <class P> __device__ __forceinline__ P& at(P* p, int row) const {
+    return (p + (int64_t)row * stride())[lane];
+  }
+  static __device__ __forceinline__ int rx(int i, int t) { return t * n + i; }
+  static __device__ __forceinline__ int ru(int a, int t) { return t * m + a; }
+  static __device__ __forceinline__ int rK(int a, int j, int t) { return (t * m + a) * n + j; }
   __device__ __forceinline__ T& lds_gain(int t, int q) const {
     return lds[(t * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
   }
@@ -94,18 +121,10 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       for (int a = 0; a < m; a++) {
 #pragma unroll
         for (int j = 0; j < n; j++)
-          gK[(((int64_t)a * n + j) * N + t) * B + b] = lds_gain(t, a * (n + 1) + j);
-        gk[iu(a, t)] = lds_gain(t, a * (n + 1) + n);
+          at(gK, rK(a, j, t)) = lds_gain(t, a * (n + 1) + j);
+        at(gk, ru(a, t)) = lds_gain(t, a * (n + 1) + n);
       }
     }
-  }
-
-  // batch-minor addressing
-  __device__ __forceinline__ int64_t ix(int comp, int t) const {  // X-like [comp][N+1][B]
-    return ((int64_t)comp * (N + 1) + t) * B + b;
-  }
-  __device__ __forceinline__ int64_t iu(int comp, int t) const {  // U-like [comp][N][B]
-    return ((int64_t)comp * N + t) * B + b;
   }
 
   template <int D> __device__ __forceinline__ T quad_form(const T* M, const T (&d)[D]) const {
@@ -164,18 +183,18 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   __device__ __forceinline__ T rollout(T* X, T* U, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
-    for (int i = 0; i < n; i++) x[i] = X[ix(i, 0)];
+    for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
     T cost = T(0);
     for (int t = 0; t < N; t++) {
 #pragma unroll
       for (int a = 0; a < m; a++) {
-        u[a] = clip(U[iu(a, t)], -c.u_max[a], c.u_max[a]);
-        U[iu(a, t)] = u[a];
+        u[a] = clip(at(U, ru(a, t)), -c.u_max[a], c.u_max[a]);
+        at(U, ru(a, t)) = u[a];
       }
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
 #pragma unroll
-      for (int i = 0; i < n; i++) X[ix(i, t + 1)] = xn[i];
+      for (int i = 0; i < n; i++) at(X, rx(i, t + 1)) = xn[i];
       cost = cost + stage_cost(x, c.xtarget, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
@@ -190,15 +209,15 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   __device__ __forceinline__ void restore_states(T* X, const T* U) const {
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
-    for (int i = 0; i < n; i++) x[i] = X[ix(i, 0)];
+    for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
     for (int t = 0; t < N; t++) {
 #pragma unroll
-      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t));
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
 #pragma unroll
       for (int i = 0; i < n; i++) {
-        X[ix(i, t + 1)] = xn[i];
+        at(X, rx(i, t + 1)) = xn[i];
         x[i] = xn[i];
       }
     }
@@ -271,7 +290,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
-  // Reads the nominal (X, U), writes the gains to gK[m][n][N][B], gk[m][N][B].
+  // Reads the nominal (X, U), writes the gains to gK[N][m][n][B], gk[N][m][B].
   // SYM: V_xx, Q_xx and Q_uu are symmetric in exact arithmetic (the reference never re-symmetrises
   // them, so its copies differ by round-off, ~1e-16 relative).  The lane kernels keep only the
   // upper triangles: a quarter fewer multiply-adds and ~30 fewer live doubles per lane, which is
@@ -286,7 +305,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
 #pragma unroll
-      for (int i = 0; i < n; i++) xN[i] = X[ix(i, N)];
+      for (int i = 0; i < n; i++) xN[i] = at(X, rx(i, N));
       obstacle(ob, xN[0], xN[1], N, o);
 #pragma unroll
       for (int i = 0; i < n; i++) {
@@ -307,13 +326,14 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     // x_t of step t (obstacle / stage terms) and the evaluation state x_{t+1} of step t-1.
     T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t
 #pragma unroll
-    for (int i = 0; i < n; i++) xe[i] = X[ix(i, N)];
+    for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
 #pragma unroll
-    for (int i = 0; i < n; i++) xp[i] = X[ix(i, N - 1)];
+    for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
 #pragma unroll
-    for (int a = 0; a < m; a++) u[a] = U[iu(a, N - 1)];
+    for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
     for (int t = N - 1; t >= 0; t--) {
       T jv[NV], o[5], tr[NT];
+      STAMP_BEGIN();
       Sys::trig(xe, tr);  // the same values the rollout used for the dynamics of step t+1
       Sys::jac_var(c, xe, u, tr, jv);
       obstacle(ob, xp[0], xp[1], t, o);
@@ -346,11 +366,12 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       for (int i = 0; i < n; i++) xe[i] = xp[i];
       if (t > 0) {
 #pragma unroll
-        for (int i = 0; i < n; i++) xp[i] = X[ix(i, t - 1)];
+        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - 1));
 #pragma unroll
-        for (int a = 0; a < m; a++) u[a] = U[iu(a, t - 1)];
+        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - 1));
       }
 
+      STAMP_END(0);
       // Row by row: T1[a][:] = (F^T [Vxx|Vx])[a][:], then H[a][:] = L[a][:] + T1[a][:n] F
       T Qa[n][n + 1];   // [Qxx | Qx]
       T G[m][n + 1];    // [Qux | Qu]
@@ -403,6 +424,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
         }
       });
 
+      STAMP_END(1);
       // gains [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
       T Qinv[m * m], Kk[m][n + 1];
       if constexpr (SYM) {
@@ -430,10 +452,11 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 #pragma unroll
         for (int a = 0; a < m; a++) {
 #pragma unroll
-          for (int j = 0; j < n; j++) gK[(((int64_t)a * n + j) * N + t) * B + b] = Kk[a][j];
-          gk[iu(a, t)] = Kk[a][n];
+          for (int j = 0; j < n; j++) at(gK, rK(a, j, t)) = Kk[a][j];
+          at(gk, ru(a, t)) = Kk[a][n];
         }
       }
+      STAMP_END(2);
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
 #pragma unroll
       for (int i = 0; i < n; i++) {
@@ -453,6 +476,7 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
           Va[i][j] = Qa[i][j] - acc;
         }
       }
+      STAMP_END(3);
     }
   }
 
@@ -461,16 +485,18 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
   // inputs next to the candidate (bit-identical to the stored X: same code, same inputs) instead
   // of being read back — n (N+1) words less HBM traffic per iteration for one more dynamics step
   // per horizon step.  Pays where the kernel sits on the HBM roof (fp64).
-  template <bool REROLL>
+  // WRITEX = false: the candidate states are not stored at all (the nominal ones stay intact); the
+  // caller re-rolls them from the candidate inputs if the step is accepted (restore_states()).
+  template <bool REROLL, bool WRITEX = true>
   __device__ __forceinline__ T forward(const T* X, const T* U, const T* gK, const T* gk, T* Xn,
                                        T* Un, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
     T xo[n], uo[m], kk[m][n + 1];
 #pragma unroll
     for (int i = 0; i < n; i++) {
-      x[i] = X[ix(i, 0)];
+      x[i] = at(X, rx(i, 0));
       xo[i] = x[i];
-      if (Xn != X) Xn[ix(i, 0)] = x[i];
+      if (WRITEX && Xn != X) at(Xn, rx(i, 0)) = x[i];
     }
     T cost = T(0);
     // The nominal state / input / gains of a step are consumed at its very start (the feedback
@@ -479,10 +505,10 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     auto load_step = [&](int t) {
       if constexpr (!REROLL) {
 #pragma unroll
-        for (int j = 0; j < n; j++) xo[j] = X[ix(j, t)];
+        for (int j = 0; j < n; j++) xo[j] = at(X, rx(j, t));
       }
 #pragma unroll
-      for (int a = 0; a < m; a++) uo[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) uo[a] = at(U, ru(a, t));
       if (t < lds_steps) {
 #pragma unroll
         for (int a = 0; a < m; a++)
@@ -492,8 +518,8 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 #pragma unroll
         for (int a = 0; a < m; a++) {
 #pragma unroll
-          for (int j = 0; j < n; j++) kk[a][j] = gK[(((int64_t)a * n + j) * N + t) * B + b];
-          kk[a][n] = gk[iu(a, t)];
+          for (int j = 0; j < n; j++) kk[a][j] = at(gK, rK(a, j, t));
+          kk[a][n] = at(gk, ru(a, t));
         }
       }
     };
@@ -516,11 +542,13 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
       }
       if (t + 1 < N) load_step(t + 1);
 #pragma unroll
-      for (int a = 0; a < m; a++) Un[iu(a, t)] = u[a];
+      for (int a = 0; a < m; a++) at(Un, ru(a, t)) = u[a];
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
+      if constexpr (WRITEX) {
 #pragma unroll
-      for (int i = 0; i < n; i++) Xn[ix(i, t + 1)] = xn[i];
+        for (int i = 0; i < n; i++) at(Xn, rx(i, t + 1)) = xn[i];
+      }
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
@@ -536,13 +564,13 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
     T cost = T(0);
     for (int t = 0; t < N; t++) {
 #pragma unroll
-      for (int i = 0; i < n; i++) x[i] = X[ix(i, t)];
+      for (int i = 0; i < n; i++) x[i] = at(X, rx(i, t));
 #pragma unroll
-      for (int a = 0; a < m; a++) u[a] = U[iu(a, t)];
+      for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t));
       cost = cost + stage_cost(x, c.xtarget, u);
     }
 #pragma unroll
-    for (int i = 0; i < n; i++) x[i] = X[ix(i, N)];
+    for (int i = 0; i < n; i++) x[i] = at(X, rx(i, N));
     return cost + terminal_cost(x, xT);
   }
 };
@@ -553,15 +581,15 @@ template <class T, class Sys, bool HASQR> struct LaneWorker {
 // fp32 fits two waves per SIMD (<= 256 registers) with a few spilled words; fp64 needs ~450
 // registers for the unrolled Riccati step and runs one wave per SIMD.
 template <class T, class Sys, bool HASQR, bool TILED>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_WAVES)) void k_lane_iterate(
     const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
   const int N = c.N;
-  const LaneView<TILED> v(a.B, b);
-  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const LaneView<TILED> v(a.B);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   extern __shared__ __align__(16) unsigned char lane_smem[];
   w.lds = reinterpret_cast<T*>(lane_smem);
   w.lds_steps = a.lds_steps;
@@ -598,13 +626,32 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
   T cost_ret = cost;
   while (it < a.n_iters && it0 + it < a.max_total) {
     w.backward(Xc, Uc, xT, ob, lamb, gK, gk);
-    const T cost_new = (INPLACE && a.reroll)
-                           ? w.template forward<true>(Xc, Uc, gK, gk, Xn, Un, xT)
-                           : w.template forward<false>(Xc, Uc, gK, gk, Xn, Un, xT);
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_BEGIN();
+    }
+#endif
+    T cost_new;
+    if (a.defer) {
+      cost_new = a.reroll ? w.template forward<true, false>(Xc, Uc, gK, gk, Xn, Un, xT)
+                          : w.template forward<false, false>(Xc, Uc, gK, gk, Xn, Un, xT);
+    } else {
+      cost_new = (INPLACE && a.reroll)
+                     ? w.template forward<true>(Xc, Uc, gK, gk, Xn, Un, xT)
+                     : w.template forward<false>(Xc, Uc, gK, gk, Xn, Un, xT);
+    }
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_END(4);
+    }
+#endif
     it++;
     if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
       T* tp = Uc; Uc = Un; Un = tp;
       if constexpr (!INPLACE) { tp = Xc; Xc = Xn; Xn = tp; }
+      if (a.defer) w.restore_states(Xc, Uc);  // store the accepted candidate's states
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
@@ -615,7 +662,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
         if (status == 0) status = 1;
       }
     } else {  // control/iterative_ilqr.py:81-84
-      if constexpr (INPLACE) w.restore_states(Xc, Uc);
+      if (INPLACE && !a.defer) w.restore_states(Xc, Uc);
       lamb *= c.lamb_factor;
       cost_ret = cost;
       if (lamb > c.max_lamb) {
@@ -623,10 +670,20 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_lane_iterate(
         if (status == 0) status = 3;
       }
     }
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_END(5);
+    }
+#endif
   }
   // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
   if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
   if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
+#ifdef I2LQR_STAMPS
+  if (a.dbg && threadIdx.x == 0)
+    for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
+#endif
   w.flush_gains(gK, gk);
   if (Xc != X0) {  // the accepted states sit in the workspace: copy them out
     for (int e = 0; e < n * (N + 1); e++)
@@ -706,8 +763,8 @@ __global__ __launch_bounds__(64) void k_lane_rollout(const DevCfg<T, Sys::n, Sys
   constexpr int n = Sys::n, m = Sys::m;
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const LaneView<TILED> v(B, b);
-  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const LaneView<TILED> v(B);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   const T* gxt = v.rebase(x_term, n);
   T xT[n];
 #pragma unroll
@@ -723,8 +780,8 @@ __global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sy
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   const int N = c.N;
-  const LaneView<TILED> v(B, b);
-  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const LaneView<TILED> v(B);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   const T* gxt = v.rebase(x_term, n);
   const T* gob = v.rebase(obs, 6);
   T xT[n], ob[6];
@@ -745,8 +802,8 @@ __global__ __launch_bounds__(64) void k_lane_forward(const DevCfg<T, Sys::n, Sys
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   const int N = c.N;
-  const LaneView<TILED> v(B, b);
-  LaneWorker<T, Sys, HASQR> w(c, v.Bs, v.bl);
+  const LaneView<TILED> v(B);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   const T* gxt = v.rebase(x_term, n);
   T xT[n];
 #pragma unroll

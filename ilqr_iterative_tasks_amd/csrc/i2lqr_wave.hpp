@@ -964,13 +964,15 @@ __global__ void k_relax_cost(int64_t B, int n, int N, int batch_minor, const T* 
   if (b >= B) return;
   double ss = 0.0;
   for (int i = 0; i < n; i++) {
-    double xN, xt;  // batch_minor: 0 problem-major, 1 batch-minor, 2 batch-tiled (tiles of 64)
+    // batch_minor: 0 problem-major, 1 batch-minor, 2 batch-tiled (tiles of 64); the lane
+    // layouts are time-major: state row of (t, i) is t n + i
+    double xN, xt;
     if (batch_minor == 2) {
       const int64_t tile = b >> 6, l = b & 63;
-      xN = (double)X[(tile * (int64_t)(n * (N + 1)) + (int64_t)i * (N + 1) + N) * 64 + l];
+      xN = (double)X[(tile * (int64_t)(n * (N + 1)) + (int64_t)N * n + i) * 64 + l];
       xt = (double)x_term[(tile * n + i) * 64 + l];
     } else if (batch_minor == 1) {
-      xN = (double)X[((int64_t)i * (N + 1) + N) * B + b];
+      xN = (double)X[((int64_t)N * n + i) * B + b];
       xt = (double)x_term[(int64_t)i * B + b];
     } else {
       xN = (double)X[b * (int64_t)(n * (N + 1)) + i * (N + 1) + N];

@@ -8,10 +8,10 @@ Tensor layouts (cfg.layout):
   problem-major (default; the reference's NumPy layout with a leading batch axis, time contiguous;
   control/iterative_ilqr.py:109-110, utils/base.py:405-409) — one problem per wavefront kernels:
     X[B, n, N+1]   U[B, m, N]   K[B, m, n, N]   k[B, m, N]   x_term[B, n]   lamb[B]   obs[B, 6]
-  batch-minor (batch index fastest) — one problem per lane kernels, the large-batch path:
-    X[n, N+1, B]   U[m, N, B]   K[m, n, N, B]   k[m, N, B]   x_term[n, B]   lamb[B]   obs[6, B]
-  batch-tiled (batch-minor inside tiles of 64 problems; B % 64 == 0) — same kernels:
-    X[B/64, n, N+1, 64]   U[B/64, m, N, 64]   K[B/64, m, n, N, 64]   ...   lamb[B] (flat)
+  batch-minor (batch index fastest, time slowest) — one problem per lane kernels, large batches:
+    X[N+1, n, B]   U[N, m, B]   K[N, m, n, B]   k[N, m, B]   x_term[n, B]   lamb[B]   obs[6, B]
+  batch-tiled (the same inside tiles of 64 problems; B % 64 == 0) — same kernels:
+    X[B/64, N+1, n, 64]   U[B/64, N, m, 64]   K[B/64, N, m, n, 64]   ...   lamb[B] (flat)
 `to_native()` / `to_problem_major()` convert between the two.
 """
 from __future__ import annotations
@@ -88,6 +88,8 @@ class BatchedILQR:
         core = {"X": (n, N + 1), "U": (m, N), "K": (m, n, N), "k": (m, N), "x_term": (n,),
                 "obs": (OBS_WORDS,), "lamb": (), "cost": (), "iters": (), "status": (),
                 "qfun": (), "cost_it": ()}[name]
+        if (self.batch_minor or self.batch_tiled) and len(core) >= 2:
+            core = core[-1:] + core[:-1]  # the lane layouts are time-major
         if self.batch_tiled and core:
             if B % 64:
                 raise ValueError(f"batch-tiled layout needs B % 64 == 0, got {B}")
@@ -98,6 +100,8 @@ class BatchedILQR:
         """problem-major [B, ...] tensor -> this solver's layout (contiguous)."""
         if t.dim() == 1 or not (self.batch_minor or self.batch_tiled):
             return t.contiguous()
+        if t.dim() >= 3:  # trajectories and gains: time (the last axis) becomes the slowest
+            t = t.movedim(-1, 1)
         if self.batch_tiled:
             if t.shape[0] % 64:
                 raise ValueError(f"batch-tiled layout needs B % 64 == 0, got {t.shape[0]}")
@@ -109,8 +113,12 @@ class BatchedILQR:
             return t
         if self.batch_tiled:
             u = t.movedim(-1, 1)
-            return u.reshape(u.shape[0] * 64, *u.shape[2:]).contiguous()
-        return t.movedim(-1, 0).contiguous()
+            u = u.reshape(u.shape[0] * 64, *u.shape[2:])
+        else:
+            u = t.movedim(-1, 0)
+        if u.dim() >= 3:
+            u = u.movedim(1, -1)
+        return u.contiguous()
 
     def batch_of(self, X: torch.Tensor) -> int:
         if self.batch_tiled:
@@ -130,6 +138,11 @@ class BatchedILQR:
         """Opt into the chunked, compacting form of solve() from `min_batch` problems (lane
         layouts; off by default — see include/i2lqr.h)."""
         self._check(self.lib.i2lqr_set_compaction(self._handle, int(min_batch)))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Scheduling options of the lane kernels (include/i2lqr.h: "defer_states",
+        "reroll_nominal", "lds_gain_steps"); -1 restores the automatic choice."""
+        self._check(self.lib.i2lqr_set_option(self._handle, name.encode(), int(value)))
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,

@@ -21,11 +21,12 @@
  *    (xvar[n, N+1], uvar[m, N], K[m, n, N], k[m, N]; control/iterative_ilqr.py:109-110,
  *    utils/base.py:405-409):
  *        X[B][n][N+1]  U[B][m][N]  K[B][m][n][N]  k[B][m][N]  x_term[B][n]  obs[B][6]
- *    Layout I2LQR_LAYOUT_BATCH_MINOR: the batch index is the fastest axis
- *        X[n][N+1][B]  U[m][N][B]  K[m][n][N][B]  k[m][N][B]  x_term[n][B]  obs[6][B]
- *    (one problem per lane; used by the throughput kernels).
- *    Layout I2LQR_LAYOUT_BATCH_TILED: batch-minor inside tiles of 64 problems, tiles outermost
- *        X[B/64][n][N+1][64]  U[B/64][m][N][64]  K[B/64][m][n][N][64]  k[B/64][m][N][64]
+ *    Layout I2LQR_LAYOUT_BATCH_MINOR: the batch index is the fastest axis and TIME the slowest
+ *        X[N+1][n][B]  U[N][m][B]  K[N][m][n][B]  k[N][m][B]  x_term[n][B]  obs[6][B]
+ *    (one problem per lane; used by the throughput kernels: the words of one horizon step are
+ *    adjacent rows of B).
+ *    Layout I2LQR_LAYOUT_BATCH_TILED: the same inside tiles of 64 problems, tiles outermost
+ *        X[B/64][N+1][n][64]  U[B/64][N][m][64]  K[B/64][N][m][n][64]  k[B/64][N][m][64]
  *        x_term[B/64][n][64]  obs[B/64][6][64];  lamb, cost, iters, status stay flat [B].
  *    B must be a multiple of 64.  Same kernels; every wavefront's rows are contiguous in HBM.
  *  - obs record = {x, y, width, height, spd, moving_option}; moving_option 0 = static,
@@ -141,6 +142,24 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
  * the lanes that are still running — so it stays off by default.
  */
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
+
+/*
+ * Scheduling options of the one-problem-per-lane kernels (batch-minor / batch-tiled layouts).
+ * They change how the work is laid out on the GPU, never the results (bit-identical; tests/).
+ * value -1 restores the automatic choice.  No reference counterpart (the NumPy path has no such
+ * degrees of freedom); they exist so that A/B measurements run in one process on one device.
+ *   "defer_states"    1: the forward pass (control/iterative_ilqr.py:133-160) stores only the
+ *                     candidate inputs; the states of an ACCEPTED step are re-rolled from them
+ *                     (rejected steps cost no state traffic at all).  0: candidate states are
+ *                     written in place and a rejected step re-rolls the nominal ones.
+ *                     Automatic: 1 for i2lqr_iterate, 0 for i2lqr_solve.
+ *   "reroll_nominal"  1: the forward pass re-rolls the nominal states it needs for the feedback
+ *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
+ *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the
+ *                     backward and the forward pass (automatic: what fits next to four
+ *                     wavefronts per CU).
+ */
+int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 
 /*
  * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.

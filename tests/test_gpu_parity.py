@@ -314,6 +314,36 @@ def test_tiled_layout_is_bit_identical_to_batch_minor(torch_mod, dtype):
         s_t.alloc(100)
 
 
+@pytest.mark.parametrize("lay,dtype", [("lane", "f64"), ("tiled", "f64"), ("tiled", "f32")])
+def test_lane_scheduling_options_do_not_change_results(torch_mod, lay, dtype):
+    """i2lqr_set_option: deferred state stores, nominal re-roll and the number of LDS-resident gain
+    steps only move work around — every combination must reproduce, bit for bit, the plain
+    configuration (states read back, candidate written in place, no gains in LDS), for the fused
+    iterations and for the solve; an unknown option is an error."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    from ilqr_iterative_tasks_amd.solver import I2lqrError
+    solver, cfg = make_solver("bicycle6", 20, dtype, dt=0.25, layout=lay)
+    host = workloads.make_batch(cfg, 2048)
+
+    def run(defer, reroll, lds):
+        solver.set_option("defer_states", defer)
+        solver.set_option("reroll_nominal", reroll)
+        solver.set_option("lds_gain_steps", lds)
+        it = solver.iterate(dev_batch(solver, host), 7)
+        so = solver.solve(dev_batch(solver, host))
+        return it, so
+
+    ref_it, ref_so = run(0, 0, 0)
+    for defer, reroll, lds in ((1, 1, -1), (1, 0, 3), (0, 1, -1), (-1, -1, -1)):
+        it, so = run(defer, reroll, lds)
+        for got, want in ((it, ref_it), (so, ref_so)):
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(got[key], want[key]), (key, defer, reroll, lds)
+    with pytest.raises(I2lqrError):
+        solver.set_option("no_such_option", 1)
+
+
 @pytest.mark.parametrize("lay,dtype,gains", [("lane", "f64", True), ("lane", "f32", False),
                                              ("tiled", "f64", False), ("tiled", "f32", True)])
 def test_chunked_compacting_solve_is_bit_identical_to_plain(torch_mod, lay, dtype, gains):

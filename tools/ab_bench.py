@@ -23,11 +23,15 @@ runs = []
 for v in args.variants.split(","):
     parts = v.split(":")
     layout, dtype, B = parts[:3]
-    lib_path = parts[3] if len(parts) > 3 else None  # e.g. tools/_diag/libold.so
+    lib_path = (parts[3] if len(parts) > 3 else None) or None  # e.g. tools/_diag/libold.so
+    # optional 5th field: i2lqr_set_option settings of this variant, e.g. defer_states=1;reroll_nominal=0
+    opts = dict(kv.split("=") for kv in parts[4].split(";")) if len(parts) > 4 else {}
     B = int(B)
     cfg = workloads.config_for(args.workload, dtype)
     cfg.layout = LAY[layout]
     solver = BatchedILQR(cfg, lib_path=lib_path)
+    for key, val in opts.items():
+        solver.set_option(key, int(val))
     host = workloads.make_batch(cfg, B)
     dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
     buf = solver.alloc(B)
@@ -54,6 +58,6 @@ for r in range(args.rounds + 1):
             times.append(e0.elapsed_time(e1))
 for v, solver, buf, init, B, times in runs:
     t = np.array(times)
-    print(f"{v:24s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  -> "
+    print(f"{v:56s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  -> "
           f"{B * args.iters / np.median(t) / 1e3:8.1f} M it/s (median)  "
           f"{B * args.iters / t.min() / 1e3:8.1f} (best)")
