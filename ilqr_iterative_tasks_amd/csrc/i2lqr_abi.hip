@@ -51,7 +51,13 @@ template <class T, int n, int m> DevCfg<T, n, m> make_dev_cfg(const i2lqr_config
   d.obs_q2 = (T)h.obs_q2;
   d.safety_margin = (T)h.safety_margin;
   bool hasQ = false, hasR = false;
-  for (int a = 0; a < m; a++) d.u_max[a] = (T)h.u_max[a];
+  d.fast_barrier = 1;
+  for (int a = 0; a < m; a++) {
+    d.u_max[a] = (T)h.u_max[a];
+    const double span = 2.0 * h.ctrl_q2 * h.u_max[a];
+    d.ctrl_c[a] = (T)std::exp(-span);
+    if (!(std::fabs(span) < 600.0)) d.fast_barrier = 0;
+  }
   for (int i = 0; i < n; i++) d.xtarget[i] = (T)h.xtarget[i];
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) {

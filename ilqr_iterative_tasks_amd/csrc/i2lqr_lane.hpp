@@ -298,6 +298,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // i2lqr_create for these layouts).  The one-problem-per-wavefront kernels keep the full blocks.
   static constexpr bool SYM = true;
 
+  template <bool FASTBAR = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk) const {
     T Va[n][n + 1];  // [Vxx | Vx]; with SYM only Va[i][j >= i] and the last column are live
@@ -338,11 +339,23 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       Sys::jac_var(c, xe, u, tr, jv);
       obstacle(ob, xp[0], xp[1], t, o);
       // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
+      //   l_u = q1 q2 (e_hi - e_lo),  l_uu = q1 q2^2 (e_hi + e_lo),
+      //   e_hi = exp(q2 (u - u_max)),  e_lo = exp(q2 (-u_max - u)).
+      // FASTBAR (fused fp64 kernels, whose inputs are clipped to [-u_max, u_max] by the rollout /
+      // forward pass, and configurations with |2 q2 u_max| < 600): e_hi e_lo = exp(-2 q2 u_max) is
+      // a constant, so e_lo = ctrl_c / e_hi — one short exp (no range handling: the argument is
+      // bounded) and one reciprocal per input instead of two general exps; a few ulp apart.
       T lu[m], luu[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
-        const T e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
-        const T e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+        T e_hi, e_lo;
+        if (FASTBAR && sizeof(T) == 8 && c.fast_barrier) {
+          e_hi = t_exp_bounded(c.ctrl_q2 * (u[a] - c.u_max[a]));
+          e_lo = c.ctrl_c[a] * t_rcp(e_hi);
+        } else {
+          e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
+          e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+        }
         T l = T(0);
         if constexpr (HASQR) {
 #pragma unroll
@@ -625,7 +638,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
   while (it < a.n_iters && it0 + it < a.max_total) {
-    w.backward(Xc, Uc, xT, ob, lamb, gK, gk);
+    w.template backward<true>(Xc, Uc, xT, ob, lamb, gK, gk);
 #ifdef I2LQR_STAMPS
     {
       auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
@@ -648,10 +661,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     }
 #endif
     it++;
-    if (cost_new < cost) {  // control/iterative_ilqr.py:74-80
+    const bool accepted = cost_new < cost;
+    if (accepted) {
       T* tp = Uc; Uc = Un; Un = tp;
       if constexpr (!INPLACE) { tp = Xc; Xc = Xn; Xn = tp; }
-      if (a.defer) w.restore_states(Xc, Uc);  // store the accepted candidate's states
+    }
+    // X must hold the states of each lane's CURRENT inputs: deferred mode owes them to the lanes
+    // that accepted, in-place mode to the lanes that rejected.  If any lane of the wavefront needs
+    // it, ALL of them re-roll and store (the others rewrite what is already there, bit for bit):
+    // full 64-lane rows instead of masked partial ones, which cost a read-modify-write in HBM.
+    if (INPLACE && __any(a.defer ? accepted : !accepted)) w.restore_states(Xc, Uc);
+    if (accepted) {  // control/iterative_ilqr.py:74-80
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
@@ -662,7 +682,6 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
         if (status == 0) status = 1;
       }
     } else {  // control/iterative_ilqr.py:81-84
-      if (INPLACE && !a.defer) w.restore_states(Xc, Uc);
       lamb *= c.lamb_factor;
       cost_ret = cost;
       if (lamb > c.max_lamb) {

@@ -107,6 +107,29 @@ template <> __device__ __forceinline__ double t_exp<double>(double x0) {
   const double e = __builtin_ldexp(p, (int)kf);
   return x0 < -745.14 ? 0.0 : (x0 > 709.79 ? __builtin_inf() : e);
 }
+// The same without the range handling, for arguments known to lie in [-700, 700].
+template <class T> __device__ __forceinline__ T t_exp_bounded(T x);
+template <> __device__ __forceinline__ double t_exp_bounded<double>(double x) {
+  const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;
+  p = __builtin_fma(p, r, 2.0876756987868098979e-09);
+  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
+  p = __builtin_fma(p, r, 2.7557319223985892511e-06);
+  p = __builtin_fma(p, r, 2.4801587301587301566e-05);
+  p = __builtin_fma(p, r, 1.9841269841269841253e-04);
+  p = __builtin_fma(p, r, 1.3888888888888889419e-03);
+  p = __builtin_fma(p, r, 8.3333333333333332177e-03);
+  p = __builtin_fma(p, r, 4.1666666666666664354e-02);
+  p = __builtin_fma(p, r, 1.6666666666666665741e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+template <> __device__ __forceinline__ float t_exp_bounded<float>(float x) { return __expf(x); }
 // fp32 exp: the hardware exp2 path (v_exp_f32), ~2 ulp
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
 template <class T> __device__ __forceinline__ T t_sqrt(T x);

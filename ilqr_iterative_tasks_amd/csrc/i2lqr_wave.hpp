@@ -27,10 +27,12 @@ enum : int { FLAG_HAS_Q = 1, FLAG_HAS_R = 2 };
 // Device copy of i2lqr_config, typed and sized for one system; passed by value as a kernel
 // argument (kernarg segment: uniform, served by the scalar cache).
 template <class T, int n, int m> struct DevCfg {
-  int N, max_iter, flags, pad_;
+  int N, max_iter, flags;
+  int fast_barrier;  // host: |2 ctrl_q2 u_max[a]| < 600 for every input (see LaneWorker::backward)
   T dt, eps, lamb_factor, max_lamb;
   T ctrl_q1, ctrl_q2, obs_q1, obs_q2, safety_margin;
   T u_max[m];
+  T ctrl_c[m];  // exp(-2 ctrl_q2 u_max[a]), rounded from the host's double
   T xtarget[n];
   T Q[n * n], Qt[n * n], R[m * m];
   T sys_par[8];
