@@ -87,6 +87,7 @@ struct i2lqr_handle {
   int64_t compact_min_batch;  // > 0: i2lqr_solve uses the chunked, compacting form from this batch
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
   int opt_defer, opt_reroll, opt_lds_steps;
+  int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
 };
 
 namespace {
@@ -97,6 +98,11 @@ template <class T, class Sys> struct Launch {
   using Cfg = DevCfg<T, n, m>;
 
   static size_t lds_bytes(int N) { return (size_t)Layout<Sys>(N).total * sizeof(T) * (64 / LANES); }
+  static size_t fstep_lds_bytes(int N) {
+    return (size_t)Layout<Sys>(N, true).total * sizeof(T) * (64 / LANES);
+  }
+  static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
+  static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
   static int prepare(i2lqr_handle* h) {
@@ -149,6 +155,25 @@ template <class T, class Sys> struct Launch {
 #ifdef I2LQR_STAMPS
     a.dbg = (unsigned long long*)h->ws;  // diagnostic build: caller registers [B][8] u64 here
 #endif
+    // Per-step F matrices (prep() writes them in parallel over t; the serial recursion then has no
+    // Jacobian refresh) double the LDS slice: taken when every wavefront of the launch still fits
+    // on the chip at once, i.e. in the latency-bound regime this variant exists for.
+    const size_t lds_f = fstep_lds_bytes(h->cfg.N);
+    const int64_t waves_per_cu = (grid(B) + kCUs - 1) / kCUs;
+    const bool fstep = kHasFstep && lds_f <= 64 * 1024 &&
+                       (h->opt_fstep >= 0 ? h->opt_fstep != 0 : waves_per_cu * lds_f <= 150 * 1024);
+    if constexpr (kHasFstep) {
+      if (fstep) {
+        if (c.flags)
+          hipLaunchKernelGGL((k_iterate<T, Sys, LANES, true, true>), dim3(grid(B)), dim3(64), lds_f,
+                             s, c, a);
+        else
+          hipLaunchKernelGGL((k_iterate<T, Sys, LANES, false, true>), dim3(grid(B)), dim3(64), lds_f,
+                             s, c, a);
+        HIP_TRY(hipGetLastError());
+        return I2LQR_OK;
+      }
+    }
     if (c.flags)
       hipLaunchKernelGGL((k_iterate<T, Sys, LANES, true>), dim3(grid(B)), dim3(64), h->lds_bytes, s,
                          c, a);
@@ -670,7 +695,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->compact_min_batch = 0;
-  h->opt_defer = h->opt_reroll = h->opt_lds_steps = -1;
+  h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
   if (rc != I2LQR_OK) {
@@ -722,6 +747,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "defer_states")) h->opt_defer = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "reroll_nominal")) h->opt_reroll = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
+  else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else return fail(I2LQR_ERR_INVALID, "unknown option '%s'", name);
   return I2LQR_OK;
 }

@@ -111,8 +111,10 @@ template <class T> __device__ __forceinline__ T clip(T v, T lo, T hi) {
 template <class Sys> struct Layout {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
   int N;
-  int X0, X1, U0, U1, Kk, trg, lu, luu, ob, Va, F, T1, H, g, Qt, total;
-  __host__ __device__ explicit Layout(int N_) : N(N_) {
+  int X0, X1, U0, U1, Kk, trg, lu, luu, ob, Va, F, T1, H, g, Qt, Fs, total;
+  // fstep: one F = [A | B] per horizon step (written by prep(), parallel over t) instead of one
+  // matrix refreshed inside the serial backward recursion
+  __host__ __device__ explicit Layout(int N_, bool fstep = false) : N(N_) {
     int o = 0;
     X0 = o; o += n * (N + 1);
     X1 = o; o += n * (N + 1);
@@ -129,6 +131,7 @@ template <class Sys> struct Layout {
     H = o; o += W * W;
     g = o; o += W;
     Qt = o; o += n * n;
+    Fs = o; o += fstep ? n * W * N : 0;
     total = (o + 1) & ~1;  // keep every problem slice 16-byte aligned for fp64
   }
 };
@@ -136,7 +139,7 @@ template <class Sys> struct Layout {
 // ---------------------------------------------------------------------------------------------
 // The per-problem worker.  All LANES lanes of a problem execute every method together.
 // ---------------------------------------------------------------------------------------------
-template <class T, class Sys, int LANES, bool HASQR> struct Worker {
+template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct Worker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
   using Cfg = DevCfg<T, n, m>;
   const Cfg& c;
@@ -149,7 +152,8 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
 #endif
 
   __device__ Worker(const Cfg& c_, T* smem, int lane)
-      : c(c_), L(c_.N), S(smem + (lane / LANES) * Layout<Sys>(c_.N).total), sl(lane % LANES),
+      : c(c_), L(c_.N, FSTEP), S(smem + (lane / LANES) * Layout<Sys>(c_.N, FSTEP).total),
+        sl(lane % LANES),
         N(c_.N) {}
 
   // d^T M d with NumPy's association (d.T @ M) @ d: control/iterative_ilqr.py:43-48, :151-159
@@ -189,6 +193,12 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
   // once per kernel: constants that live in LDS
   __device__ __forceinline__ void stage_consts() const {
     for (int e = sl; e < n * n; e += LANES) S[L.Qt + e] = c.Qt[e];
+    if constexpr (FSTEP) {  // constant pattern of every step's F; prep() fills in the varying entries
+      for (int e = sl; e < n * W * N; e += LANES) {
+        const int r = e % (n * W);
+        S[L.Fs + e] = Sys::jac_const(c, r / W, r % W);
+      }
+    }
   }
 
   // -- HBM <-> LDS ---------------------------------------------------------------------------
@@ -283,12 +293,22 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
 #pragma unroll
         for (int i = 0; i < n; i++) xe[i] = S[Xo + (t + 1) * n + i];
         Sys::trig(xe, tr);
-#pragma unroll
-        for (int q = 0; q < NT; q++) S[L.trg + t * NT + q] = tr[q];
-        // add_control_constraint(): control/ilqr_helper.py:83-103, one symmetric box per input
         T u[m];
 #pragma unroll
         for (int a = 0; a < m; a++) u[a] = S[Uo + t * m + a];
+        if constexpr (FSTEP) {
+          // state-dependent entries of F_t = [A | B] at (x_{t+1}, u_t): control/iterative_ilqr.py:92-99
+          T jv[Sys::NVAR];
+          Sys::jac_var(c, xe, u, tr, jv);
+          static_for_i<0, Sys::NVAR>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            S[L.Fs + t * (n * W) + Sys::var_idx_c(q)] = jv[q];
+          });
+        } else {
+#pragma unroll
+          for (int q = 0; q < NT; q++) S[L.trg + t * NT + q] = tr[q];
+        }
+        // add_control_constraint(): control/ilqr_helper.py:83-103, one symmetric box per input
 #pragma unroll
         for (int a = 0; a < m; a++) {
           const T e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
@@ -522,7 +542,10 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
     constexpr int P1P = (P1N + LANES - 1) / LANES, P2P = (P2N + LANES - 1) / LANES,
                   P4P = (P4N + LANES - 1) / LANES, GP = (W + LANES - 1) / LANES;
     // constant pattern of F = [A | B]; the state-dependent entries are refreshed every step
-    for (int e = sl; e < n * W; e += LANES) S[L.F + e] = Sys::jac_const(c, e / W, e % W);
+    if constexpr (!FSTEP)
+      for (int e = sl; e < n * W; e += LANES) S[L.F + e] = Sys::jac_const(c, e / W, e % W);
+    constexpr int FW = n * W;                       // words of one F
+    const int Fbase = FSTEP ? L.Fs : L.F;           // step t's F sits at Fbase + (FSTEP ? t FW : 0)
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150
     for (int e = sl; e < P4N; e += LANES) {
       const int i = e / NA, j = e - i * NA;
@@ -549,7 +572,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       const int e0 = sl + r * LANES;
       p1_on[r] = e0 < P1N;
       const int e = p1_on[r] ? e0 : 0, a = e / NA, j = e - a * NA;
-      p1_f[r] = L.F + a;
+      p1_f[r] = Fbase + a;
       p1_v[r] = L.Va + j;
     }
     // P2: H[a][b] = lconst + [extra term] + T1[a][:] . F[:, b]
@@ -562,7 +585,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       const int e = e0 < P2N ? e0 : 0, a = e / W, b = e - a * W;
       p2_on[r] = e0 < P2N && !(a < n && b >= n);  // Qxu is never used by the reference
       p2_t[r] = L.T1 + a * NA;
-      p2_f[r] = L.F + b;
+      p2_f[r] = Fbase + b;
       // optional term: obstacle block (a, b < 2; control/ilqr_helper.py:51) or the input barrier
       // on the diagonal of l_uu (:28)
       p2_xon[r] = (a < 2 && b < 2) || (a >= n && a == b);
@@ -626,18 +649,21 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
       }
     };
     wave_sync();  // F's constant pattern is in place before the first refresh writes into it
-    refresh_load(N - 1);
-    refresh_store();
-    wave_sync();
+    if constexpr (!FSTEP) {
+      refresh_load(N - 1);
+      refresh_store();
+      wave_sync();
+    }
 
     for (int t = N - 1; t >= 0; t--) {
       STAMP_BEGIN();
       // P1: T1 = F^T [Vxx | Vx]   ((n+m) x (n+1)); f.T @ V of control/iterative_ilqr.py:112-116
+      const int fo = FSTEP ? t * FW : 0;
 #pragma unroll
       for (int r = 0; r < P1P; r++) {
         T acc = T(0);
 #pragma unroll
-        for (int i = 0; i < n; i++) acc = t_fma(S[p1_f[r] + i * W], S[p1_v[r] + i * NA], acc);
+        for (int i = 0; i < n; i++) acc = t_fma(S[p1_f[r] + fo + i * W], S[p1_v[r] + i * NA], acc);
         if (p1_on[r]) S[L.T1 + sl + r * LANES] = acc;
       }
       wave_sync();
@@ -656,7 +682,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
         const T extra = S[p2_x[r] + t * p2_xs[r]];
         T acc = T(0);
 #pragma unroll
-        for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + i * W], acc);
+        for (int i = 0; i < n; i++) acc = t_fma(S[p2_t[r] + i], S[p2_f[r] + fo + i * W], acc);
         h_val[r] = (p2_const[r] + (p2_xon[r] ? extra : T(0))) + acc;
       }
 #pragma unroll
@@ -696,7 +722,7 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
         }
         Qv[r] = S[p4_q[r]];
       }
-      refresh_load(t > 0 ? t - 1 : 0);  // reads of the next step's Jacobian refresh
+      if constexpr (!FSTEP) refresh_load(t > 0 ? t - 1 : 0);  // reads of the next step's refresh
       quu_inverse(Quu, lamb, Qinv);
       STAMP_END(3);
 #pragma unroll
@@ -729,7 +755,8 @@ template <class T, class Sys, int LANES, bool HASQR> struct Worker {
         if (p4_on[r]) S[L.Va + e] = Qv[r] - acc;
       }
       STAMP_END(4);
-      refresh_store();  // (at t == 0 this rewrites step 0's entries: harmless, F is not read again)
+      // (at t == 0 the refresh rewrites step 0's entries: harmless, F is not read again)
+      if constexpr (!FSTEP) refresh_store();
       wave_sync();
       STAMP_END(5);
     }
@@ -787,7 +814,7 @@ template <class T> __device__ __forceinline__ bool t_isfinite(T v) {
   return (v - v) == T(0);
 }
 
-template <class T, class Sys, int LANES, bool HASQR>
+template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false>
 __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> c,
                                                 const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
@@ -795,7 +822,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
   if (prob >= a.B) return;
-  Worker<T, Sys, LANES, HASQR> w(c, reinterpret_cast<T*>(smem_raw), lane);
+  Worker<T, Sys, LANES, HASQR, FSTEP> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   const auto& L = w.L;
   T* S = w.S;

@@ -144,10 +144,10 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
 
 /*
- * Scheduling options of the one-problem-per-lane kernels (batch-minor / batch-tiled layouts).
- * They change how the work is laid out on the GPU, never the results (bit-identical; tests/).
+ * Scheduling options of the kernels.  They change how the work is laid out on the GPU, never the results (bit-identical; tests/).
  * value -1 restores the automatic choice.  No reference counterpart (the NumPy path has no such
  * degrees of freedom); they exist so that A/B measurements run in one process on one device.
+ * One problem per lane (batch-minor / batch-tiled layouts):
  *   "defer_states"    1: the forward pass (control/iterative_ilqr.py:133-160) stores only the
  *                     candidate inputs; the states of an ACCEPTED step are re-rolled from them
  *                     (rejected steps cost no state traffic at all).  0: candidate states are
@@ -158,6 +158,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the
  *                     backward and the forward pass (automatic: what fits next to four
  *                     wavefronts per CU).
+ * One problem per wavefront (problem-major layout), i2lqr_iterate / i2lqr_solve:
+ *   "per_step_jacobians"  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
+ *                     30-52) are written to LDS by the parallel per-step phase, so the serial
+ *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.
+ *                     Automatic: on while every wavefront of the launch fits on the chip at once
+ *                     (n <= 6 systems).
  */
 int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 

@@ -314,6 +314,25 @@ def test_tiled_layout_is_bit_identical_to_batch_minor(torch_mod, dtype):
         s_t.alloc(100)
 
 
+@pytest.mark.parametrize("system,N,dt", [("bicycle6", 20, 0.25), ("bicycle4", 50, 1.0)])
+def test_per_step_jacobians_option_is_bit_identical(torch_mod, system, N, dt):
+    """One-problem-per-wavefront kernel: with "per_step_jacobians" the [A | B] matrices come from
+    the parallel per-step phase instead of the refresh inside the serial recursion — same
+    arithmetic, so iterate() and solve() must agree bit for bit with the option forced off."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = make_solver(system, N, dt=dt, layout="wave")
+    host = workloads.make_batch(cfg, 512)
+    out = {}
+    for flag in (0, 1, -1):
+        solver.set_option("per_step_jacobians", flag)
+        out[flag] = (solver.iterate(dev_batch(solver, host), 6), solver.solve(dev_batch(solver, host)))
+    for flag in (1, -1):
+        for got, want in zip(out[flag], out[0]):
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(got[key], want[key]), (key, flag)
+
+
 @pytest.mark.parametrize("lay,dtype", [("lane", "f64"), ("tiled", "f64"), ("tiled", "f32")])
 def test_lane_scheduling_options_do_not_change_results(torch_mod, lay, dtype):
     """i2lqr_set_option: deferred state stores, nominal re-roll and the number of LDS-resident gain
