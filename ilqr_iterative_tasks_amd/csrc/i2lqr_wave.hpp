@@ -100,8 +100,16 @@ template <class T, int L> __device__ __forceinline__ T pick(const T (&a)[L], int
   return v;
 }
 
-template <class T> __device__ __forceinline__ T clip(T v, T lo, T hi) {
-  return v < lo ? lo : (v > hi ? hi : v);
+// np.clip(v, lo, hi) = min(max(v, lo), hi) with NaN passing through (utils: iterative_ilqr.py:36,
+// :145).  v_max / v_min + a NaN select: 5 instructions in fp64 against 12 for two compare-selects.
+template <class T> __device__ __forceinline__ T clip(T v, T lo, T hi);
+template <> __device__ __forceinline__ double clip<double>(double v, double lo, double hi) {
+  const double r = __builtin_fmin(__builtin_fmax(v, lo), hi);
+  return v != v ? v : r;
+}
+template <> __device__ __forceinline__ float clip<float>(float v, float lo, float hi) {
+  const float r = __builtin_fminf(__builtin_fmaxf(v, lo), hi);
+  return v != v ? v : r;
 }
 
 // LDS layout of one problem, in words of T.  Trajectories and gains are TIME-major in LDS
