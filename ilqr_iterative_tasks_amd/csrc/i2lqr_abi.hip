@@ -264,7 +264,6 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a, Carved* cv = nullptr) {
     const int N = h->cfg.N;
     T* p = (T*)h->ws;
-    a.wsX = p; p += B * (int64_t)(n * (N + 1));
     a.wsU = p; p += B * (int64_t)(m * N);
     a.wsK = p; p += B * (int64_t)(m * n * N);
     a.wsk = p; p += B * (int64_t)(m * N);

@@ -37,8 +37,8 @@ template <class T> struct LaneArgs {
   int n_iters, early_exit;
   T* X; T* U; const T* x_term; T* lamb; const T* obs; T* cost; T* K; T* k;
   int32_t* iters; int32_t* status;
-  // workspace (batch-minor): candidate trajectory, gains if K == null
-  T* wsX; T* wsU; T* wsK; T* wsk;
+  // workspace (batch-minor): candidate inputs, gains if K == null
+  T* wsU; T* wsK; T* wsk;
   // chunked solve (solve_compacting): the live batch size is read from device memory, the
   // iteration counter continues from iters[b], and a problem that is still running when the
   // chunk ends gets status RUNNING unless it has reached max_total iterations
@@ -53,7 +53,7 @@ template <class T> struct LaneArgs {
 // words of T the workspace needs for B problems
 template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int N, int64_t B) {
   constexpr int n = Sys::n, m = Sys::m;
-  return B * (int64_t)(n * (N + 1) + m * N + m * n * N + m * N);
+  return B * (int64_t)(m * N + m * n * N + m * N);
 }
 
 // Batch-minor ("rows of B") vs batch-tiled ("tiles of 64 problems, rows of 64") addressing.  In
@@ -616,29 +616,25 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   T lamb = a.lamb[b];
   T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
   T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
-  // States live in ONE buffer (the caller's X): the forward pass writes the candidate states over
-  // the nominal ones in place (each x_t is loaded one step ahead of being overwritten) and a
-  // rejected step re-rolls the nominal states from the nominal inputs (bit-identical); only the
-  // inputs (m N words) are double-buffered per lane.  With X double-buffered per lane, divergent
-  // accept/reject decisions split every row access of a wavefront over two buffers: +38 % HBM
-  // traffic per iteration (rocprofv3 FETCH_SIZE / WRITE_SIZE, tools/pmc_iters.sh).  In place,
-  // measured on the same device (tools/ab_bench.py): fp64 +7..17 % iterations/s; fp32 +9..12 %
-  // once sin/cos are the short in-line versions (with the library sincosf the re-roll cost more
-  // than the traffic it saved).  The double-buffered form stays selectable for A/B runs.
-  constexpr bool INPLACE = true;
-  T* const X0 = v.rebase(a.X, n * (N + 1));
+  // States live in ONE buffer (the caller's X); only the inputs (m N words) are double-buffered
+  // per lane.  With X double-buffered per lane too, divergent accept/reject decisions split every
+  // row access of a wavefront over two buffers: +38 % HBM traffic per iteration (rocprofv3
+  // FETCH_SIZE / WRITE_SIZE, tools/pmc_iters.sh).  Either the forward pass stores no states and
+  // accepted steps re-roll them (a.defer), or it writes the candidate states over the nominal
+  // ones in place (each x_t is loaded one step ahead of being overwritten) and rejected steps
+  // re-roll the nominal ones; both re-rolls are bit-identical to what the rollout stored.
+  T* const X = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
-  T *Xc = X0, *Uc = U0;
-  T *Xn = INPLACE ? X0 : v.rebase(a.wsX, n * (N + 1)), *Un = v.rebase(a.wsU, m * N);
+  T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
-  T cost = w.rollout(Xc, Uc, xT);
+  T cost = w.rollout(X, Uc, xT);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
   while (it < a.n_iters && it0 + it < a.max_total) {
-    w.template backward<true>(Xc, Uc, xT, ob, lamb, gK, gk);
+    w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
 #ifdef I2LQR_STAMPS
     {
       auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
@@ -647,12 +643,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 #endif
     T cost_new;
     if (a.defer) {
-      cost_new = a.reroll ? w.template forward<true, false>(Xc, Uc, gK, gk, Xn, Un, xT)
-                          : w.template forward<false, false>(Xc, Uc, gK, gk, Xn, Un, xT);
+      cost_new = a.reroll ? w.template forward<true, false>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false, false>(X, Uc, gK, gk, X, Un, xT);
     } else {
-      cost_new = (INPLACE && a.reroll)
-                     ? w.template forward<true>(Xc, Uc, gK, gk, Xn, Un, xT)
-                     : w.template forward<false>(Xc, Uc, gK, gk, Xn, Un, xT);
+      cost_new = a.reroll ? w.template forward<true>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false>(X, Uc, gK, gk, X, Un, xT);
     }
 #ifdef I2LQR_STAMPS
     {
@@ -664,19 +659,18 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     const bool accepted = cost_new < cost;
     if (accepted) {
       T* tp = Uc; Uc = Un; Un = tp;
-      if constexpr (!INPLACE) { tp = Xc; Xc = Xn; Xn = tp; }
     }
     // X must hold the states of each lane's CURRENT inputs: deferred mode owes them to the lanes
     // that accepted, in-place mode to the lanes that rejected.  If any lane of the wavefront needs
     // it, ALL of them re-roll and store (the others rewrite what is already there, bit for bit):
     // full 64-lane rows instead of masked partial ones, which cost a read-modify-write in HBM.
-    if (INPLACE && __any(a.defer ? accepted : !accepted)) w.restore_states(Xc, Uc);
+    if (__any(a.defer ? accepted : !accepted)) w.restore_states(X, Uc);
     if (accepted) {  // control/iterative_ilqr.py:74-80
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
       // next iteration's nominal cost: stage terms are measured to xtarget, not x_terminal
-      cost = HASQR ? w.nominal_cost(Xc, Uc, xT) : cost_new;
+      cost = HASQR ? w.nominal_cost(X, Uc, xT) : cost_new;
       if (conv) {
         if (a.early_exit) { status = 1; break; }
         if (status == 0) status = 1;
@@ -704,11 +698,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
 #endif
   w.flush_gains(gK, gk);
-  if (Xc != X0) {  // the accepted states sit in the workspace: copy them out
-    for (int e = 0; e < n * (N + 1); e++)
-      X0[(int64_t)e * v.Bs + v.bl] = Xc[(int64_t)e * v.Bs + v.bl];
-  }
-  if (Uc != U0) {  // likewise the inputs
+  if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
     for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
   }
   a.lamb[b] = lamb;
