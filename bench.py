@@ -160,12 +160,14 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                         "tiled": "batch-tiled x64 (one problem per lane)"}[layout])
 
 
-def run_solve(args, cfg, B, torch, reps=3):
+def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
     layout = pick_layout(args, B, "f64" if cfg.dtype == 0 else "f32")
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
+    if single_launch:
+        solver.set_compaction(0)
     host = workloads.make_batch(cfg, B)
     sets = make_step_buffers(solver, host, reps + 1, torch)
     solver.solve(sets[0])
@@ -182,7 +184,9 @@ def run_solve(args, cfg, B, torch, reps=3):
     solver.close()
     return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
             "iterations_mean": executed / B, "iterations_max": int(it.max()),
-            "kernel": "k_iterate" if layout == "wave" else "k_lane_iterate"}
+            "kernel": "k_iterate" if layout == "wave" else (
+                "k_lane_iterate" if single_launch else
+                "k_lane_iterate chunks + k_lane_compact + k_iterate tail")}
 
 
 def load_traffic(key):
@@ -308,9 +312,12 @@ def main():
                            "traffic": load_traffic(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
-        # problem is done, so this is below the fixed-count rate
+        # problem is done, so this is below the fixed-count rate.  Default = chunked solve with
+        # compaction and the one-problem-per-wavefront tail; single launch beside it.
         extra["solve_to_termination_B65536_f64"] = run_solve(args, workloads.config_for(
             args.workload, "f64"), 65536, torch)
+        extra["solve_to_termination_B65536_f64_single_launch"] = run_solve(
+            args, workloads.config_for(args.workload, "f64"), 65536, torch, single_launch=True)
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))

@@ -600,6 +600,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
+  if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
   const int N = c.N;
   const LaneView<TILED> v(a.B);
   LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneS
     for (int r = 0; r < 6; r++) dst.obs[(int64_t)r * dst.B + j] = src.obs[saddr(6, r, i)];
   dst.lamb[j] = src.lamb[i];
   dst.iters[j] = src.iters[i];
+  dst.status[j] = 0;  // RUNNING (a tail launch of the one-problem-per-wavefront kernel may finish it)
   dst.orig[j] = src_is_user ? (int32_t)i : src.orig[i];
 }
 

@@ -53,6 +53,13 @@ template <class T> struct IterArgs {
   int32_t* iters;  // [B] out or null
   int32_t* status; // [B] out or null
   unsigned long long* dbg;  // diagnostic builds only: [B][8] phase cycle sums; null otherwise
+  // SETIO kernels (tail of the chunked solve of the one-problem-per-lane layouts): the problems are
+  // columns 0..*count-1 of a batch-minor, time-major work set with row stride `set_stride`
+  // (i2lqr_lane.hpp); the launch does nothing unless *count <= count_max; the iteration counter
+  // continues from iters[] and stops at max_total.
+  const int32_t* count;
+  int count_max, max_total;
+  int64_t set_stride;
 };
 
 // Diagnostic build only (-DI2LQR_STAMPS, tools/stamp_build.sh): per-phase cycle shares of one
@@ -822,30 +829,49 @@ template <class T> __device__ __forceinline__ bool t_isfinite(T v) {
   return (v - v) == T(0);
 }
 
-template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false>
+template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false, bool SETIO = false>
 __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> c,
                                                 const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int64_t prob = (int64_t)blockIdx.x * (64 / LANES) + lane / LANES;
-  if (prob >= a.B) return;
+  if constexpr (SETIO) {
+    const int64_t live = *a.count;
+    if (live > a.count_max || prob >= live) return;
+  } else {
+    if (prob >= a.B) return;
+  }
   Worker<T, Sys, LANES, HASQR, FSTEP> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   const auto& L = w.L;
   T* S = w.S;
+  const int64_t Bs = SETIO ? a.set_stride : 0;
 
-  // entry: x0, U, x_term, lamb, obs  (HBM -> LDS/registers, coalesced along the record)
-  const T* gX = a.X + prob * (int64_t)(n * (N + 1));
-  if (w.sl < n) S[L.X0 + w.sl] = gX[w.sl * (N + 1)];
-  w.load_rec(a.U + prob * (int64_t)(m * N), L.U0, m, N);
-  w.stage_consts();
+  // entry: x0, U, x_term, lamb, obs  (HBM -> LDS/registers)
   T xT[n], ob[6];
+  if constexpr (SETIO) {
+    // a column of the work set: row e of X / U is exactly word e of the time-major LDS copy
+    if (w.sl < n) S[L.X0 + w.sl] = a.X[w.sl * Bs + prob];
+    for (int e = w.sl; e < m * N; e += LANES) S[L.U0 + e] = a.U[e * Bs + prob];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+    for (int i = 0; i < n; i++) xT[i] = a.x_term[i * Bs + prob];
 #pragma unroll
-  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+    for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[q * Bs + prob] : T(q == 5 ? -1 : 1);
+  } else {
+    // problem-major records, coalesced along the record
+    const T* gX = a.X + prob * (int64_t)(n * (N + 1));
+    if (w.sl < n) S[L.X0 + w.sl] = gX[w.sl * (N + 1)];
+    w.load_rec(a.U + prob * (int64_t)(m * N), L.U0, m, N);
+#pragma unroll
+    for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+#pragma unroll
+    for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  }
+  w.stage_consts();
   T lamb = a.lamb[prob];
+  const int it0 = SETIO ? a.iters[prob] : 0;             // iterations of the earlier chunks
+  const int it_cap = SETIO ? a.max_total - it0 : a.n_iters;
   wave_sync();
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
@@ -854,7 +880,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   T cost = w.rollout(L.X0, L.U0, xT);
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
   T cost_ret = cost;
-  while (it < a.n_iters) {
+  while (it < it_cap) {
     const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
     const int Xn = cur ? L.X0 : L.X1, Un = cur ? L.U0 : L.U1;
 #ifdef I2LQR_STAMPS
@@ -903,13 +929,25 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
 
   // exit: X, U, gains, scalars (LDS -> HBM)
   const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
-  w.store_rec(a.X + prob * (int64_t)(n * (N + 1)), Xo, n, N + 1);
-  w.store_rec(a.U + prob * (int64_t)(m * N), Uo, m, N);
-  if (a.K) w.store_gains(a.K + prob * (int64_t)(m * n * N), a.k + prob * (int64_t)(m * N));
+  if constexpr (SETIO) {
+    for (int e = w.sl; e < n * (N + 1); e += LANES) a.X[e * Bs + prob] = S[Xo + e];
+    for (int e = w.sl; e < m * N; e += LANES) a.U[e * Bs + prob] = S[Uo + e];
+    if (a.K) {  // K rows (t m + a) n + j, k rows t m + a  <-  LDS Kk[t][m][n+1]
+      for (int e = w.sl; e < m * N * (n + 1); e += LANES) {
+        const int r = e / (n + 1), j = e - r * (n + 1);
+        if (j < n) a.K[((int64_t)r * n + j) * Bs + prob] = S[L.Kk + e];
+        else a.k[(int64_t)r * Bs + prob] = S[L.Kk + e];
+      }
+    }
+  } else {
+    w.store_rec(a.X + prob * (int64_t)(n * (N + 1)), Xo, n, N + 1);
+    w.store_rec(a.U + prob * (int64_t)(m * N), Uo, m, N);
+    if (a.K) w.store_gains(a.K + prob * (int64_t)(m * n * N), a.k + prob * (int64_t)(m * N));
+  }
   if (w.sl == 0) {
     a.lamb[prob] = lamb;
     a.cost[prob] = cost_ret;
-    if (a.iters) a.iters[prob] = it;
+    if (a.iters) a.iters[prob] = it0 + it;
     if (a.status) a.status[prob] = status;
   }
 }

@@ -134,12 +134,17 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B);
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
- * Opt-in chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
+ * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
  * problems the solve runs in chunks of 2, 2, 4, 8, ... iterations and packs the still-running
- * problems into dense work sets between chunks (no host synchronisation; results bit-identical
- * to the single launch).  min_batch <= 0 (default) disables it.  Measured on MI355X at n=6, N=20:
- * no gain up to 2^20 problems — the single launch is HBM-bound and its cost already scales with
- * the lanes that are still running — so it stays off by default.
+ * problems into dense work sets between chunks (no host synchronisation); once few problems are
+ * left ("wave_tail" option below) they are finished by the one-problem-per-wavefront kernel.
+ * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
+ * large solve is bound by the slowest problem's iteration latency.
+ *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
+ *   from 4096 problems when max_iter > 16).
+ * Measured on MI355X, n=6, N=20, 65536 problems, fp64: 6.8 ms single launch, 7.4 ms chunked
+ * without the tail kernel, 3.6 ms with it.  The chunks alone are bit-identical to the single
+ * launch; with the tail kernel the outputs agree to the solve tolerance (1e-8 rel).
  */
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
 
@@ -158,6 +163,11 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the
  *                     backward and the forward pass (automatic: what fits next to four
  *                     wavefronts per CU).
+ *   "wave_tail"       chunked solve (i2lqr_set_compaction) only: once a compaction leaves at most
+ *                     this many running problems (<= 8192), they are finished by the one-problem-
+ *                     per-wavefront kernel, whose iteration latency is ~2.8x lower.  Same
+ *                     algorithm, different summation order: results agree with the single launch
+ *                     to the solve tolerance (1e-8), not bit for bit.  0: off; automatic: 2048.
  * One problem per wavefront (problem-major layout), i2lqr_iterate / i2lqr_solve:
  *   "per_step_jacobians"  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
  *                     30-52) are written to LDS by the parallel per-step phase, so the serial

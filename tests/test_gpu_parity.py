@@ -314,6 +314,37 @@ def test_tiled_layout_is_bit_identical_to_batch_minor(torch_mod, dtype):
         s_t.alloc(100)
 
 
+@pytest.mark.parametrize("lay,gains", [("lane", True), ("tiled", False)])
+def test_chunked_solve_with_wave_tail_matches_oracle_and_plain(torch_mod, lay, gains):
+    """Chunked solve with the latency tail on the one-problem-per-wavefront kernel ("wave_tail"):
+    problems that survive the first chunks are finished by a different kernel (same algorithm,
+    different summation order), so the outputs are compared at the solve tolerance (1e-8) with the
+    oracle and with the plain single-launch solve, iteration counts and statuses exactly."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = make_solver("bicycle6", 20, "f64", dt=0.25, layout=lay)
+    B = 4096
+    host = workloads.make_batch(cfg, B)
+    host["lamb"] = 10.0 ** np.random.default_rng(3).integers(-3, 3, B).astype(float)
+    plain = solver.solve(dev_batch(solver, host, want_gains=gains))
+    solver.set_compaction(1024)
+    solver.set_option("wave_tail", 2048)
+    tail = solver.solve(dev_batch(solver, host, want_gains=gains))
+    it_p, it_t = plain["iters"].cpu().numpy(), tail["iters"].cpu().numpy()
+    assert it_t.max() > 16, "the workload must have a tail for this test to mean anything"
+    assert (it_p == it_t).all() and torch.equal(plain["status"], tail["status"])
+    for key in ("X", "U") + (("K", "k") if gains else ()):
+        a, b = to_host(solver, plain[key]), to_host(solver, tail[key])
+        floor = 1.0 if key == "k" else 1e-2
+        assert batch_rel_err(b, a, floor=floor) < (1e-6 if key in ("K", "k") else TOL_SOLVE), key
+    assert rel_err(tail["lamb"].cpu().numpy(), plain["lamb"].cpu().numpy()) == 0.0
+    want = oracle().ilqr_batch(cfg, host["X"][:512], host["U"][:512], host["x_term"][:512],
+                               host["lamb"][:512], host["obs"][:512])
+    assert (want["iters"] == it_t[:512]).all()
+    assert batch_rel_err(to_host(solver, tail["X"])[:512], want["X"]) < TOL_SOLVE
+    assert batch_rel_err(to_host(solver, tail["U"])[:512], want["U"], floor=1e-2) < TOL_SOLVE
+
+
 @pytest.mark.parametrize("system,N,dt", [("bicycle6", 20, 0.25), ("bicycle4", 50, 1.0)])
 def test_per_step_jacobians_option_is_bit_identical(torch_mod, system, N, dt):
     """One-problem-per-wavefront kernel: with "per_step_jacobians" the [A | B] matrices come from
@@ -375,6 +406,7 @@ def test_chunked_compacting_solve_is_bit_identical_to_plain(torch_mod, lay, dtyp
     solver, cfg = make_solver("bicycle6", 20, dtype, dt=0.25, layout=lay)
     B, sub = 8192, 2048
     solver.set_compaction(4096)
+    solver.set_option("wave_tail", 0)  # the tail kernel is tested separately (tolerance, not bits)
     host = workloads.make_batch(cfg, B)
     host["lamb"] = 10.0 ** np.random.default_rng(1).integers(-3, 3, B).astype(float)
     big = solver.solve(dev_batch(solver, host, want_gains=gains))

@@ -8,12 +8,18 @@ import torch
 
 from ilqr_iterative_tasks_amd import BatchedILQR, workloads
 
+# spec = layout:dtype:batch[:compaction_min_batch[:wave_tail]]
 for spec in sys.argv[1:]:
-    layout, dtype, B = spec.split(":")
+    parts = spec.split(":")
+    layout, dtype, B = parts[:3]
     B = int(B)
     cfg = workloads.config_for("config2", dtype)
     cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[layout]
     solver = BatchedILQR(cfg)
+    if len(parts) > 3:
+        solver.set_compaction(int(parts[3]))
+    if len(parts) > 4:
+        solver.set_option("wave_tail", int(parts[4]))
     host = workloads.make_batch(cfg, B)
     dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
     buf = solver.alloc(B, want_gains=False)
@@ -35,6 +41,6 @@ for spec in sys.argv[1:]:
         ts.append(e0.elapsed_time(e1))
     it = buf["iters"].double()
     ms = min(ts[1:])
-    print(f"{spec:22s} {ms:9.3f} ms  iterations mean {float(it.mean()):5.2f} max {int(it.max()):3d}  "
+    print(f"{spec:32s} {ms:9.3f} ms  iterations mean {float(it.mean()):5.2f} max {int(it.max()):3d}  "
           f"-> {float(it.sum()) / ms / 1e3:8.1f} M executed it/s, {B / ms / 1e3:7.2f} M problems/s")
     solver.close()
