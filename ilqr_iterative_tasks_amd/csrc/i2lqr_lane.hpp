@@ -224,7 +224,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   }
 
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
-  __device__ __forceinline__ void obstacle(const T (&ob)[6], T px, T py, int t, T (&o)[5]) const {
+  // pa, pb = 1 / width^2, 1 / height^2: the same for every horizon step, computed once by the caller
+  __device__ __forceinline__ void obstacle(const T (&ob)[6], T pa, T pb, T px, T py, int t,
+                                           T (&o)[5]) const {
 #pragma unroll
     for (int q = 0; q < 5; q++) o[q] = T(0);
     if (ob[5] >= T(0)) {
@@ -232,7 +234,6 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       T dz = px - ob[0], dy = py - ob[1];
       if (opt == 1) dy = py - (ob[1] + T(t) * ob[4]);
       if (opt == 2) dz = px - (ob[0] - T(t) * ob[4]);
-      const T pa = T(1) / (ob[2] * ob[2]), pb = T(1) / (ob[3] * ob[3]);
       const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
       const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
       const T e = t_exp(c.obs_q2 * h);
@@ -301,13 +302,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   template <bool FASTBAR = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk) const {
+    const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     T Va[n][n + 1];  // [Vxx | Vx]; with SYM only Va[i][j >= i] and the last column are live
     {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
 #pragma unroll
       for (int i = 0; i < n; i++) xN[i] = at(X, rx(i, N));
-      obstacle(ob, xN[0], xN[1], N, o);
+      obstacle(ob, ob_pa, ob_pb, xN[0], xN[1], N, o);
 #pragma unroll
       for (int i = 0; i < n; i++) {
         T vx = T(0);
@@ -337,7 +339,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       STAMP_BEGIN();
       Sys::trig(xe, tr);  // the same values the rollout used for the dynamics of step t+1
       Sys::jac_var(c, xe, u, tr, jv);
-      obstacle(ob, xp[0], xp[1], t, o);
+      obstacle(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
       // input barrier, add_control_constraint(): control/ilqr_helper.py:83-103
       //   l_u = q1 q2 (e_hi - e_lo),  l_uu = q1 q2^2 (e_hi + e_lo),
       //   e_hi = exp(q2 (u - u_max)),  e_lo = exp(q2 (-u_max - u)).

@@ -148,7 +148,12 @@ template <> __device__ __forceinline__ double t_rcp<double>(double x) {
   const double r2 = __builtin_fma(r, e, r);
   return (r2 == r2) ? r2 : r;  // x = 0 / inf: keep the seed's inf / 0 instead of the NaN of 0 * inf
 }
-template <> __device__ __forceinline__ float t_rcp<float>(float x) { return 1.0f / x; }
+template <> __device__ __forceinline__ float t_rcp<float>(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);  // 1 ulp seed, one Newton step
+  const float e = __builtin_fmaf(-x, r, 1.0f);
+  const float r2 = __builtin_fmaf(r, e, r);
+  return (r2 == r2) ? r2 : r;
+}
 template <class T> __device__ __forceinline__ T t_sqrt_fast(T x);
 template <> __device__ __forceinline__ double t_sqrt_fast<double>(double x) {
   if (!(x > 1.0e-290) || !(x < 1.0e290)) return __builtin_sqrt(x);  // 0, tiny, huge, NaN
