@@ -299,7 +299,7 @@ def main():
         # secondary single-GPU workloads (not the headline): large batches of the same problem
         extra = {}
         for name, eb, edt in (("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32"),
-                              ("B1048576_f64", 1 << 20, "f64")):
+                              ("B1048576_f64", 1 << 20, "f64"), ("B1048576_f32", 1 << 20, "f32")):
             ecfg = workloads.config_for(args.workload, edt)
             nst = 3 if eb > 100000 else 6
             r = run_gpu(args, ecfg, eb, 0, 1, torch, dist_mod, nst, 2, with_tail=False)
