@@ -880,6 +880,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   T cost = w.rollout(L.X0, L.U0, xT);
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
   T cost_ret = cost;
+  bool fresh = true;  // the nominal trajectory changed since the last prep()
   while (it < it_cap) {
     const int Xo = cur ? L.X1 : L.X0, Uo = cur ? L.U1 : L.U0;
     const int Xn = cur ? L.X0 : L.X1, Un = cur ? L.U0 : L.U1;
@@ -887,7 +888,8 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
     STAMP_DECL;
     STAMP_BEGIN();
 #endif
-    w.prep(Xo, Uo, ob);
+    // the per-step caches depend on the nominal trajectory only: still valid after a rejected step
+    if (fresh) w.prep(Xo, Uo, ob);
 #ifdef I2LQR_STAMPS
     STAMP_END(0);
 #endif
@@ -905,7 +907,8 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
 #endif
     it++;
     // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
-    if (cost_new < cost) {
+    fresh = cost_new < cost;
+    if (fresh) {
       cur ^= 1;
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
