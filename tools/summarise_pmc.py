@@ -47,5 +47,22 @@ for name, elem in (("wave_f64_B1024", 8), ("lane_f64_B65536", 8), ("tiled_f32_B6
     if rec:
         rec["hbm_bytes_per_launch"] = rec.get("FETCH_SIZE_bytes_corrected", 0) + \
             rec.get("WRITE_SIZE_bytes_corrected", 0)
+    # SQ pass: shares of the wavefronts' lifetime (all values per launch, summed over the chip)
+    sq = {}
+    for (kname, c), v in per_kernel(f"{out}/{name}_SQ/**/*counter_collection.csv").items():
+        if "iterate" in kname:
+            sq[c] = avg(v)
+    if sq.get("SQ_WAVE_CYCLES"):
+        wc = sq["SQ_WAVE_CYCLES"]
+        rec["sq"] = {k: v for k, v in sq.items()}
+        rec["sq_shares_of_wave_cycles"] = {
+            "issuing_any_instruction": sq.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+            "issuing_valu": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+            "parked_on_waitcnt_or_barrier": sq.get("SQ_WAIT_ANY", 0) / wc,
+            "issue_stalled": sq.get("SQ_WAIT_INST_ANY", 0) / wc}
+        if sq.get("SQ_INSTS_VALU") is not None:
+            tot = sq["SQ_INSTS_VALU"] + sq.get("SQ_INSTS_SALU", 0)
+            rec["valu_fraction_of_valu_plus_salu_instructions"] = sq["SQ_INSTS_VALU"] / max(tot, 1)
+    if rec:
         summary[name] = rec
 print(json.dumps(summary, indent=1))
