@@ -75,6 +75,9 @@ template <bool TILED> struct LaneView {
   }
 };
 
+#ifndef I2LQR_DEEP_PREFETCH
+#define I2LQR_DEEP_PREFETCH 1
+#endif
 #ifndef I2LQR_F64_WAVES
 #define I2LQR_F64_WAVES 1
 #endif
@@ -207,12 +210,18 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // trajectory after a rejected step, whose candidate was written over it in place.  Bit-identical
   // to what rollout() / an accepted forward() stored (same code, same inputs).
   __device__ __forceinline__ void restore_states(T* X, const T* U) const {
-    T x[n], u[m], xn[n], tr[NT];
+    T x[n], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
-    for (int t = 0; t < N; t++) {
+    // two input register sets take turns, each re-loaded for step t+2 right after step t read it
+    auto body = [&](const int t, T (&ul)[m]) __attribute__((always_inline)) {
+      T u[m];
 #pragma unroll
-      for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t));
+      for (int a = 0; a < m; a++) u[a] = ul[a];
+      if (t + 2 < N) {
+#pragma unroll
+        for (int a = 0; a < m; a++) ul[a] = at(U, ru(a, t + 2));
+      }
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
 #pragma unroll
@@ -220,7 +229,20 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         at(X, rx(i, t + 1)) = xn[i];
         x[i] = xn[i];
       }
+    };
+    T ua[m], ub[m];
+#pragma unroll
+    for (int a = 0; a < m; a++) ua[a] = at(U, ru(a, 0));
+    if (N >= 2) {
+#pragma unroll
+      for (int a = 0; a < m; a++) ub[a] = at(U, ru(a, 1));
     }
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      body(t, ua);
+      body(t + 1, ub);
+    }
+    if (t < N) body(t, ua);
   }
 
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
@@ -298,6 +320,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // what lets the unrolled step stay in registers.  Cost weights must be symmetric (checked in
   // i2lqr_create for these layouts).  The one-problem-per-wavefront kernels keep the full blocks.
   static constexpr bool SYM = true;
+  static constexpr bool DEEP = sizeof(T) == 4 && I2LQR_DEEP_PREFETCH;
 
   template <bool FASTBAR = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
@@ -327,6 +350,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     // entries, barrier terms); the loads of step t-1 are then issued into the same registers, so
     // the HBM latency hides under the Riccati arithmetic of step t.  X[:, t] is read ONCE: it is
     // x_t of step t (obstacle / stage terms) and the evaluation state x_{t+1} of step t-1.
+    // DEEP (fp32): two buffers take turns, each re-loaded for step t-2 right after step t has
+    // consumed it — twice the distance between a load and its use.  fp32 moves half the bytes of
+    // fp64 per step, so its steps are too short for a one-step distance under load (a wavefront
+    // alone on its SIMD cannot hide the rest); fp64 sits on the HBM roof either way.
+    constexpr int D = DEEP ? 2 : 1;  // prefetch distance in horizon steps
     T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t
 #pragma unroll
     for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
@@ -334,7 +362,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
 #pragma unroll
     for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
-    for (int t = N - 1; t >= 0; t--) {
+    auto body = [&](const int t, T (&xp)[n], T (&u)[m]) __attribute__((always_inline)) {
       T jv[NV], o[5], tr[NT];
       STAMP_BEGIN();
       Sys::trig(xe, tr);  // the same values the rollout used for the dynamics of step t+1
@@ -379,11 +407,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
 #pragma unroll
       for (int i = 0; i < n; i++) xe[i] = xp[i];
-      if (t > 0) {
+      if (t >= D) {
 #pragma unroll
-        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - 1));
+        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - D));
 #pragma unroll
-        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - 1));
+        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - D));
       }
 
       STAMP_END(0);
@@ -492,6 +520,23 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
       }
       STAMP_END(3);
+    };
+    if constexpr (DEEP) {
+      T xq[n], uq[m];  // the second buffer: x_{N-2}, u_{N-2}
+      if (N >= 2) {
+#pragma unroll
+        for (int i = 0; i < n; i++) xq[i] = at(X, rx(i, N - 2));
+#pragma unroll
+        for (int a = 0; a < m; a++) uq[a] = at(U, ru(a, N - 2));
+      }
+      int t = N - 1;
+      for (; t >= 1; t -= 2) {
+        body(t, xp, u);
+        body(t - 1, xq, uq);
+      }
+      if (t == 0) body(0, xp, u);
+    } else {
+      for (int t = N - 1; t >= 0; t--) body(t, xp, u);
     }
   }
 
@@ -515,47 +560,53 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     }
     T cost = T(0);
     // The nominal state / input / gains of a step are consumed at its very start (the feedback
-    // law); the loads for step t+1 are issued right after, into the same registers, so the HBM
-    // latency hides under the rest of the serial step.
-    auto load_step = [&](int t) {
+    // law); the loads for step t+D are issued right after, into the same registers, so the HBM
+    // latency hides under the rest of the serial step(s).  D = 2 with two register sets that take
+    // turns (DEEP, fp32), else 1.
+    constexpr int D = DEEP ? 2 : 1;
+    auto load_step = [&](int t, T (&xl)[n], T (&ul)[m], T (&kl)[m][n + 1])
+        __attribute__((always_inline)) {
       if constexpr (!REROLL) {
 #pragma unroll
-        for (int j = 0; j < n; j++) xo[j] = at(X, rx(j, t));
+        for (int j = 0; j < n; j++) xl[j] = at(X, rx(j, t));
       }
 #pragma unroll
-      for (int a = 0; a < m; a++) uo[a] = at(U, ru(a, t));
+      for (int a = 0; a < m; a++) ul[a] = at(U, ru(a, t));
       if (t < lds_steps) {
 #pragma unroll
         for (int a = 0; a < m; a++)
 #pragma unroll
-          for (int j = 0; j <= n; j++) kk[a][j] = lds_gain(t, a * (n + 1) + j);
+          for (int j = 0; j <= n; j++) kl[a][j] = lds_gain(t, a * (n + 1) + j);
       } else {
 #pragma unroll
         for (int a = 0; a < m; a++) {
 #pragma unroll
-          for (int j = 0; j < n; j++) kk[a][j] = at(gK, rK(a, j, t));
-          kk[a][n] = at(gk, ru(a, t));
+          for (int j = 0; j < n; j++) kl[a][j] = at(gK, rK(a, j, t));
+          kl[a][n] = at(gk, ru(a, t));
         }
       }
     };
-    load_step(0);
-    for (int t = 0; t < N; t++) {
+    // one horizon step on the register set (xl, ul, kl); with REROLL the nominal state is the
+    // loop-carried xo, otherwise it is the loaded xl
+    auto body = [&](const int t, T (&xl)[n], T (&ul)[m], T (&kl)[m][n + 1])
+        __attribute__((always_inline)) {
       T uon[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
-        u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
-        uon[a] = uo[a];
+        for (int j = 0; j < n; j++)
+          acc = t_fma(kl[a][j], x[j] - (REROLL ? xo[j] : xl[j]), acc);
+        u[a] = clip(ul[a] + kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        uon[a] = ul[a];
       }
-      if constexpr (REROLL) {  // nominal state of step t+1, before its registers are reloaded
+      if constexpr (REROLL) {  // nominal state of step t+1
         Sys::trig(xo, tr);
         Sys::step_tr(c, xo, uon, tr, xn);
 #pragma unroll
         for (int i = 0; i < n; i++) xo[i] = xn[i];
       }
-      if (t + 1 < N) load_step(t + 1);
+      if (t + D < N) load_step(t + D, xl, ul, kl);
 #pragma unroll
       for (int a = 0; a < m; a++) at(Un, ru(a, t)) = u[a];
       Sys::trig(x, tr);
@@ -567,6 +618,22 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
+    };
+    T xl0[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) xl0[i] = xo[i];
+    load_step(0, xl0, uo, kk);
+    if constexpr (DEEP) {
+      T xl1[n], uo1[m], kk1[m][n + 1];
+      if (N >= 2) load_step(1, xl1, uo1, kk1);
+      int t = 0;
+      for (; t + 1 < N; t += 2) {
+        body(t, xl0, uo, kk);
+        body(t + 1, xl1, uo1, kk1);
+      }
+      if (t < N) body(t, xl0, uo, kk);
+    } else {
+      for (int t = 0; t < N; t++) body(t, xl0, uo, kk);
     }
     cost = cost + terminal_cost(x, xT);
     return cost;
