@@ -16,12 +16,6 @@
 
 namespace i2lqr {
 
-template <class T> __device__ __forceinline__ T t_sin(T x);
-template <> __device__ __forceinline__ double t_sin<double>(double x) { return sin(x); }
-template <> __device__ __forceinline__ float t_sin<float>(float x) { return sinf(x); }
-template <class T> __device__ __forceinline__ T t_cos(T x);
-template <> __device__ __forceinline__ double t_cos<double>(double x) { return cos(x); }
-template <> __device__ __forceinline__ float t_cos<float>(float x) { return cosf(x); }
 // sin and cos of one argument.  fp64: Cody-Waite reduction by pi/2 in three FMA steps (exact for
 // |x| < 2^20 pi/2) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]
 // (<= ~1 ulp each); about a third of the instructions of the general-range library routine, which
