@@ -189,12 +189,13 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
                 "k_lane_iterate chunks + k_lane_compact + k_iterate tail")}
 
 
-def load_traffic(key):
-    """HBM bytes per launch from the committed PMC summary (tools/collect_pmc.sh), or None."""
+def load_traffic(key, field="hbm_bytes_per_launch"):
+    """HBM bytes per launch (or another field, e.g. the SQ-counter shares of the wavefronts'
+    lifetime) from the committed PMC summary (tools/collect_pmc.sh), or None."""
     tf = ROOT / "profiles" / "pmc_traffic.json"
     try:
         rec = json.loads(tf.read_text()).get(key)
-        return rec["hbm_bytes_per_launch"] if rec else None
+        return rec.get(field) if rec else None
     except Exception:
         return None
 
@@ -290,7 +291,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_iteration": alg_bytes,
-                     "kernel_ms_avg": res["kernel_ms"]},
+                     "kernel_ms_avg": res["kernel_ms"],
+                     # SQ counters of the same kernel (separate --pmc pass): shares of the
+                     # wavefronts' lifetime spent issuing (any / VALU), parked on s_waitcnt, stalled
+                     "sq_shares_of_wave_cycles": load_traffic(
+                         f"{args.workload}:{dtype}:B{B}:it{args.iters}", "sq_shares_of_wave_cycles")},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,8 @@ for key, src, kern in (("config2:f64:B1024:it10", "wave_f64_B1024", "k_iterate (
                        ("config2:f32:B65536:it10", "tiled_f32_B65536", "k_lane_iterate (tiled)"),
                        ("config2:f64:B1048576:it10", "tiled_f64_B1048576", "k_lane_iterate (tiled)")):
     out[key] = {"hbm_bytes_per_launch": s[src]["hbm_bytes_per_launch"], "kernel": kern}
+    if "sq_shares_of_wave_cycles" in s[src]:  # third --pmc pass: SQ counters
+        out[key]["sq_shares_of_wave_cycles"] = s[src]["sq_shares_of_wave_cycles"]
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
 cp "$ROOT/profiles/pmc_traffic.json" "$NEW/pmc_traffic.json"
