@@ -209,7 +209,69 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // Re-roll the nominal states X[:, 1..N] from the (already clipped) nominal inputs: restores the
   // trajectory after a rejected step, whose candidate was written over it in place.  Bit-identical
   // to what rollout() / an accepted forward() stored (same code, same inputs).
-  __device__ __forceinline__ void restore_states(T* X, const T* U) const {
+  // Blocks of RB horizon steps: the inputs of block b+1 are loaded while block b computes (two
+  // register sets take turns), and the states of a block are stored one block LATE, right after the
+  // next block's inputs have arrived.  On gfx950 loads and stores share vmcnt and a wait with both
+  // kinds pending drains the counter: this way everything pending at the one wait per block was
+  // issued a whole block (RB steps) earlier.
+  __device__ __forceinline__ void restore_states_blocked(T* X, const T* U) const {
+    constexpr int RB = 4;
+    T x[n], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
+    T xs[RB][n];  // states computed by the previous block
+    auto load_block = [&](const int b, T (&ul)[RB][m]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < RB; j++)
+        if (b * RB + j < N) {
+#pragma unroll
+          for (int a = 0; a < m; a++) ul[j][a] = at(U, ru(a, b * RB + j));
+        }
+    };
+    auto block = [&](const int b, T (&ucur)[RB][m], T (&unext)[RB][m])
+        __attribute__((always_inline)) {
+      T u[RB][m];
+#pragma unroll
+      for (int j = 0; j < RB; j++)
+#pragma unroll
+        for (int a = 0; a < m; a++) u[j][a] = ucur[j][a];
+      if ((b + 1) * RB < N) load_block(b + 1, unext);
+      if (b > 0) {  // the previous block was complete: RB states
+#pragma unroll
+        for (int j = 0; j < RB; j++)
+#pragma unroll
+          for (int i = 0; i < n; i++) at(X, rx(i, (b - 1) * RB + j + 1)) = xs[j][i];
+      }
+#pragma unroll
+      for (int j = 0; j < RB; j++)
+        if (b * RB + j < N) {
+          Sys::trig(x, tr);
+          Sys::step_tr(c, x, u[j], tr, xn);
+#pragma unroll
+          for (int i = 0; i < n; i++) {
+            xs[j][i] = xn[i];
+            x[i] = xn[i];
+          }
+        }
+    };
+    T ua[RB][m], ub[RB][m];
+    load_block(0, ua);
+    const int nb = (N + RB - 1) / RB;
+    int b = 0;
+    for (; b + 1 < nb; b += 2) {
+      block(b, ua, ub);
+      block(b + 1, ub, ua);
+    }
+    if (b < nb) block(b, ua, ub);
+#pragma unroll
+    for (int j = 0; j < RB; j++)  // the last block's states
+      if ((nb - 1) * RB + j < N) {
+#pragma unroll
+        for (int i = 0; i < n; i++) at(X, rx(i, (nb - 1) * RB + j + 1)) = xs[j][i];
+      }
+  }
+
+  __device__ __forceinline__ void restore_states_paired(T* X, const T* U) const {
     T x[n], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
@@ -243,6 +305,13 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       body(t + 1, ub);
     }
     if (t < N) body(t, ua);
+  }
+
+  // fp32 (DEEP) takes the blocked form (+3-4 %); in fp64 its 40 extra live registers cost more
+  // AGPR traffic than the waits it saves (-1.5 %)
+  __device__ __forceinline__ void restore_states(T* X, const T* U) const {
+    if constexpr (DEEP) restore_states_blocked(X, U);
+    else restore_states_paired(X, U);
   }
 
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
