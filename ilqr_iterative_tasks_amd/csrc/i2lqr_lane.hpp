@@ -669,15 +669,17 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         u[a] = clip(ul[a] + kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
         uon[a] = ul[a];
       }
+      // all memory operations of the step are issued here, right after the wait for its inputs:
+      // the next wait drains the shared load / store counter, and by then they are a step old
+      if (t + D < N) load_step(t + D, xl, ul, kl);
+#pragma unroll
+      for (int a = 0; a < m; a++) at(Un, ru(a, t)) = u[a];
       if constexpr (REROLL) {  // nominal state of step t+1
         Sys::trig(xo, tr);
         Sys::step_tr(c, xo, uon, tr, xn);
 #pragma unroll
         for (int i = 0; i < n; i++) xo[i] = xn[i];
       }
-      if (t + D < N) load_step(t + D, xl, ul, kl);
-#pragma unroll
-      for (int a = 0; a < m; a++) at(Un, ru(a, t)) = u[a];
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
       if constexpr (WRITEX) {
