@@ -324,7 +324,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
 
   // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per
   // problem, so a wavefront of 64 problems would otherwise idle on its slowest lane.  The batch
-  // is solved in chunks of 2, 2, 4, 4, 4, 8, 8, 16, ... iterations; after every chunk the terminated problems
+  // is solved in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations; after every chunk the terminated problems
   // are scattered to the caller's arrays and the survivors are packed into a dense work set
   // (k_lane_compact).  No host synchronisation: the live count stays in device memory and
   // surplus wavefronts exit at once.  Results are bit-identical to the plain launch.
@@ -346,7 +346,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     usr.orig = nullptr;
     if (!obs) { cv.set[0].obs = nullptr; cv.set[1].obs = nullptr; }
     // chunk 0 runs in place on the caller's arrays
-    int done = 0, len = 2;
+    int done = 0, len = 4;
     a0.B = B; a0.n_iters = len; a0.early_exit = 1;
     a0.X = usr.X; a0.U = usr.U; a0.x_term = usr.x_term; a0.lamb = usr.lamb; a0.obs = usr.obs;
     a0.cost = usr.cost; a0.K = usr.K; a0.k = usr.k; a0.iters = usr.iters; a0.status = usr.status;
@@ -390,9 +390,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           }
         }
       }
-      // chunk lengths 2, 2, 4, 4, 4, 8, 8, 16, 16, 32, ...: compaction points at 2, 4, 8, 12, 16, 24,
+      // chunk lengths 4, 4, 4, 4, 8, 8, 16, 16, 32, ...: compaction points at 4, 8, 12, 16, 24,
       // 32, 48, 64, 96 iterations (a late compaction costs little: its work scales with the survivors)
-      len = done < 4 ? 2 : (done < 16 ? 4 : (done < 32 ? 8 : (done < 64 ? 16 : 32)));
+      len = done < 16 ? 4 : (done < 32 ? 8 : (done < 64 ? 16 : 32));
       if (done + len > max_iter) len = max_iter - done;
       LaneArgs<T> a = a0;
       a.X = w.X; a.U = w.U; a.x_term = w.x_term; a.lamb = w.lamb; a.obs = w.obs; a.cost = w.cost;

@@ -135,7 +135,7 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
- * problems the solve runs in chunks of 2, 2, 4, 4, 4, 8, 8, 16, ... iterations and packs the still-running
+ * problems the solve runs in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations and packs the still-running
  * problems into dense work sets between chunks (no host synchronisation); once few problems are
  * left ("wave_tail" option below) they are finished by the one-problem-per-wavefront kernel.
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
@@ -143,7 +143,7 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
  *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
  *   from 4096 problems when max_iter > 16).
  * Measured on MI355X, n=6, N=20, 65536 problems, fp64: 6.8 ms single launch, 7.4 ms chunked
- * without the tail kernel, 3.6 ms with it.  The chunks alone are bit-identical to the single
+ * without the tail kernel, 3.0 ms with it.  The chunks alone are bit-identical to the single
  * launch; with the tail kernel the outputs agree to the solve tolerance (1e-8 rel).
  */
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);

@@ -397,7 +397,7 @@ def test_lane_scheduling_options_do_not_change_results(torch_mod, lay, dtype):
 @pytest.mark.parametrize("lay,dtype,gains", [("lane", "f64", True), ("lane", "f32", False),
                                              ("tiled", "f64", False), ("tiled", "f32", True)])
 def test_chunked_compacting_solve_is_bit_identical_to_plain(torch_mod, lay, dtype, gains):
-    """Opt-in chunked solve (i2lqr_set_compaction): chunks of 2, 2, 4, 4, 4, 8, ... iterations with the
+    """Opt-in chunked solve (i2lqr_set_compaction): chunks of 4, 4, 4, 4, 8, ... iterations with the
     surviving problems packed between chunks (k_lane_compact).  Every output must equal, bit for
     bit, the plain single-launch solve (taken here on sub-batches of 2048, below the threshold),
     and the iteration counts must match the oracle's."""
