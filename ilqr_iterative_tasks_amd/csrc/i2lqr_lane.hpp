@@ -879,15 +879,32 @@ __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneS
     if (src_is_user) return uaddr(rows, row, p);
     return (int64_t)row * src.B + p;
   };
+  // rows are moved eight at a time: eight independent loads in flight, then eight stores (the
+  // arrays may alias as far as the compiler knows, so a plain loop would serialise every pair)
+  auto move_rows = [&](int rows, auto&& dst_at, auto&& src_at) __attribute__((always_inline)) {
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+      T v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = src_at(r + q);
+#pragma unroll
+      for (int q = 0; q < 8; q++) dst_at(r + q, v[q]);
+    }
+    for (; r < rows; r++) dst_at(r, src_at(r));
+  };
   const int st = src.status[i];
   if (st != 0) {
     if (src_is_user) return;  // already in place
     const int64_t o = src.orig[i];
-    for (int r = 0; r < rx; r++) usr.X[uaddr(rx, r, o)] = src.X[(int64_t)r * src.B + i];
-    for (int r = 0; r < ru; r++) usr.U[uaddr(ru, r, o)] = src.U[(int64_t)r * src.B + i];
+    move_rows(rx, [&](int r, T v) { usr.X[uaddr(rx, r, o)] = v; },
+              [&](int r) { return src.X[(int64_t)r * src.B + i]; });
+    move_rows(ru, [&](int r, T v) { usr.U[uaddr(ru, r, o)] = v; },
+              [&](int r) { return src.U[(int64_t)r * src.B + i]; });
     if (usr.K) {
-      for (int r = 0; r < rK; r++) usr.K[uaddr(rK, r, o)] = src.K[(int64_t)r * src.B + i];
-      for (int r = 0; r < ru; r++) usr.k[uaddr(ru, r, o)] = src.k[(int64_t)r * src.B + i];
+      move_rows(rK, [&](int r, T v) { usr.K[uaddr(rK, r, o)] = v; },
+                [&](int r) { return src.K[(int64_t)r * src.B + i]; });
+      move_rows(ru, [&](int r, T v) { usr.k[uaddr(ru, r, o)] = v; },
+                [&](int r) { return src.k[(int64_t)r * src.B + i]; });
     }
     usr.lamb[o] = src.lamb[i];
     usr.cost[o] = src.cost[i];
@@ -897,11 +914,17 @@ __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneS
   }
   if (!dst.X) return;  // final pass: nothing survives (every problem has a terminal status)
   const int64_t j = atomicAdd(count_out, 1);
-  for (int r = 0; r < rx; r++) dst.X[(int64_t)r * dst.B + j] = src.X[saddr(rx, r, i)];
-  for (int r = 0; r < ru; r++) dst.U[(int64_t)r * dst.B + j] = src.U[saddr(ru, r, i)];
-  for (int r = 0; r < n; r++) dst.x_term[(int64_t)r * dst.B + j] = src.x_term[saddr(n, r, i)];
+  // a survivor carries its inputs and x_0 only (the rows t = 0 of the time-major X): every chunk
+  // starts by rolling the states out again
+  move_rows(n, [&](int r, T v) { dst.X[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return src.X[saddr(rx, r, i)]; });
+  move_rows(ru, [&](int r, T v) { dst.U[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return src.U[saddr(ru, r, i)]; });
+  move_rows(n, [&](int r, T v) { dst.x_term[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return src.x_term[saddr(n, r, i)]; });
   if (src.obs)
-    for (int r = 0; r < 6; r++) dst.obs[(int64_t)r * dst.B + j] = src.obs[saddr(6, r, i)];
+    move_rows(6, [&](int r, T v) { dst.obs[(int64_t)r * dst.B + j] = v; },
+              [&](int r) { return src.obs[saddr(6, r, i)]; });
   dst.lamb[j] = src.lamb[i];
   dst.iters[j] = src.iters[i];
   dst.status[j] = 0;  // RUNNING (a tail launch of the one-problem-per-wavefront kernel may finish it)

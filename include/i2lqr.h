@@ -143,7 +143,7 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
  *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
  *   from 4096 problems when max_iter > 16).
  * Measured on MI355X, n=6, N=20, 65536 problems, fp64: 6.8 ms single launch, 7.4 ms chunked
- * without the tail kernel, 3.0 ms with it.  The chunks alone are bit-identical to the single
+ * without the tail kernel, 2.7 ms with it.  The chunks alone are bit-identical to the single
  * launch; with the tail kernel the outputs agree to the solve tolerance (1e-8 rel).
  */
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
