@@ -167,7 +167,9 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     this many running problems (<= 8192), they are finished by the one-problem-
  *                     per-wavefront kernel, whose iteration latency is ~2.8x lower.  Same
  *                     algorithm, different summation order: results agree with the single launch
- *                     to the solve tolerance (1e-8), not bit for bit.  0: off; automatic: 2048.
+ *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
+ *                     settle an accept / reject tie the other way and stop at a different
+ *                     iteration).  0: off; automatic: 2048.
  * One problem per wavefront (problem-major layout), i2lqr_iterate / i2lqr_solve:
  *   "per_step_jacobians"  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
  *                     30-52) are written to LDS by the parallel per-step phase, so the serial
