@@ -558,9 +558,12 @@ template <class T> __device__ __forceinline__ bool better(T v, int64_t i, T bv, 
   return v < bv || (v == bv && i < bi);
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void k_argmin_partial(int64_t B, const T* cost,
-                                                        MinPair<T>* part) {
+// FINAL: a single workgroup scans the whole vector and writes the result itself (small batches:
+// one launch instead of two)
+template <class T, bool FINAL = false>
+__global__ __launch_bounds__(256) void k_argmin_partial(int64_t B, const T* cost, MinPair<T>* part,
+                                                        int64_t* best_idx = nullptr,
+                                                        T* best_cost = nullptr) {
   __shared__ T sv[256];
   __shared__ int64_t si[256];
   T bv = T(0);
@@ -583,7 +586,15 @@ __global__ __launch_bounds__(256) void k_argmin_partial(int64_t B, const T* cost
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { part[blockIdx.x].v = sv[0]; part[blockIdx.x].i = si[0]; }
+  if (threadIdx.x == 0) {
+    if constexpr (FINAL) {
+      *best_idx = si[0];
+      *best_cost = si[0] >= 0 ? sv[0] : (T)INFINITY;
+    } else {
+      part[blockIdx.x].v = sv[0];
+      part[blockIdx.x].i = si[0];
+    }
+  }
 }
 
 template <class T>
@@ -619,6 +630,7 @@ __global__ __launch_bounds__(256) void k_argmin_final(int nparts, const MinPair<
 }
 
 constexpr int kArgminBlocks = 256;
+constexpr int64_t kArgminSingle = 16384;  // up to here a single workgroup scans the vector
 
 }  // namespace
 
@@ -887,7 +899,16 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
   hipStream_t s = (hipStream_t)stream;
   int64_t want = (B + 255) / 256;
   const int blocks = (int)(want < 1 ? 1 : (want > kArgminBlocks ? kArgminBlocks : want));
-  if (h->cfg.dtype == I2LQR_F64) {
+  if (B <= kArgminSingle) {  // one workgroup, one launch
+    if (h->cfg.dtype == I2LQR_F64)
+      hipLaunchKernelGGL((k_argmin_partial<double, true>), dim3(1), dim3(256), 0, s, B,
+                         (const double*)cost_it, (MinPair<double>*)nullptr, best_idx,
+                         (double*)best_cost);
+    else
+      hipLaunchKernelGGL((k_argmin_partial<float, true>), dim3(1), dim3(256), 0, s, B,
+                         (const float*)cost_it, (MinPair<float>*)nullptr, best_idx,
+                         (float*)best_cost);
+  } else if (h->cfg.dtype == I2LQR_F64) {
     auto* part = (MinPair<double>*)workspace;
     hipLaunchKernelGGL((k_argmin_partial<double>), dim3(blocks), dim3(256), 0, s, B,
                        (const double*)cost_it, part);
