@@ -135,8 +135,8 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
- * problems the solve runs in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations and packs the still-running
- * problems into dense work sets between chunks (no host synchronisation); once few problems are
+ * problems the solve runs in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations and packs the
+ * still-running problems into dense work sets between chunks (no host synchronisation); once few problems are
  * left ("wave_tail" option below) they are finished by the one-problem-per-wavefront kernel.
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
  * large solve is bound by the slowest problem's iteration latency.
@@ -149,7 +149,8 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
 
 /*
- * Scheduling options of the kernels.  They change how the work is laid out on the GPU, never the results (bit-identical; tests/).
+ * Scheduling options of the kernels.  They change how the work is laid out on the GPU, not the
+ * results (bit-identical, tests/; the one exception is "wave_tail", see there).
  * value -1 restores the automatic choice.  No reference counterpart (the NumPy path has no such
  * degrees of freedom); they exist so that A/B measurements run in one process on one device.
  * One problem per lane (batch-minor / batch-tiled layouts):
