@@ -136,8 +136,9 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
  * problems the solve runs in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations and packs the
- * still-running problems into dense work sets between chunks (no host synchronisation); once few problems are
- * left ("wave_tail" option below) they are finished by the one-problem-per-wavefront kernel.
+ * still-running problems into dense work sets between chunks (no host synchronisation); once few
+ * problems are left ("wave_tail" option below) they are finished by the one-problem-per-wavefront
+ * kernel.
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
  * large solve is bound by the slowest problem's iteration latency.
  *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
