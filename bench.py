@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2",
                     help="config2 (default: B=1024 fp64), config3 (B=65536 fp32), config4, config5")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload's)")
