@@ -5,21 +5,38 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started plainly with --gpus N > 1 (no RANK / WORLD_SIZE in the environment) this process becomes the
+launcher: it starts N fresh rank processes through torch.distributed.run BEFORE anything touches the
+GPU (it never imports torch itself) and relays rank 0's JSON line.  Under a launcher whose world
+differs from --gpus it exits non-zero instead of reporting a smaller world.
+
 A "step" is one pass of the hot path over one batch of synthetic problems that is already resident
 in HBM: `iters` fused iLQR iterations per problem (i2lqr_iterate: rollout + cost, backward Riccati
 pass with dynamics Jacobians and cost quadratisation, forward rollout, accept/reject), the relaxed
-terminal cost of every candidate, the all-gather of those costs across ranks (N > 1; RCCL over
-xGMI) and the arg-min.  Default workload = BASELINE.json configs[1]: batch 1024 per GPU,
-kinematic bicycle n=6 m=2 N=20, fp64.  Weak scaling: every rank owns its own `batch` problems.
+terminal cost of every candidate, the all-gather of those costs across ranks (one RCCL
+ncclAllGather through the C-ABI, i2lqr_allgather_costs, on a side stream) and the arg-min every
+rank evaluates locally (utils/base.py:462-469).  Default workload = BASELINE.json configs[1]: batch
+1024 per GPU, kinematic bicycle n=6 m=2 N=20, fp64.  Weak scaling: every rank owns its own `batch`
+problems; `extra.config4_strong` adds the strong-scaled configs[3] (2^20 problems over all ranks).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_iterate) against the HBM
-peak with the ALGORITHMIC bytes of SURVEY.md §8(d) (4968 B per iteration per problem at
-n=6, m=2, N=20, fp64); `cpu_baseline` times the CPU oracle (a port, oracle/ilqr_oracle.c) on the
-host cores of the same box on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the HBM peak with the
+ALGORITHMIC bytes of SURVEY.md §8(d) (4968 B per iteration per problem at n=6, m=2, N=20, fp64);
+`roofline_issue` prices the same kernel against the instruction-issue peak of its wavefronts (the
+bound that matters while a launch is one wavefront per SIMD); `cpu_baseline` times the CPU oracle
+(a port, oracle/ilqr_oracle.c) on the host cores of the same box on a bounded sample of the same
+workload.
+
+--exchange-only (no GPU needed; gloo): the multi-rank harness alone — launcher, process group,
+barriers, max-over-ranks timing, all-gather of synthetic cost shards, local arg-min — with the
+solve left out.  It exists so that the N > 1 plumbing of this file is testable on a CPU box; its
+JSON line says so and is not a throughput figure of the solver.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -29,9 +46,12 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SIMDS = 256 * 4        # CUs x SIMDs per CU
+CLOCK_GHZ = 2.4        # max clock; one wavefront alone on a SIMD issues one instruction per 4 cycles
+LIB = ROOT / "ilqr_iterative_tasks_amd" / "csrc" / "libi2lqr_hip.so"
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -44,19 +64,57 @@ def parse_args():
     ap.add_argument("--layout", default="auto", choices=["auto", "wave", "lane", "tiled"],
                     help="kernel family: wave = one problem per wavefront (problem-major), lane = "
                          "one problem per lane (batch-minor); auto picks by batch size")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="all-gather of the costs: native = i2lqr_allgather_costs (RCCL through the "
+                         "C-ABI), torch = torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="CPU/gloo dry run of the multi-rank harness without the solve (see above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  ->  N rank processes
+# ------------------------------------------------------------------------------------------------
+
+def spawn_ranks(args) -> int:
+    """Start args.gpus ranks of this script as fresh processes and relay rank 0's JSON line.  Runs
+    before torch is imported: the launcher never initialises a GPU, and nothing is exec'ed from a
+    process that has."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout)
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode})\n")
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
 
 LANE_THRESHOLD = 4096  # per-GPU batch from which the one-problem-per-lane kernels win
-
-
 LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
+LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",
+               "lane": "batch-minor (one problem per lane)",
+               "tiled": "batch-tiled x64 (one problem per lane)"}
 
 
-def pick_layout(args, B, dtype="f64"):
+def pick_layout(args, B):
     """wave: one problem per wavefront (latency path); lane / tiled: one problem per lane over
     batch-minor rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
     if args.layout != "auto":
@@ -91,11 +149,11 @@ def make_step_buffers(solver, host, n_sets, torch):
 
 
 def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True):
-    """Time `steps` steps; returns dict(seconds, kernel_ms_avg, iterations)."""
+    """Time `steps` steps; returns dict(seconds, kernel_ms, iterations, ...)."""
     import torch.distributed as dist
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    layout = pick_layout(args, B, "f64" if cfg.dtype == 0 else "f32")
+    layout = pick_layout(args, B)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     host = workloads.make_batch(cfg, B, offset=rank * B)
@@ -107,9 +165,16 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 for _ in range(steps + warmup)]
     main_stream = torch.cuda.current_stream()
     grouped = dist.is_available() and dist.is_initialized()
-    comm_stream = torch.cuda.Stream() if grouped else None
+    exchange = None
+    if grouped and with_tail:
+        exchange = dist_mod.CostExchange(solver) if args.exchange == "native" else "torch"
+    comm_stream = torch.cuda.Stream() if exchange is not None else None
+    cost_alls = ([torch.zeros(B * world, dtype=solver.dtype, device=solver.device)
+                  for _ in range(steps + warmup)] if exchange is not None else None)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    xv0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    xv1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     picks = []
 
     def step(i_set, i_timed=None):
@@ -121,15 +186,22 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             ev1[i_timed].record()
         if with_tail:
             solver.relax_cost(buf["X"], buf["x_term"], qfun, 0, 55, cost_it)
-            if comm_stream is None:
+            if exchange is None:
                 picks.append(solver.argmin(cost_it))
             else:
                 ready = torch.cuda.Event()
                 ready.record(main_stream)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(ready)
-                    cost_all = dist_mod.allgather_costs(cost_it)
+                    if i_timed is not None:
+                        xv0[i_timed].record()
+                    if exchange == "torch":
+                        cost_all = dist_mod.allgather_costs(cost_it)
+                    else:
+                        cost_all = exchange.allgather(cost_it, cost_alls[i_set])
                     picks.append(solver.argmin(cost_all))
+                    if i_timed is not None:
+                        xv1[i_timed].record()
 
     for i in range(warmup):
         step(i)
@@ -145,25 +217,39 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         dist.barrier()
         torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
+    rank_seconds = [seconds]
     if grouped:
         t = torch.tensor([seconds], dtype=torch.float64, device=solver.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seconds = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_seconds = [float(x.item()) for x in allt]
+        seconds = max(rank_seconds)
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
     # every problem executes exactly `iters` iterations (no early exit): check on the last set
     assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
+    res = dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps,
+               rank_seconds=rank_seconds, layout=LAYOUT_NAME[layout],
+               kernel="k_iterate" if layout == "wave" else "k_lane_iterate")
+    if exchange is not None:
+        res["exchange_ms"] = sum(a.elapsed_time(b) for a, b in zip(xv0, xv1)) / steps
+        # the pick is the same on every rank and is the arg-min of the gathered vector
+        idx, val = picks[-1]
+        ref = cost_alls[-1] if exchange != "torch" else dist_mod.allgather_costs(cost_its[-1])
+        first, best = dist_mod.select_best_flat(ref)
+        assert int(idx.item()) == first and float(val.item()) == best, "exchange / pick mismatch"
+        if exchange != "torch":
+            res["nccl_world"] = exchange.comm_world
+            exchange.close()
+        else:
+            res["nccl_world"] = dist.get_world_size()
     solver.close()
-    return dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps,
-                kernel="k_iterate" if layout == "wave" else "k_lane_iterate",
-                layout={"wave": "problem-major (one problem per wavefront)",
-                        "lane": "batch-minor (one problem per lane)",
-                        "tiled": "batch-tiled x64 (one problem per lane)"}[layout])
+    return res
 
 
 def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    layout = pick_layout(args, B, "f64" if cfg.dtype == 0 else "f32")
+    layout = pick_layout(args, B)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     if single_launch:
@@ -189,15 +275,57 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
                 "k_lane_iterate chunks + k_lane_compact + k_iterate tail")}
 
 
-def load_traffic(key, field="hbm_bytes_per_launch"):
-    """HBM bytes per launch (or another field, e.g. the SQ-counter shares of the wavefronts'
-    lifetime) from the committed PMC summary (tools/collect_pmc.sh), or None."""
-    tf = ROOT / "profiles" / "pmc_traffic.json"
+def lib_sha256():
     try:
-        rec = json.loads(tf.read_text()).get(key)
-        return rec.get(field) if rec else None
-    except Exception:
+        return hashlib.sha256(LIB.read_bytes()).hexdigest()
+    except OSError:
         return None
+
+
+class PmcFile:
+    """profiles/pmc_traffic.json: per-launch HBM bytes (FETCH_SIZE / WRITE_SIZE) and SQ counters
+    from separate `rocprofv3 --pmc` passes (tools/collect_profiles.sh), stamped with the sha256 of
+    the library they were collected on.  Counters of another build are not reported: `traffic`
+    becomes null and `traffic_stale` true."""
+
+    def __init__(self):
+        try:
+            self.data = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        except Exception:
+            self.data = {}
+        self.collected_on = (self.data.get("_meta") or {}).get("lib_sha256")
+        self.running = lib_sha256()
+        self.stale = self.collected_on is None or self.collected_on != self.running
+
+    def get(self, key, field="hbm_bytes_per_launch"):
+        rec = self.data.get(key)
+        if self.stale or not rec:
+            return None
+        return rec.get(field)
+
+    def stamp(self):
+        return {"traffic_stale": self.stale,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes, "
+                                  f"library sha256 {str(self.collected_on)[:16]})",
+                "library_sha256": str(self.running)[:16]}
+
+
+def issue_roofline(pmc, key, kernel_ms, waves):
+    """Instruction-issue roofline of a launch whose wavefronts each sit alone on a SIMD: such a
+    wavefront issues at most one instruction per 4 cycles, whatever the instruction
+    (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').  achieved = wavefront-instructions
+    issued per second (SQ_INSTS_VALU + SALU + LDS + ... = SQ_INSTS of the --pmc pass, per launch,
+    / the kernel time measured here); peak = occupied SIMDs x clock / 4."""
+    insts = pmc.get(key, "wave_instructions_per_launch")
+    simds = min(waves, SIMDS)
+    peak = simds * CLOCK_GHZ / 4.0  # G wave-instructions / s
+    out = {"bound": "issue", "unit": "G wavefront-instructions/s", "peak": peak,
+           "simds_occupied": simds, "achieved": None, "frac": None,
+           "wave_instructions_per_launch": insts}
+    if insts:
+        out["achieved"] = insts / (kernel_ms * 1e-3) / 1e9
+        out["frac"] = out["achieved"] / peak
+    return out
 
 
 def cpu_baseline(cfg, B, iters, budget_s):
@@ -247,26 +375,94 @@ def cpu_baseline(cfg, B, iters, budget_s):
                 value_1thread=one_thread, logical_cpus=avail)
 
 
-def main():
-    args = parse_args()
+def run_exchange_only(args, rank, world, torch, dist_mod):
+    """The multi-rank harness without the solve (CPU tensors, gloo): per step every rank
+    contributes a synthetic cost shard, all-gathers, and picks; the pick is checked against the
+    shards every rank can regenerate from the seeds."""
+    import numpy as np
+    import torch.distributed as dist
+    B = args.batch or 1024
+    total = B * world
+
+    def shard(step, r):
+        return np.random.default_rng([20230228, step, r]).uniform(1.0, 1e4, B)
+
+    grouped = dist.is_available() and dist.is_initialized()
+
+    def step(i):
+        cost_all = dist_mod.allgather_costs(torch.as_tensor(shard(i, rank)))
+        return dist_mod.select_best_flat(cost_all)
+
+    for i in range(args.warmup):
+        step(i)
+    if grouped:
+        dist.barrier()
+    t0 = time.perf_counter()
+    pick = None
+    for i in range(args.steps):
+        pick = step(args.warmup + i)
+    if grouped:
+        dist.barrier()
+    seconds = time.perf_counter() - t0
+    if grouped:
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+    full = np.concatenate([shard(args.warmup + args.steps - 1, r) for r in range(world)])
+    assert pick == (int(np.argmin(full)), float(full.min())), "all-gather / pick mismatch"
+    return {
+        "metric": "exchange-only dry run: candidates/s through all-gather + arg-min (NO solve; "
+                  "harness check, not a solver throughput)",
+        "value": total * args.steps / seconds, "unit": "candidates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic cost shards (no GPU, gloo)",
+        "config": {"workload": "exchange-only", "batch_per_gpu": B, "global_batch": total,
+                   "backend": dist.get_backend() if grouped else "none",
+                   "parallelism": f"batch-sharded x{world}, one all-gather of terminal costs"},
+    }
+
+
+def run_rank(args) -> int:
     import torch
     from ilqr_iterative_tasks_amd import dist as dist_mod, workloads
 
-    rank, world, local = dist_mod.init_from_env("nccl")
-    if world != max(1, args.gpus) and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    gpu_mode = not args.exchange_only
+    want = int(os.environ.get("WORLD_SIZE", "1"))
+    if gpu_mode and torch.cuda.device_count() < want:  # (counting devices initialises nothing)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"bench.py: {want} ranks but {torch.cuda.device_count()} HIP devices are "
+                  "visible (use --exchange-only for the CPU dry run of the harness)",
+                  file=sys.stderr)
+        return 3
+    rank, world, local = dist_mod.init_from_env("nccl" if gpu_mode else "gloo")
+    if world != max(1, args.gpus):
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks",
+                  file=sys.stderr)
+        return 2
+    import torch.distributed as dist
+    if not gpu_mode:
+        out = run_exchange_only(args, rank, world, torch, dist_mod)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     torch.cuda.set_device(local)
     wl = workloads.CONFIGS[args.workload]
     cfg = workloads.config_for(args.workload, args.dtype)
     B = args.batch or wl["batch"]
     dtype = "f64" if cfg.dtype == 0 else "f32"
+    pmc = PmcFile()
 
     res = run_gpu(args, cfg, B, rank, world, torch, dist_mod, args.steps, args.warmup)
     value = res["iterations"] / res["seconds"]
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
-
-    traffic = load_traffic(f"{args.workload}:{dtype}:B{B}:it{args.iters}")
+    key = f"{args.workload}:{dtype}:B{B}:it{args.iters}"
+    waves = B if res["kernel"] == "k_iterate" else (B + 63) // 64
 
     out = {
         "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"
@@ -290,19 +486,40 @@ def main():
                    "parallelism": f"batch-sharded x{world}, one all-gather of terminal costs"},
         "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_iteration": alg_bytes,
-                     "kernel_ms_avg": res["kernel_ms"],
+                     "traffic": pmc.get(key), "algorithmic_bytes_per_iteration": alg_bytes,
+                     "kernel_ms_avg": res["kernel_ms"], **pmc.stamp(),
                      # SQ counters of the same kernel (separate --pmc pass): shares of the
                      # wavefronts' lifetime spent issuing (any / VALU), parked on s_waitcnt, stalled
-                     "sq_shares_of_wave_cycles": load_traffic(
-                         f"{args.workload}:{dtype}:B{B}:it{args.iters}", "sq_shares_of_wave_cycles")},
+                     "sq_shares_of_wave_cycles": pmc.get(key, "sq_shares_of_wave_cycles")},
+        "roofline_issue": issue_roofline(pmc, key, res["kernel_ms"], waves),
+        "per_rank_iterations_per_s": [B * args.iters * args.steps / s for s in res["rank_seconds"]],
     }
+    if "exchange_ms" in res:
+        out["exchange"] = {"ms_per_step": res["exchange_ms"], "nccl_world": res["nccl_world"],
+                           "path": "i2lqr_allgather_costs (RCCL ncclAllGather via the C-ABI) + "
+                                   "i2lqr_argmin on a side stream" if args.exchange == "native"
+                           else "torch.distributed.all_gather_into_tensor + i2lqr_argmin on a "
+                                "side stream",
+                           "bytes_per_rank": B * (8 if dtype == "f64" else 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B, args.iters, args.cpu_seconds)
+    extra = {}
+    if not args.no_extra:
+        # configs[3] strong-scaled: 2^20 problems over all ranks, exchange included
+        total = 1 << 20
+        ecfg = workloads.config_for(args.workload, "f64")
+        r = run_gpu(args, ecfg, total // world, rank, world, torch, dist_mod, 3, 2)
+        eb_bytes = workloads.algorithmic_bytes_per_iteration(ecfg)
+        ach = eb_bytes * (total // world) * args.iters / (r["kernel_ms"] * 1e-3) / 1e9
+        extra["config4_strong"] = {
+            "iterations_per_s": r["iterations"] / r["seconds"], "global_batch": total,
+            "batch_per_gpu": total // world, "scaling": "strong", "kernel": r["kernel"],
+            "layout": r["layout"], "kernel_ms": r["kernel_ms"], "achieved_GBs_per_gpu": ach,
+            "hbm_frac_per_gpu": ach / HBM_PEAK_GBS,
+            "exchange_ms_per_step": r.get("exchange_ms"), "nccl_world": r.get("nccl_world")}
     if world == 1 and not args.no_extra:
         # secondary single-GPU workloads (not the headline): large batches of the same problem
-        extra = {}
         for name, eb, edt in (("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32"),
                               ("B1048576_f64", 1 << 20, "f64"), ("B1048576_f32", 1 << 20, "f32")):
             ecfg = workloads.config_for(args.workload, edt)
@@ -314,22 +531,31 @@ def main():
                            "kernel": r["kernel"], "layout": r["layout"],
                            "kernel_ms": r["kernel_ms"], "achieved_GBs": ach,
                            "hbm_frac": ach / HBM_PEAK_GBS,
-                           "traffic": load_traffic(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
+                           "traffic": pmc.get(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
         # problem is done, so this is below the fixed-count rate.  Default = chunked solve with
         # compaction and the one-problem-per-wavefront tail; single launch beside it.
-        extra["solve_to_termination_B65536_f64"] = run_solve(args, workloads.config_for(
-            args.workload, "f64"), 65536, torch)
+        f64 = workloads.config_for(args.workload, "f64")
+        for sb in (1024, 4096, 16384, 65536):
+            extra[f"solve_to_termination_B{sb}_f64"] = run_solve(args, f64, sb, torch)
         extra["solve_to_termination_B65536_f64_single_launch"] = run_solve(
-            args, workloads.config_for(args.workload, "f64"), 65536, torch, single_launch=True)
+            args, f64, 65536, torch, single_launch=True)
+    if extra:
         out["extra"] = extra
     if rank == 0:
-        print(json.dumps(out))
-    import torch.distributed as dist
+        print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -16,6 +16,8 @@ MAX_N = 12
 MAX_M = 4
 MAX_HORIZON = 64
 OBS_WORDS = 6
+COMM_ID_BYTES = 128
+QF_NONE = 0x7FFFFFFF  # I2LQR_QF_NONE: qfun value of an empty candidate slot
 
 F64, F32 = 0, 1
 LAYOUT_PROBLEM_MAJOR, LAYOUT_BATCH_MINOR, LAYOUT_BATCH_TILED = 0, 1, 2
@@ -154,6 +156,11 @@ EXPORTS = {
                                           C.c_int32, _P, _P, _P, _P]),
     "i2lqr_init_candidates": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P, _P, _P]),
     "i2lqr_pick_best": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_comm_unique_id": (C.c_int, [_P]),
+    "i2lqr_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "i2lqr_comm_destroy": (C.c_int, [_P]),
+    "i2lqr_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "i2lqr_allgather_costs": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
 }
 
 _lib = None

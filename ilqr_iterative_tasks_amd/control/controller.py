@@ -44,14 +44,27 @@ class ControlBase:
         return self.u
 
 
-def _plant_step(x, u, dt):
-    """kinetic_bicycle(): systems/kinetic_bicycle.py:10-27 (host copy for the N <= 1 branch)."""
-    w = x[2] * dt + (u[0] * dt ** 2) / 2
-    return np.array([x[0] + np.cos(x[3]) * w, x[1] + np.sin(x[3]) * w, x[2] + u[0] * dt,
-                     x[3] + u[1] * dt])
+def plant_step(x, u, dt):
+    """One step of the reference plant on the host, x[4], u[2] -> x_next[4]
+    (kinetic_bicycle(), systems/kinetic_bicycle.py:10-27): used by the N <= 1 branch of
+    calc_input and by the lap driver; the batched solves run the same formula on the GPU."""
+    px, py, v, theta = (float(c) for c in x)
+    accel, delta = float(u[0]), float(u[1])
+    travel = v * dt + (accel * dt ** 2) / 2
+    return np.array([px + np.cos(theta) * travel, py + np.sin(theta) * travel, v + accel * dt,
+                     theta + delta * dt])
 
 
 class iLqr(ControlBase):
+    """State kept between control steps:
+      safe set        ss[lap] = states [n, T], u_ss[lap] = inputs [m, T-1], Qfun[lap] = steps to go
+      iter            number of laps in the safe set;  iter_cost[lap] = its length in steps
+      num_horizon     current horizon (shrinks near the end of a lap, utils/base.py:472-478)
+      x_pred, u_pred  the plan chosen by the last calc_input;  u_old = its tail, replayed while
+                      the horizon shrinks;  x_terminal_guess = its last state
+    The reference's LMPC-only bookkeeping (old_cost, cost_improve, ss_point_selected_id, ...) is not
+    part of the i2LQR path and is not kept."""
+
     def __init__(self, ilqr_param, obstacle=None, system_param=None, solver=None,
                  lamb_mode="chained", verbose=False, device_rounds=False):
         ControlBase.__init__(self)
@@ -59,69 +72,43 @@ class iLqr(ControlBase):
         # device_rounds: run the three outer rounds (select / solve / relaxed cost / pick) on the
         # GPU with one read-back per control step (control/device_round.py; independent lamb)
         assert not device_rounds or lamb_mode == "independent"
-        self.device_rounds = device_rounds
-        self._rounds = None
         self.ilqr_param = ilqr_param
         self.system_param = system_param
-        self.ss = []
-        self.u_ss = []
-        self.Qfun = []
-        self.ss_point_selected_id = []
-        self.x_terminal_guess = None
-        self.x_guess = None
-        self.iter = 0
-        self.iter_cost = []
-        self.cost = None
-        self.old_cost = None
-        self.old_iter = None
-        self.u_old = None
-        self.x_pred = None
-        self.u_pred = None
-        self.cost_improve = None
-        self.num_horizon = self.ilqr_param.num_horizon
-        self.matrix_Qterminal = self.ilqr_param.matrix_Qterminal
-        self.matrix_Q = self.ilqr_param.matrix_Q
-        self.matrix_R = self.ilqr_param.matrix_R
-        self.obstacle = obstacle
+        self.obstacle = obstacle          # public: scenario scripts swap it between laps
         self.lamb_mode = lamb_mode
+        self.device_rounds = device_rounds
         self.verbose = verbose
         self._solver = solver
+        self._rounds = None
+        self.ss, self.u_ss, self.Qfun, self.iter_cost = [], [], [], []
+        self.iter = 0
+        self.cost = None
+        self.num_horizon = ilqr_param.num_horizon
+        self.x_pred = self.u_pred = self.u_old = None
+        self.x_guess = self.x_terminal_guess = None
         self.last_round = None  # diagnostics of the most recent calc_input (tests)
 
     # -- safe set ---------------------------------------------------------------------------
     def select_close_ss(self, iter, x0):
-        """k nearest safe-set columns in the 1-norm: utils/base.py:332-341."""
-        x = self.ss[iter]
-        diff = x - np.asarray(x0, float).reshape(-1, 1)
-        norm = np.linalg.norm(diff, 1, axis=0)
-        index_min_norm = np.argsort(norm)
-        return index_min_norm[0: self.ilqr_param.num_ss_points]
+        """The num_ss_points columns of lap `iter` nearest to x0 in the 1-norm, nearest first
+        (utils/base.py:332-341; stable order on ties, like np.argsort)."""
+        dist = np.abs(self.ss[iter] - np.asarray(x0, float)[:, None]).sum(axis=0)
+        return np.argsort(dist)[: self.ilqr_param.num_ss_points]
 
     def add_trajectory(self, x, u):
-        """utils/base.py:343-369.  x[T, n], u[T-1, m] of a finished lap."""
-        self.ss.append(deepcopy(x.T))
-        self.u_ss.append(deepcopy(u.T))
-        self.Qfun.append(deepcopy(np.arange(x.shape[0] - 1, -1, -1)))
+        """A finished lap x[T, n], u[T-1, m] joins the safe set (utils/base.py:343-369): its
+        states, its inputs and the cost-to-go of every state in steps; the horizon is reset to
+        its full length."""
+        states, inputs = np.array(x, float).T, np.array(u, float).T  # own copies, time last
+        steps = states.shape[1] - 1
+        self.ss.append(states)
+        self.u_ss.append(inputs)
+        self.Qfun.append(np.arange(steps, -1, -1))
+        self.iter_cost.append(steps)
+        self.cost = steps
+        self.iter += 1
         self.num_horizon = self.ilqr_param.num_horizon
-        self.x_terminal_guess = x.T[:, self.num_horizon]
-        self.cost = self.Qfun[-1][0]
-        self.iter_cost.append(deepcopy(self.cost))
-        self.old_cost = self.cost + 1
-        self.old_iter = self.iter
-        self.x_sol = x.T[:, 0: (self.num_horizon + 1)]
-        self.u_sol = u.T[:, 0: (self.num_horizon)]
-        self.cost_improve = -1
-        self.iter = self.iter + 1
-        self.ss_point_selected_id = []
-        min_cost = np.min(self.iter_cost)
-        for id in range(self.iter):
-            iter_cost = np.shape(self.ss[id])[1] - 1
-            if self.ilqr_param.all_ss_point:
-                self.ss_point_selected_id.append(np.arange(0, self.ss[id].shape[1]))
-            else:
-                self.ss_point_selected_id.append(np.arange(
-                    iter_cost - min_cost + self.num_horizon,
-                    iter_cost - min_cost + self.num_horizon + self.ilqr_param.num_ss_points))
+        self.x_terminal_guess = states[:, self.num_horizon]
 
     # -- solve --------------------------------------------------------------------------------
     def _get_solver(self):
@@ -177,6 +164,12 @@ class iLqr(ControlBase):
                  for c, j in enumerate(idx)] for a, (lap, idx) in enumerate(candidates)]
         return cost, U, X
 
+    def _device_rounds_ok(self, min_iter):
+        from .device_round import DeviceRounds
+        if self._rounds is None:
+            self._rounds = DeviceRounds()
+        return DeviceRounds.supports(self, range(min_iter, self.iter))
+
     def calc_input(self):
         """utils/base.py:371-479."""
         p = self.ilqr_param
@@ -189,10 +182,7 @@ class iLqr(ControlBase):
             self.u = self.u_pred[:, 0]
             self.u_old = self.u_pred[:, 1:]
             self.num_horizon = self.num_horizon - 1
-        elif self.device_rounds and self.num_horizon > 1:
-            if self._rounds is None:
-                from .device_round import DeviceRounds
-                self._rounds = DeviceRounds()
+        elif self.device_rounds and self.num_horizon > 1 and self._device_rounds_ok(min_iter):
             laps = list(range(min_iter, self.iter))
             self.u_pred, self.x_pred, (best_loc, best_time), idx = self._rounds.run(self, laps)
             self.u = self.u_pred[:, 0]
@@ -218,7 +208,7 @@ class iLqr(ControlBase):
                             uvar = np.zeros((U_DIM, num_horizon))
                             xvar = np.zeros((X_DIM, num_horizon + 1))
                             xvar[:, 0] = self.x
-                            x_next = _plant_step(np.asarray(self.x, float), self.u_old[:, 0],
+                            x_next = plant_step(np.asarray(self.x, float), self.u_old[:, 0],
                                                  self.timestep)
                             xvar[:, -1] = x_next
                             uvar[:, 0] = self.u_old[:, 0]

@@ -52,6 +52,15 @@ class DeviceRounds:
             self.device)
         self._ss_key = key
 
+    @staticmethod
+    def supports(ctrl, laps) -> bool:
+        """The device rounds solve a fixed k candidates per lap; a lap with fewer than k states
+        (never the case for a real lap: the fastest ones are > 20 steps) yields fewer candidates in
+        the host path (utils/base.py:332-341), whose list-of-lists pick then compares lists of
+        different lengths — the controller falls back to host rounds for such a safe set."""
+        k = int(ctrl.ilqr_param.num_ss_points)
+        return all(ctrl.ss[l].shape[1] >= k for l in laps)
+
     def _plan(self, ctrl, laps, solver, cfg):
         """Static buffers + (optionally) the captured graph for one (config, safe set, obstacle
         on/off) combination."""

@@ -2,13 +2,17 @@
 // kernel dispatch.  No exception crosses the boundary; every entry point returns an int code and
 // records a thread-local message for i2lqr_last_error().
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound at run time (rccl_api())
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_set>
 
 #include "../../include/i2lqr.h"
 #include "i2lqr_lane.hpp"
@@ -541,6 +545,14 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
 
 int prepare_dispatch(i2lqr_handle* h) { I2LQR_DISPATCH(h, prepare(h)); }
 
+// Live handles: i2lqr_destroy of NULL is a no-op, of a pointer that is not (or no longer) a live
+// handle an error code instead of a double free.
+std::mutex g_live_mu;
+std::unordered_set<const i2lqr_handle*>& live_handles() {
+  static std::unordered_set<const i2lqr_handle*> set;
+  return set;
+}
+
 int check_common(const i2lqr_handle* h, int64_t B) {
   if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
   if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
@@ -628,6 +640,56 @@ __global__ __launch_bounds__(256) void k_argmin_final(int nparts, const MinPair<
     *best_cost = si[0] >= 0 ? sv[0] : (T)INFINITY;
   }
 }
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------
+// The one collective of the path is an all-gather of the candidates' terminal
+// costs.  libi2lqr_hip.so does not link librccl: a process that already carries a copy (PyTorch
+// ships its own librccl.so, the one torch.distributed's "nccl" backend uses) must not get a
+// second one, and single-GPU users need none at all.  The first communicator call looks for a
+// loaded librccl first and loads the ROCm one otherwise.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+      if ((a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!a.lib)
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!a.lib) return a;
+    auto sym = [&](const char* n) { return dlsym(a.lib, n); };
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
+    a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommCount && a.CommUserRank &&
+           a.AllGather && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+
+#define RCCL_TRY(api, expr)                                                                 \
+  do {                                                                                      \
+    ncclResult_t r_ = (expr);                                                               \
+    if (r_ != ncclSuccess)                                                                  \
+      return fail(I2LQR_ERR_LAUNCH, "%s failed: %s", #expr, (api).GetErrorString(r_));      \
+  } while (0)
 
 constexpr int kArgminBlocks = 256;
 constexpr int64_t kArgminSingle = 16384;  // up to here a single workgroup scans the vector
@@ -751,12 +813,23 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
     delete h;
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    live_handles().insert(h);
+  }
   *out = h;
   g_err[0] = 0;
   return I2LQR_OK;
 }
 
 int i2lqr_destroy(i2lqr_handle* h) {
+  if (!h) return I2LQR_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    if (live_handles().erase(h) == 0)
+      return fail(I2LQR_ERR_INVALID, "i2lqr_destroy: %p is not a live handle (destroyed twice?)",
+                  (void*)h);
+  }
   delete h;
   return I2LQR_OK;
 }
@@ -894,7 +967,7 @@ int64_t i2lqr_argmin_workspace_bytes(int64_t B) {
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
                  void* best_cost, void* workspace, void* stream) {
   if (int rc = check_common(h, B)) return rc;
-  if (!cost_it || !best_idx || !best_cost || !workspace)
+  if ((B > 0 && !cost_it) || !best_idx || !best_cost || !workspace)
     return fail(I2LQR_ERR_INVALID, "null buffer");
   hipStream_t s = (hipStream_t)stream;
   int64_t want = (B + 255) / 256;
@@ -988,6 +1061,66 @@ int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, 
                        (const float*)cost_it, (const float*)X, (const float*)U, best,
                        (float*)x_pred, (float*)u_pred);
   HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int i2lqr_comm_unique_id(void* id) {
+  if (!id) return fail(I2LQR_ERR_INVALID, "null id buffer");
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  static_assert(sizeof(ncclUniqueId) == I2LQR_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId uid;
+  RCCL_TRY(api, api.GetUniqueId(&uid));
+  std::memcpy(id, &uid, sizeof(uid));
+  return I2LQR_OK;
+}
+
+int i2lqr_comm_create(const void* id, int32_t world, int32_t rank, void** comm) {
+  if (!id || !comm) return fail(I2LQR_ERR_INVALID, "null argument");
+  *comm = nullptr;
+  if (world < 1 || rank < 0 || rank >= world)
+    return fail(I2LQR_ERR_INVALID, "need 0 <= rank < world (got rank %d, world %d)", rank, world);
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t c = nullptr;
+  RCCL_TRY(api, api.CommInitRank(&c, world, uid, rank));  // binds the calling thread's device
+  *comm = (void*)c;
+  return I2LQR_OK;
+}
+
+int i2lqr_comm_destroy(void* comm) {
+  if (!comm) return I2LQR_OK;
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  RCCL_TRY(api, api.CommDestroy((ncclComm_t)comm));
+  return I2LQR_OK;
+}
+
+int i2lqr_comm_info(void* comm, int32_t* world, int32_t* rank) {
+  if (!comm || !world || !rank) return fail(I2LQR_ERR_INVALID, "null argument");
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  int w = 0, r = 0;
+  RCCL_TRY(api, api.CommCount((ncclComm_t)comm, &w));
+  RCCL_TRY(api, api.CommUserRank((ncclComm_t)comm, &r));
+  *world = w;
+  *rank = r;
+  return I2LQR_OK;
+}
+
+int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, void* cost_all,
+                          int64_t n_local, void* stream) {
+  if (int rc = check_common(h, n_local)) return rc;
+  if (!comm) return fail(I2LQR_ERR_INVALID, "null communicator");
+  if (n_local == 0) return I2LQR_OK;
+  if (!cost_local || !cost_all) return fail(I2LQR_ERR_INVALID, "null buffer");
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  const ncclDataType_t dt = h->cfg.dtype == I2LQR_F64 ? ncclDouble : ncclFloat;
+  RCCL_TRY(api, api.AllGather(cost_local, cost_all, (size_t)n_local, dt, (ncclComm_t)comm,
+                              (hipStream_t)stream));
   return I2LQR_OK;
 }
 

@@ -9,6 +9,8 @@
 
 namespace i2lqr {
 
+constexpr int32_t kQfNone = 0x7fffffff;  // I2LQR_QF_NONE: "no candidate in this slot"
+
 // k nearest safe-set columns in the 1-norm for each of L laps, and the gather of the candidates:
 // replaces iLqr.select_close_ss (utils/base.py:332-341: argsort of the column-wise 1-norm, first
 // k) and the candidate set-up x_terminal = ss[id][:, j], cost_terminal = Qfun[id][j] (:411-412).
@@ -18,6 +20,10 @@ namespace i2lqr {
 //   xg     x_guess, element i at xg[i * xg_stride]
 // out: idx[L][k], x_term[L*k][n] (problem-major), qf[L*k].  Ties resolve to the lower column
 // (a stable argsort; numpy's default sort is not stable, exact ties do not occur in practice).
+// A lap with fewer than k valid columns (T[lap] < k; the reference's argsort()[0:k] then simply
+// returns fewer candidates) fills its surplus slots with idx = -1, qf = I2LQR_QF_NONE and a copy of
+// the lap's last valid state (zeros if the lap is empty): i2lqr_relax_cost turns that sentinel into
+// cost +inf, so a surplus slot can never be picked.
 // One workgroup of 128 threads per lap; Tmax <= 1024.
 template <class T>
 __global__ __launch_bounds__(128) void k_select_candidates(int n, int Tmax, int k, const T* ss,
@@ -28,10 +34,10 @@ __global__ __launch_bounds__(128) void k_select_candidates(int n, int Tmax, int 
   __shared__ double red_v[128];
   __shared__ int red_i[128];
   const int lap = blockIdx.x, tid = threadIdx.x;
-  const int Tn = Tl[lap];
+  const int Tn = Tl[lap] < 0 ? 0 : (Tl[lap] > Tmax ? Tmax : Tl[lap]);
   const T* S = ss + (int64_t)lap * n * Tmax;
   for (int j = tid; j < Tmax; j += 128) {
-    double d = INFINITY;
+    double d = NAN;  // padding columns and columns already taken: never picked (NaN compares false)
     if (j < Tn) {
       d = 0.0;
       for (int i = 0; i < n; i++) d += fabs((double)S[i * Tmax + j] - (double)xg[i * xg_stride]);
@@ -61,13 +67,14 @@ __global__ __launch_bounds__(128) void k_select_candidates(int n, int Tmax, int 
       }
       __syncthreads();
     }
-    const int j = red_i[0] < Tn ? red_i[0] : (Tn - 1);  // fewer than k finite columns: repeat last
+    const bool surplus = red_i[0] >= Tn;  // the lap has no r-th nearest column
+    const int j = surplus ? (Tn > 0 ? Tn - 1 : 0) : red_i[0];
     if (tid == 0) {
-      idx[lap * k + r] = j;
-      qf[lap * k + r] = qfun[(int64_t)lap * Tmax + j];
-      dist[j] = INFINITY;  // remove from the next round (kept INFINITY if already)
+      idx[lap * k + r] = surplus ? -1 : j;
+      qf[lap * k + r] = surplus ? kQfNone : qfun[(int64_t)lap * Tmax + j];
+      if (!surplus) dist[j] = NAN;  // remove from the next round
     }
-    if (tid < n) x_term[(int64_t)(lap * k + r) * n + tid] = S[tid * Tmax + j];
+    if (tid < n) x_term[(int64_t)(lap * k + r) * n + tid] = Tn > 0 ? S[tid * Tmax + j] : T(0);
     __syncthreads();
   }
 }

@@ -1063,6 +1063,10 @@ __global__ void k_relax_cost(int64_t B, int n, int N, int batch_minor, const T* 
   double scale = 1.0;
   for (int q = 0; q < outer_iter; q++) scale *= 10.0;
   double out = INFINITY;
+  if (qfun[b] == 0x7fffffff) {  // I2LQR_QF_NONE: an empty candidate slot (i2lqr_select_candidates)
+    cost_it[b] = (T)out;
+    return;
+  }
   for (int i = 1; i <= max_relax_iter; i++) {
     if (nrm <= 80.0 * i / scale) { out = (double)qfun[b] + N + 100 * i; break; }
     if (nrm > 80.0 * max_relax_iter / scale) break;

@@ -67,6 +67,65 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
     return torch.cat([gathered[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)])
 
 
+class CostExchange:
+    """The all-gather of the candidates' terminal costs through the C-ABI (i2lqr_allgather_costs:
+    one RCCL ncclAllGather on a communicator the library creates itself).
+
+    The ranks agree on the communicator's unique id through the torch.distributed group that is
+    already up (any backend: the id is 128 bytes of host data, sent with broadcast_object_list);
+    without a process group this is a world of one.  A host language other than Python does the
+    same with i2lqr_comm_unique_id / i2lqr_comm_create and its own side channel."""
+
+    def __init__(self, solver, group=None):
+        import ctypes as C
+        from . import _abi
+        self.solver, self.lib = solver, solver.lib
+        grouped = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if grouped else 1
+        self.rank = dist.get_rank(group) if grouped else 0
+        uid = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        if self.rank == 0:
+            solver._check(self.lib.i2lqr_comm_unique_id(uid))
+        box = [uid.raw]
+        if grouped and self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(solver.device):
+            solver._check(self.lib.i2lqr_comm_create(C.c_char_p(box[0]), self.world, self.rank,
+                                                     C.byref(self._comm)))
+        w, r = C.c_int32(), C.c_int32()
+        solver._check(self.lib.i2lqr_comm_info(self._comm, C.byref(w), C.byref(r)))
+        self.comm_world, self.comm_rank = int(w.value), int(r.value)  # what RCCL itself reports
+
+    def allgather(self, cost_local: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """cost_local[n] on this rank -> cost_all[world * n] in rank order, on the current stream."""
+        import ctypes as C
+        n = cost_local.numel()
+        if out is None:
+            out = torch.empty(n * self.world, dtype=cost_local.dtype, device=cost_local.device)
+        if out.numel() != n * self.world or not out.is_contiguous() or not cost_local.is_contiguous():
+            raise ValueError("cost_all must be a contiguous tensor of world * n_local elements")
+        if cost_local.dtype != self.solver.dtype or out.dtype != self.solver.dtype:
+            raise ValueError(f"cost tensors must be {self.solver.dtype}")
+        with torch.cuda.device(self.solver.device):
+            self.solver._check(self.lib.i2lqr_allgather_costs(
+                self.solver._handle, self._comm, C.c_void_p(cost_local.data_ptr()),
+                C.c_void_p(out.data_ptr()), n, self.solver._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_comm", None) is not None and self._comm.value:
+            torch.cuda.synchronize(self.solver.device)
+            self.lib.i2lqr_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def select_best_flat(cost_all: torch.Tensor) -> tuple[int, float]:
     """Flat arg-min with first-index tie-break (used for the synthetic 10^4..10^6 batches)."""
     val, idx = torch.min(cost_all, dim=0)

@@ -135,13 +135,22 @@ class BatchedILQR:
                                                      self._ws.numel()))
 
     def set_compaction(self, min_batch: int) -> None:
-        """Opt into the chunked, compacting form of solve() from `min_batch` problems (lane
-        layouts; off by default — see include/i2lqr.h)."""
+        """Threshold of the chunked, compacting form of solve() on the lane layouts
+        (i2lqr_set_compaction in include/i2lqr.h): min_batch > 0 explicit, 0 never (single launch),
+        < 0 automatic — the handle's default: chunked from 4096 problems when max_iter > 16, with
+        the last <= 2048 survivors finished by the one-problem-per-wavefront kernel ("wave_tail").
+        The chunks alone are bit-identical to the single launch; with the wave tail the outputs
+        agree to 1e-8 (fp64), not bit for bit: for bit-reproducibility against the single launch
+        call set_compaction(0) or set_option("wave_tail", 0).  The chunked form always runs with
+        in-place candidate states and stored nominal states ("defer_states" / "reroll_nominal"
+        overrides apply to the single launch only)."""
         self._check(self.lib.i2lqr_set_compaction(self._handle, int(min_batch)))
 
     def set_option(self, name: str, value: int) -> None:
-        """Scheduling options of the lane kernels (include/i2lqr.h: "defer_states",
-        "reroll_nominal", "lds_gain_steps"); -1 restores the automatic choice."""
+        """Scheduling options (i2lqr_set_option in include/i2lqr.h); -1 restores the automatic
+        choice.  Lane layouts: "defer_states", "reroll_nominal", "lds_gain_steps", "wave_tail";
+        problem-major layout: "per_step_jacobians".  All but "wave_tail" leave the
+        results bit-identical."""
         self._check(self.lib.i2lqr_set_option(self._handle, name.encode(), int(value)))
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:

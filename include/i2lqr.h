@@ -48,6 +48,7 @@ extern "C" {
 #define I2LQR_MAX_M 4
 #define I2LQR_MAX_HORIZON 64
 #define I2LQR_OBS_WORDS 6
+#define I2LQR_QF_NONE 0x7fffffff /* qfun value of an empty candidate slot (i2lqr_select_candidates) */
 
 /* cfg.dtype */
 enum { I2LQR_F64 = 0, I2LQR_F32 = 1 };
@@ -121,6 +122,8 @@ int i2lqr_config_default(i2lqr_config* cfg, int system_id, int num_horizon);
 /* Validate the config, upload it to the device and size internal state.  No user-visible memory
  * is allocated.  One handle per stream; a handle is not thread-safe. */
 int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
+/* i2lqr_destroy(NULL) is a no-op (I2LQR_OK); a pointer that is not a live handle of this library —
+ * e.g. a second destroy of the same handle — returns I2LQR_ERR_INVALID and frees nothing. */
 int i2lqr_destroy(i2lqr_handle* h);
 
 /*
@@ -244,11 +247,37 @@ int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_te
  * Flat arg-min over cost_it[B] with first-index tie-break (the reduction the all-gather feeds;
  * utils/base.py:462-465 applies it per lap, see the Python host for the list-of-lists form).
  * Out (device): best_idx[1] (int64), best_cost[1] (`real`).  `workspace` must hold
- * i2lqr_argmin_workspace_bytes(B) bytes.
+ * i2lqr_argmin_workspace_bytes(B) bytes.  If no element can win — B == 0, or every cost is NaN —
+ * best_idx = -1 and best_cost = +inf (Python's min() of an empty list raises instead).
  */
 int64_t i2lqr_argmin_workspace_bytes(int64_t B);
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
                  void* best_cost, void* workspace, void* stream);
+
+/*
+ * The one collective of the path (multi-GPU): all-gather of the per-candidate
+ * terminal costs, one RCCL ncclAllGather over xGMI.  Rank r owns a contiguous shard of n_local
+ * candidates; afterwards every rank holds cost_all[world * n_local] in rank order and evaluates
+ * the pick (utils/base.py:462-469; i2lqr_argmin for the flat form) locally.  The reference runs
+ * its candidates sequentially in one process and has no counterpart.
+ *
+ * `comm` is an RCCL communicator (ncclComm_t passed as void*): either the caller's own, or one
+ * made by the helpers below, which wrap ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy so
+ * that a host language needs no second binding.  i2lqr_comm_unique_id fills I2LQR_COMM_ID_BYTES
+ * bytes on ONE rank; the caller distributes them to all ranks (any side channel) and every rank
+ * calls i2lqr_comm_create(id, world, rank, &comm) with its GPU current (hipSetDevice).  RCCL is
+ * bound at run time: a librccl already loaded in the process is used, else the ROCm one;
+ * I2LQR_ERR_UNSUPPORTED if neither is available.
+ * cost_local[n_local] and cost_all[world * n_local] are device buffers of `real`; the collective
+ * is enqueued on `stream`.
+ */
+#define I2LQR_COMM_ID_BYTES 128
+int i2lqr_comm_unique_id(void* id);
+int i2lqr_comm_create(const void* id, int32_t world, int32_t rank, void** comm);
+int i2lqr_comm_destroy(void* comm);
+int i2lqr_comm_info(void* comm, int32_t* world, int32_t* rank);
+int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, void* cost_all,
+                          int64_t n_local, void* stream);
 
 /*
  * Controller round on the device (problem-major layout).
@@ -259,6 +288,9 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
  *   ss[L][n][Tmax] (`real`, component-major, time contiguous, padded), T[L], qfun[L][Tmax] (int32),
  *   x_guess: element i at x_guess[i * guess_stride]  (so X_pred[:, N] can be passed in place).
  *   out: idx[L][k] (int32), x_term[L*k][n], qf[L*k] (int32).   Tmax <= 1024, k <= Tmax.
+ *   A lap with T[l] < k has only T[l] candidates (the reference's argsort()[0:k] returns fewer):
+ *   its surplus slots get idx = -1, qf = I2LQR_QF_NONE and a copy of the lap's last state, and
+ *   i2lqr_relax_cost gives a slot with qfun == I2LQR_QF_NONE the cost +inf, so it is never picked.
  * i2lqr_init_candidates — uvar = 0, xvar[:, 0] = x0, lamb = lamb0 for B candidates (:393, :405-408).
  * i2lqr_pick_best — the pick of utils/base.py:462-469 on cost_it[L][k] (lexicographic over the
  *   laps' lists, then first minimum); copies the winner's X, U to x_pred[n][N+1], u_pred[m][N];

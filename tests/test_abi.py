@@ -72,9 +72,19 @@ def test_invalid_configs_are_error_codes_not_crashes():
     rc = lib.i2lqr_create(C.byref(cfg), C.byref(handle))
     assert rc in (0, -4)
     if rc == 0:
-        lib.i2lqr_destroy(handle)
+        assert lib.i2lqr_destroy(handle) == 0
+        assert lib.i2lqr_destroy(handle) == -1  # second destroy: an error code, not a double free
+        assert b"not a live handle" in lib.i2lqr_last_error()
     else:
         assert b"no HIP device" in lib.i2lqr_last_error()
+
+
+def test_destroy_of_null_and_of_foreign_pointers():
+    lib = _abi.load_library()
+    assert lib.i2lqr_destroy(C.c_void_p(None)) == 0
+    junk = C.create_string_buffer(64)
+    assert lib.i2lqr_destroy(C.cast(junk, C.c_void_p)) == -1
+    assert b"not a live handle" in lib.i2lqr_last_error()
 
 
 def test_missing_extension_fails_loudly(tmp_path):

@@ -67,3 +67,53 @@ def test_single_process_world_is_a_noop():
     t = torch.arange(5, dtype=torch.float64)
     assert idist.allgather_costs(t) is t
     assert idist.select_best_flat(torch.tensor([5.0, 2.0, 2.0, 9.0])) == (1, 2.0)
+
+
+# -- bench.py's own multi-rank path -----------------------------------------------------------------
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(root / "bench.py"), *argv], capture_output=True,
+                          text=True, timeout=600, cwd=str(root), env=e)
+
+
+def test_bench_gpus2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher) must start two ranks on its own and report
+    n_gpus = 2.  On this GPU-less box the solve cannot run, so the same launcher / process-group /
+    barrier / all-gather / pick / max-over-ranks path is driven with --exchange-only (gloo)."""
+    import json
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", "--exchange-only", "--batch", "257")
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["config"]["global_batch"] == 514 and d["config"]["backend"] == "gloo"
+    assert d["value"] > 0 and "exchange-only" in d["metric"]
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """Under a launcher whose world is not --gpus the bench exits non-zero instead of printing an
+    n_gpus = 1 line."""
+    out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--exchange-only",
+                 env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(_free_port())))
+    assert out.returncode == 2
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_without_gpu_fails_loudly():
+    """No HIP device and no --exchange-only: an error, never a CPU fallback of the solver."""
+    out = _bench("--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline")
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by the gpu-marked contract test")
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

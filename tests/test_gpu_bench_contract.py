@@ -33,8 +33,67 @@ def test_bench_json_line_contract():
     assert r["algorithmic_bytes_per_iteration"] == 4968
     assert abs(r["achieved"] - 4968 * 1024 * 10 / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
+    assert r["traffic_stale"] in (True, False) and (r["traffic"] is None or not r["traffic_stale"])
+    ri = d["roofline_issue"]
+    assert ri["bound"] == "issue" and ri["simds_occupied"] == 1024
+    assert abs(ri["peak"] - 1024 * 2.4 / 4) < 1e-9
+    assert ri["frac"] is None or 0 < ri["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_under_torchrun_world_of_one_uses_the_native_rccl_exchange():
+    """The driver's N > 1 command form with one rank (all this box has): RCCL process group,
+    communicator created through the C-ABI, i2lqr_allgather_costs on the side stream, pick checked
+    against the gathered vector inside bench.py; the strong-scaled configs[3] line beside it."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+                          str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "5",
+                          "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["exchange"]["nccl_world"] == 1
+    assert "i2lqr_allgather_costs" in d["exchange"]["path"] and d["exchange"]["ms_per_step"] > 0
+    assert d["exchange"]["bytes_per_rank"] == 8192
+    assert len(d["per_rank_iterations_per_s"]) == 1
+    s4 = d["extra"]["config4_strong"]
+    assert s4["global_batch"] == 1 << 20 and s4["batch_per_gpu"] == 1 << 20
+    assert s4["nccl_world"] == 1 and s4["iterations_per_s"] > 1e8
+
+
+def test_bench_mismatched_world_exits_nonzero():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    # one GPU here: the two ranks cannot both get a device -> the launcher reports the failure
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_native_allgather_matches_torch_world_of_one():
+    """i2lqr_comm_* / i2lqr_allgather_costs without any process group: a world of one."""
+    import torch
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config
+    from ilqr_iterative_tasks_amd.dist import CostExchange
+    for dtype in ("f64", "f32"):
+        solver = BatchedILQR(default_config("bicycle4", 6, dtype))
+        ex = CostExchange(solver)
+        assert (ex.world, ex.rank, ex.comm_world, ex.comm_rank) == (1, 0, 1, 0)
+        cost = torch.rand(4099, dtype=solver.dtype, device=solver.device)
+        out = ex.allgather(cost)
+        torch.cuda.synchronize()
+        assert torch.equal(out, cost) and out.data_ptr() != cost.data_ptr()
+        with pytest.raises(ValueError):
+            ex.allgather(cost, torch.zeros(5, dtype=solver.dtype, device=solver.device))
+        ex.close()
+        solver.close()
 
 
 def test_graft_entry_smoke():

@@ -3,21 +3,22 @@ against the reference's config-1 closed loop (BASELINE configs[0]; golden G5 / G
 import numpy as np
 import pytest
 
-from helpers import batch_rel_err
+from helpers import SCENARIOS, batch_rel_err, check_scenario
 from ilqr_iterative_tasks_amd import harness
 from ilqr_iterative_tasks_amd.control import KineticBicycleParam, Obstacle, iLqr, iLqrParam, ilqr
+from ilqr_iterative_tasks_amd.control.controller import plant_step
 
 pytestmark = pytest.mark.gpu
 
 
-def build(lamb_mode, device_rounds=False):
+def build(lamb_mode, device_rounds=False, obstacle=Obstacle(31, -3, 8, 6)):
     ego = harness.KineticBicycle(system_param=KineticBicycleParam())
     ego.set_state(np.zeros(4))
     ego.set_timestep(1)
     ego.get_traj()
     ego.set_zero_noise()
     param = iLqrParam(num_ss_points=8, num_ss_iter=2, timestep=1, num_horizon=6)
-    ctrl = iLqr(param, obstacle=Obstacle(31, -3, 8, 6), system_param=KineticBicycleParam(),
+    ctrl = iLqr(param, obstacle=obstacle, system_param=KineticBicycleParam(),
                 lamb_mode=lamb_mode, device_rounds=device_rounds)  # default solver = HIP
     ctrl.add_trajectory(ego.xcl, ego.ucl)
     ctrl.set_timestep(1)
@@ -39,6 +40,19 @@ def test_closed_loop_config1_on_gpu_chained(golden_dir):
     laps = harness.run_laps(ego, ctrl, 3)
     assert laps == [121, 54, 29, 23]
     assert np.abs(np.stack(us) - g5["step_u"]).max() < 1e-6
+    assert all(int(f) == 1 for lap in ego.diagnostics["feasibility"] for f in np.ravel(lap))
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_paper_scenarios_on_gpu(golden_dir, name):
+    """the five paper scenarios of iterative_ilqr/result/ilqr_test_*.py (no
+    obstacle, large static obstacle, obstacle added at lap 5 and removed at lap 6, obstacle moving
+    up / left: result/ilqr_test_add_moving_obstacle.py:18-31, :63-75) driven through the HIP
+    controller (chained lamb = the reference's semantics): lap lengths equal the reference's
+    exactly, last lap within 2e-3 (golden G8)."""
+    ob0 = SCENARIOS[name][1]
+    ego, ctrl = build("chained", obstacle=None if ob0 is None else Obstacle(*ob0))
+    check_scenario(golden_dir, name, ego, ctrl)
     assert all(int(f) == 1 for lap in ego.diagnostics["feasibility"] for f in np.ravel(lap))
 
 
@@ -106,6 +120,57 @@ def test_select_and_pick_kernels_against_host_logic(golden_dir):
         assert torch.equal(xp, X[w]) and torch.equal(up, U[w])
 
 
+def test_select_with_fewer_columns_than_candidates_and_empty_argmin(golden_dir):
+    """A lap with T < k columns has only T candidates (the reference's argsort()[0:k] returns
+    fewer): the surplus slots are marked (idx -1, qf I2LQR_QF_NONE), get the relaxed cost +inf and
+    never win the pick; an empty lap (T = 0) reads nothing out of bounds.  The controller itself
+    falls back to host rounds for such a safe set.  i2lqr_argmin of an empty / all-NaN vector
+    returns (-1, +inf) as the header says."""
+    import torch
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config
+    from ilqr_iterative_tasks_amd._abi import QF_NONE
+    from ilqr_iterative_tasks_amd.control.device_round import DeviceRounds
+    g7 = np.load(golden_dir / "g7_dynamics.npz")
+    traj = g7["closed_loop_feasible"]
+    solver = BatchedILQR(default_config("bicycle4", 6))
+    dev = solver.device
+    Tmax, k = 16, 8
+    ss = np.zeros((3, 4, Tmax))
+    ss[0, :, :16] = traj[:16].T
+    ss[1, :, :5] = traj[40:45].T          # 5 < k columns
+    ss[1, :, 5:] = np.nan                 # padding must never be read as data
+    ss = torch.as_tensor(ss).to(dev)
+    T = torch.tensor([16, 5, 0], dtype=torch.int32, device=dev)
+    qfun = torch.arange(Tmax - 1, -1, -1, dtype=torch.int32, device=dev).repeat(3, 1).contiguous()
+    idx = torch.zeros(3, k, dtype=torch.int32, device=dev)
+    x_term = torch.zeros(3 * k, 4, dtype=torch.float64, device=dev)
+    qf = torch.zeros(3 * k, dtype=torch.int32, device=dev)
+    xg = traj[42]
+    solver.select_candidates(ss, T, qfun, torch.as_tensor(xg).to(dev), 1, k, idx, x_term, qf)
+    got = idx.cpu().numpy()
+    want0 = np.argsort(np.abs(traj[:16] - xg).sum(1), kind="stable")[:k]
+    want1 = np.argsort(np.abs(traj[40:45] - xg).sum(1), kind="stable")
+    assert (got[0] == want0).all()
+    assert (got[1, :5] == want1).all() and (got[1, 5:] == -1).all() and (got[2] == -1).all()
+    q = qf.cpu().numpy().reshape(3, k)
+    assert (q[1, 5:] == QF_NONE).all() and (q[2] == QF_NONE).all() and (q[1, :5] == 15 - want1).all()
+    assert torch.isfinite(x_term).all()
+    X = torch.zeros(3 * k, 4, 7, dtype=torch.float64, device=dev)
+    X[:, :, -1] = x_term  # every candidate "reaches" its target: finite relaxed cost unless empty
+    cost = solver.relax_cost(X, x_term, qf, 0).cpu().numpy().reshape(3, k)
+    assert np.isfinite(cost[0]).all() and np.isfinite(cost[1, :5]).all()
+    assert np.isinf(cost[1, 5:]).all() and np.isinf(cost[2]).all()
+
+    class Ctrl:  # what DeviceRounds.supports() looks at
+        ss = [np.zeros((4, 16)), np.zeros((4, 5))]
+        ilqr_param = iLqrParam(num_ss_points=8)
+    assert DeviceRounds.supports(Ctrl, [0]) and not DeviceRounds.supports(Ctrl, [0, 1])
+    i0, v0 = solver.argmin(torch.zeros(0, dtype=torch.float64, device=dev))
+    assert int(i0) == -1 and np.isinf(float(v0))
+    i1, v1 = solver.argmin(torch.full((300,), float("nan"), dtype=torch.float64, device=dev))
+    assert int(i1) == -1 and np.isinf(float(v1))
+
+
 def test_ilqr_dropin_signature_matches_reference_calls(golden_dir):
     """`uvar, xvar, lamb = ilqr(ilqr_param, num_horizon, xtarget, timestep, obstacle,
     system_param, x_terminal, dX, uvar, xvar, lamb)` — utils/base.py:414-426."""
@@ -122,3 +187,18 @@ def test_ilqr_dropin_signature_matches_reference_calls(golden_dir):
         assert batch_rel_err(x[None], g["X"][i][None]) < 1e-8
         assert batch_rel_err(u[None], g["U"][i][None], floor=1e-2) < 1e-8
         np.testing.assert_array_equal(dX[:, 1:], x[:, 1:])
+        # the caller's own arrays are left as the reference's first iteration leaves them
+        # (control/iterative_ilqr.py:33-42): clipped initial inputs and their rollout
+        roll = [g["x0"][i]]
+        for t in range(6):
+            roll.append(plant_step(roll[-1], [0.0, 0.0], 1))
+        assert (uvar == 0).all() and x is not xvar and u is not uvar
+        np.testing.assert_allclose(xvar, np.array(roll).T, rtol=1e-13, atol=1e-13)
+    # inputs outside the box are clipped in place (a_max = 2, round(pi/2, 2) = 1.57)
+    uvar, xvar, dX = 3.0 * np.ones((2, 6)), np.zeros((4, 7)), np.zeros((4, 7))
+    ilqr(param, 6, np.zeros(4), 1, None, sysp, g["x_term"][0], dX, uvar, xvar, 1.0)
+    np.testing.assert_array_equal(uvar, np.array([[2.0] * 6, [1.57] * 6]))
+    roll = [np.zeros(4)]
+    for t in range(6):
+        roll.append(plant_step(roll[-1], [2.0, 1.57], 1))
+    np.testing.assert_allclose(xvar, np.array(roll).T, rtol=1e-13, atol=1e-13)

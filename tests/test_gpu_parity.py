@@ -170,6 +170,22 @@ def test_function_level_vs_oracle(torch_mod, system, N, dt, B, layout):
     np.testing.assert_allclose(cn.cpu().numpy(), cn_o, rtol=1e-10)
 
 
+def _check_flipped(buf, ref, same, cost_tol):
+    """Problems whose accept / reject history differs from the oracle's (a cost comparison decided
+    at round-off level went the other way) are excluded from the trajectory comparison — but not
+    from scrutiny: the branch that was taken instead must be as good.  Their returned cost must
+    agree with the oracle's to `cost_tol` (relative) and their status must be a legal exit."""
+    if same.all():
+        return
+    cost = buf["cost"].double().cpu().numpy()[~same]
+    want = ref["cost"][~same]
+    assert np.isfinite(cost).all()
+    rel = np.abs(cost - want) / np.maximum(np.abs(want), 1e-300)
+    assert rel.max() <= cost_tol, f"flipped problems: cost off by {rel.max():.3e} (> {cost_tol})"
+    st = buf["status"].cpu().numpy()[~same]
+    assert set(np.unique(st)) <= {0, 1, 2, 3}, np.unique(st)
+
+
 @pytest.mark.parametrize("system,N,dt,B,iters", [("bicycle6", 20, 0.25, 1024, 10),
                                                  ("bicycle4", 6, 1.0, 512, 10),
                                                  ("quad12", 50, 0.02, 64, 4)])
@@ -187,6 +203,8 @@ def test_iterate_vs_oracle(torch_mod, system, N, dt, B, iters, layout):
     same = lamb == ref["lamb"]
     # an accept/reject decided by a cost difference at round-off level may flip; it must be rare
     assert same.mean() > 0.99, f"{(~same).sum()} of {B} problems took a different branch"
+    # ... and where it flips the two branches are equally good: same cost to 1e-6
+    _check_flipped(buf, ref, same, 1e-6)
     for key in ("X", "U"):
         assert batch_rel_err(to_host(solver, buf[key])[same], ref[key][same]) < TOL_SOLVE, key
     np.testing.assert_allclose(buf["cost"].cpu().numpy()[same], ref["cost"][same], rtol=1e-7)
@@ -206,27 +224,81 @@ def test_solve_vs_oracle_bicycle6(torch_mod, layout):
     buf = solver.solve(dev_batch(solver, host))
     same = (buf["iters"].cpu().numpy() == ref["iters"]) & (buf["lamb"].cpu().numpy() == ref["lamb"])
     assert same.mean() > 0.98
+    # a flipped problem may stop one iteration earlier or later than the oracle: its cost is then
+    # within the convergence threshold eps (control/iterative_ilqr.py:78) of the oracle's
+    _check_flipped(buf, ref, same, cfg.eps)
     assert (buf["status"].cpu().numpy()[same] == ref["status"][same]).all()
     assert batch_rel_err(to_host(solver, buf["X"])[same], ref["X"][same]) < TOL_SOLVE
     assert batch_rel_err(to_host(solver, buf["U"])[same], ref["U"][same]) < 1e-7
 
 
-def test_fp32_tracks_fp64_oracle(torch_mod, layout):
-    """BASELINE configs[2] dtype: fp32 gains of one backward pass against the fp64 oracle."""
+# fp32 (BASELINE configs[2]) against the fp64 oracle.  fp32 is narrower than the reference's
+# arithmetic, so this is a stated accuracy, not bit parity:
+#   one backward pass   K: median 1e-4, k: 5e-3 of the input box (24-bit mantissa through a 20-step
+#                       Riccati recursion whose value function spans 4 decades)
+#   iterate(10), solve  returned cost within FP32_COST (relative, or relative to the batch's median
+#                       initial cost for targets reached to ~0) on FP32_AGREE of the problems
+#                       (measured: 99 %) and within 5e-2 on all;
+#                       U within FP32_U of the input box (max |u_max|) on FP32_AGREE of the problems;
+#                       solve(): exit status equal on FP32_AGREE of the problems; iteration counts
+#                       equal on FP32_ITERS of them (measured 94.3 %: at a converged solution
+#                       `cost_new < cost` compares values that agree to fp32 round-off, the tie goes
+#                       either way and the lamb schedule then exits a few iterations apart) and
+#                       never more than 16 apart; every status a legal exit.
+FP32_COST, FP32_U, FP32_AGREE, FP32_ITERS = 1e-3, 1e-2, 0.95, 0.92
+
+
+def _fp32_vs_oracle(solver, cfg, buf, ref, counts):
+    B = len(ref["cost"])
+    cost = buf["cost"].double().cpu().numpy()
+    assert np.isfinite(cost).all()
+    rel = np.abs(cost - ref["cost"]) / np.maximum(np.abs(ref["cost"]), 1e-30)
+    # problems that have converged to cost ~ 0 (a reachable target): compare absolutely at the
+    # scale of the batch's typical initial cost instead
+    scale = np.median(ref["cost0"]) if "cost0" in ref else 1.0
+    rel = np.minimum(rel, np.abs(cost - ref["cost"]) / scale)
+    assert (rel <= FP32_COST).mean() >= FP32_AGREE, (rel <= FP32_COST).mean()
+    assert rel.max() <= 5e-2, rel.max()
+    box = max(list(cfg.u_max)[:cfg.m])
+    du = np.abs(to_host(solver, buf["U"]).astype(np.float64) - ref["U"]).reshape(B, -1).max(1) / box
+    assert (du <= FP32_U).mean() >= FP32_AGREE, (du <= FP32_U).mean()
+    st = buf["status"].cpu().numpy()
+    assert set(np.unique(st)) <= {0, 1, 2, 3}, np.unique(st)
+    if counts:
+        it = buf["iters"].cpu().numpy()
+        assert (it == ref["iters"]).mean() >= FP32_ITERS, (it == ref["iters"]).mean()
+        assert np.abs(it - ref["iters"]).max() <= 16
+        assert it.min() >= 1 and it.max() <= cfg.max_iter
+        assert (st == ref["status"]).mean() >= FP32_AGREE
+
+
+@pytest.mark.parametrize("lay", ["wave", "lane", "tiled"])
+def test_fp32_tracks_fp64_oracle(torch_mod, lay):
+    """BASELINE configs[2] (n=6, m=2, N=20, fp32) inputs: one backward pass, 10 fused iterations
+    and the solve to termination in fp32 against the fp64 oracle, tolerances above."""
     from ilqr_iterative_tasks_amd import workloads
     orc = oracle()
-    solver, cfg = make_solver("bicycle6", 20, "f32", dt=0.25, layout=layout)
-    host = workloads.make_batch(cfg, 2048)
+    solver, cfg = make_solver("bicycle6", 20, "f32", dt=0.25, layout=lay)
+    B = 2048
+    host = workloads.make_batch(cfg, B)
     Xr, Ur, cr = orc.rollout_batch(cfg, host["X"], host["U"], host["x_term"])
     ko, Ko = orc.backward_batch(cfg, Xr, Ur, host["x_term"], host["lamb"], host["obs"])
     k, K = solver.backward(to_dev(solver, Xr), to_dev(solver, Ur), to_dev(solver, host["x_term"]),
                            to_dev(solver, host["lamb"]), to_dev(solver, host["obs"]))
-    # fp32 tolerance: 24-bit mantissa through a 20-step Riccati recursion
-    assert np.median(np.abs(to_host(solver, K) - Ko).reshape(2048, -1).max(1) /
-                     np.abs(Ko).reshape(2048, -1).max(1)) < 1e-4
-    assert batch_rel_err(to_host(solver, k), ko) < 5e-2
+    assert np.median(np.abs(to_host(solver, K) - Ko).reshape(B, -1).max(1) /
+                     np.abs(Ko).reshape(B, -1).max(1)) < 1e-4
+    box = max(list(cfg.u_max)[:cfg.m])
+    assert np.abs(to_host(solver, k) - ko).max() / box < 5e-3
+    ref = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"],
+                         max_iter=10, early_exit=False)
+    ref["cost0"] = cr
     buf = solver.iterate(dev_batch(solver, host), 10)
-    assert np.isfinite(buf["cost"].cpu().numpy()).all()
+    assert (buf["iters"].cpu().numpy() == 10).all()
+    _fp32_vs_oracle(solver, cfg, buf, ref, counts=False)
+    ref = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"])
+    ref["cost0"] = cr
+    buf = solver.solve(dev_batch(solver, host))
+    _fp32_vs_oracle(solver, cfg, buf, ref, counts=True)
 
 
 def test_relax_cost_and_argmin_vs_oracle(torch_mod, layout):
@@ -279,6 +351,63 @@ def test_properties_full_size(torch_mod, dtype, B, layout):
     assert (a["cost"] >= 0).all()
     u_max = torch.tensor(list(cfg.u_max)[:cfg.m], dtype=solver.dtype, device=solver.device)
     assert (solver.to_problem_major(a["U"]).abs() <= u_max[None, :, None]).all()
+
+
+@pytest.mark.parametrize("lay,B", [("wave", 131072), ("lane", 131072), ("tiled", 131072),
+                                   ("lane", 1 << 20), ("tiled", 1 << 20)])
+def test_config4_sizes_properties_and_oracle_sample(torch_mod, lay, B):
+    """BASELINE configs[3]: 2^20 problems over 8 GPUs = 131072 per GPU, and the whole 2^20 on one
+    (fp64, n=6, m=2, N=20).  Size-independent properties over the full batch — determinism, returned
+    X is bit-exactly the rollout of returned U, cost is its terminal cost, inputs inside the box,
+    every problem ran exactly 10 iterations — and the CPU oracle on a strided sample of 512
+    problems that spans the whole index range, so the row addressing above 65536 problems
+    (offsets beyond 2^31 bytes in the batch-minor gains at 2^20) is checked against known answers."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = make_solver("bicycle6", 20, "f64", dt=0.25, layout=lay)
+    host = workloads.make_batch(cfg, B)
+    a = solver.iterate(dev_batch(solver, host), 10)
+    b = solver.iterate(dev_batch(solver, host), 10)
+    for key in ("X", "U", "lamb", "cost", "K", "k"):
+        assert torch.equal(a[key], b[key]), key
+    del b
+    assert int(a["iters"].min()) == 10 == int(a["iters"].max())
+    X2, U2 = a["X"].clone(), a["U"].clone()
+    cost2 = solver.rollout(X2, U2, a["x_term"])
+    assert torch.equal(U2, a["U"]) and torch.equal(X2, a["X"]) and torch.equal(cost2, a["cost"])
+    del X2, U2
+    assert torch.isfinite(a["cost"]).all() and (a["cost"] >= 0).all()
+    u_max = torch.tensor(list(cfg.u_max)[:cfg.m], dtype=solver.dtype, device=solver.device)
+    Upm = solver.to_problem_major(a["U"])
+    assert (Upm.abs() <= u_max[None, :, None]).all()
+    # strided sample incl. the last problem
+    idx = np.unique(np.concatenate([np.arange(0, B, B // 511), [B - 1]]))
+    ref = oracle().ilqr_batch(cfg, host["X"][idx], host["U"][idx], host["x_term"][idx],
+                              host["lamb"][idx], host["obs"][idx], max_iter=10, early_exit=False)
+    tidx = torch.as_tensor(idx, device=solver.device)
+    got = {key: solver.to_problem_major(a[key])[tidx].cpu().numpy() for key in ("X", "U", "K", "k")}
+    sub = {key: a[key][tidx] for key in ("lamb", "cost", "status")}
+    same = sub["lamb"].cpu().numpy() == ref["lamb"]
+    assert same.mean() > 0.99
+    _check_flipped(sub, ref, same, 1e-6)
+    for key in ("X", "U"):
+        assert batch_rel_err(got[key][same], ref[key][same]) < TOL_SOLVE, key
+    np.testing.assert_allclose(sub["cost"].cpu().numpy()[same], ref["cost"][same], rtol=1e-7)
+    assert batch_rel_err(got["K"][same], ref["K"][same]) < 1e-6
+    assert batch_rel_err(got["k"][same], ref["k"][same], floor=1.0) < 1e-6
+    # the solve to termination (chunked + compaction + wave tail on the lane layouts) on the same
+    # batch: every problem ends with a legal status, the sample matches the oracle
+    s = solver.solve(dev_batch(solver, host, want_gains=False))
+    st = s["status"].cpu().numpy()
+    assert set(np.unique(st)) <= {1, 2, 3}
+    ref = oracle().ilqr_batch(cfg, host["X"][idx], host["U"][idx], host["x_term"][idx],
+                              host["lamb"][idx], host["obs"][idx])
+    it = s["iters"][tidx].cpu().numpy()
+    same = (it == ref["iters"]) & (s["lamb"][tidx].cpu().numpy() == ref["lamb"])
+    assert same.mean() > 0.98
+    _check_flipped({key: s[key][tidx] for key in ("cost", "status")}, ref, same, cfg.eps)
+    Xs = solver.to_problem_major(s["X"])[tidx].cpu().numpy()
+    assert batch_rel_err(Xs[same], ref["X"][same]) < TOL_SOLVE
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
