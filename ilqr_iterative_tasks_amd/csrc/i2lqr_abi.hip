@@ -15,6 +15,8 @@
 #include <unordered_set>
 
 #include "../../include/i2lqr.h"
+#include "i2lqr_devcfg.hpp"
+#include "i2lqr_group.h"
 #include "i2lqr_lane.hpp"
 #include "i2lqr_select.hpp"
 #include "i2lqr_wave.hpp"
@@ -40,45 +42,6 @@ int fail(int code, const char* fmt, ...) {
       return fail(I2LQR_ERR_LAUNCH, "%s failed: %s", #expr, hipGetErrorString(e_));        \
   } while (0)
 
-template <class T, int n, int m> DevCfg<T, n, m> make_dev_cfg(const i2lqr_config& h) {
-  DevCfg<T, n, m> d;
-  std::memset(&d, 0, sizeof(d));
-  d.N = h.N;
-  d.max_iter = h.max_iter;
-  d.dt = (T)h.dt;
-  d.eps = (T)h.eps;
-  d.lamb_factor = (T)h.lamb_factor;
-  d.max_lamb = (T)h.max_lamb;
-  d.ctrl_q1 = (T)h.ctrl_q1;
-  d.ctrl_q2 = (T)h.ctrl_q2;
-  d.obs_q1 = (T)h.obs_q1;
-  d.obs_q2 = (T)h.obs_q2;
-  d.safety_margin = (T)h.safety_margin;
-  bool hasQ = false, hasR = false;
-  d.fast_barrier = 1;
-  for (int a = 0; a < m; a++) {
-    d.u_max[a] = (T)h.u_max[a];
-    const double span = 2.0 * h.ctrl_q2 * h.u_max[a];
-    d.ctrl_c[a] = (T)std::exp(-span);
-    if (!(std::fabs(span) < 600.0)) d.fast_barrier = 0;
-  }
-  for (int i = 0; i < n; i++) d.xtarget[i] = (T)h.xtarget[i];
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) {
-      d.Q[i * n + j] = (T)h.Q[i * I2LQR_MAX_N + j];
-      d.Qt[i * n + j] = (T)h.Qt[i * I2LQR_MAX_N + j];
-      hasQ |= h.Q[i * I2LQR_MAX_N + j] != 0.0;
-    }
-  for (int a = 0; a < m; a++)
-    for (int b = 0; b < m; b++) {
-      d.R[a * m + b] = (T)h.R[a * I2LQR_MAX_M + b];
-      hasR |= h.R[a * I2LQR_MAX_M + b] != 0.0;
-    }
-  for (int q = 0; q < 8; q++) d.sys_par[q] = (T)h.sys_par[q];
-  d.flags = (hasQ ? FLAG_HAS_Q : 0) | (hasR ? FLAG_HAS_R : 0);
-  return d;
-}
-
 }  // namespace
 
 struct i2lqr_handle {
@@ -93,6 +56,7 @@ struct i2lqr_handle {
   int opt_defer, opt_reroll, opt_lds_steps;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
+  int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
 };
 
 namespace {
@@ -107,6 +71,7 @@ template <class T, class Sys> struct Launch {
     return (size_t)Layout<Sys>(N, true).total * sizeof(T) * (64 / LANES);
   }
   static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
+  static constexpr int64_t kAutoGroupBatch = 1024;
   static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
@@ -161,6 +126,23 @@ template <class T, class Sys> struct Launch {
 #ifdef I2LQR_STAMPS
     a.dbg = (unsigned long long*)h->ws;  // diagnostic build: caller registers [B][8] u64 here
 #endif
+    // Eight lanes per problem, eight problems per wavefront (i2lqr_group.hpp).  Automatic where it
+    // is built (the bicycles, Q = R = 0) from 1024 problems: below that every problem gets a SIMD
+    // of its own either way and the one-problem-per-wavefront kernel's iteration is ~8 % shorter
+    // (tools/group_ab.py: 0.195 vs 0.212 ms per 10 iterations at 64-256 problems, 0.219 vs 0.213
+    // at 1024, 0.63 vs 0.25 at 4096).
+    if constexpr (m == 2 && n + m <= 8) {
+      const bool can = group_supported(h->cfg);
+      if (h->opt_group == 8 && !can)
+        return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 "
+                    "and a horizon whose eight problem slices fit the 160 KiB of LDS");
+      if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
+        HIP_TRY(group_iterate<T>(h->cfg, a, s));
+        return I2LQR_OK;
+      }
+    } else if (h->opt_group == 8) {
+      return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 is built for the m = 2 plants only");
+    }
     // Per-step F matrices (prep() writes them in parallel over t; the serial recursion then has no
     // Jacobian refresh) double the LDS slice: taken when every wavefront of the launch still fits
     // on the chip at once, i.e. in the latency-bound regime this variant exists for.
@@ -805,7 +787,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
-  h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = -1;
+  h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -871,6 +853,10 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
+  else if (!strcmp(name, "group_lanes")) {
+    if (v != -1 && v != 8 && v != 64) return fail(I2LQR_ERR_INVALID, "\"group_lanes\" is 8, 64 or -1");
+    h->opt_group = v;
+  }
   else return fail(I2LQR_ERR_INVALID, "unknown option '%s'", name);
   return I2LQR_OK;
 }

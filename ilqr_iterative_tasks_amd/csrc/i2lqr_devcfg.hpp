@@ -1,0 +1,51 @@
+// Host side: i2lqr_config (include/i2lqr.h) -> the typed device copy the kernels take by value.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "../../include/i2lqr.h"
+#include "i2lqr_wave.hpp"
+
+namespace i2lqr {
+
+template <class T, int n, int m> inline DevCfg<T, n, m> make_dev_cfg(const i2lqr_config& h) {
+  DevCfg<T, n, m> d;
+  std::memset(&d, 0, sizeof(d));
+  d.N = h.N;
+  d.max_iter = h.max_iter;
+  d.dt = (T)h.dt;
+  d.eps = (T)h.eps;
+  d.lamb_factor = (T)h.lamb_factor;
+  d.max_lamb = (T)h.max_lamb;
+  d.ctrl_q1 = (T)h.ctrl_q1;
+  d.ctrl_q2 = (T)h.ctrl_q2;
+  d.obs_q1 = (T)h.obs_q1;
+  d.obs_q2 = (T)h.obs_q2;
+  d.safety_margin = (T)h.safety_margin;
+  bool hasQ = false, hasR = false;
+  d.fast_barrier = 1;
+  for (int a = 0; a < m; a++) {
+    d.u_max[a] = (T)h.u_max[a];
+    const double span = 2.0 * h.ctrl_q2 * h.u_max[a];
+    d.ctrl_c[a] = (T)std::exp(-span);
+    if (!(std::fabs(span) < 600.0)) d.fast_barrier = 0;
+  }
+  for (int i = 0; i < n; i++) d.xtarget[i] = (T)h.xtarget[i];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      d.Q[i * n + j] = (T)h.Q[i * I2LQR_MAX_N + j];
+      d.Qt[i * n + j] = (T)h.Qt[i * I2LQR_MAX_N + j];
+      hasQ |= h.Q[i * I2LQR_MAX_N + j] != 0.0;
+    }
+  for (int a = 0; a < m; a++)
+    for (int b = 0; b < m; b++) {
+      d.R[a * m + b] = (T)h.R[a * I2LQR_MAX_M + b];
+      hasR |= h.R[a * I2LQR_MAX_M + b] != 0.0;
+    }
+  for (int q = 0; q < 8; q++) d.sys_par[q] = (T)h.sys_par[q];
+  d.flags = (hasQ ? FLAG_HAS_Q : 0) | (hasR ? FLAG_HAS_R : 0);
+  return d;
+}
+
+
+}  // namespace i2lqr

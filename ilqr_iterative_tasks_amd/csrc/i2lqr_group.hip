@@ -1,0 +1,67 @@
+// Instantiations and launcher of the eight-lanes-per-problem kernel (i2lqr_group.hpp).
+#include "i2lqr_group.h"
+
+#include "i2lqr_devcfg.hpp"
+#include "i2lqr_group.hpp"
+
+namespace i2lqr {
+
+namespace {
+
+template <class T, class Sys> size_t group_lds_bytes(int N) {
+  return (size_t)GLayout<Sys>(N).wave_words() * sizeof(T);
+}
+
+bool has_stage_weights(const i2lqr_config& cfg) {
+  for (int i = 0; i < cfg.n; i++)
+    for (int j = 0; j < cfg.n; j++)
+      if (cfg.Q[i * I2LQR_MAX_N + j] != 0.0) return true;
+  for (int a = 0; a < cfg.m; a++)
+    for (int b = 0; b < cfg.m; b++)
+      if (cfg.R[a * I2LQR_MAX_M + b] != 0.0) return true;
+  return false;
+}
+
+template <class T, class Sys>
+hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
+  const size_t lds = group_lds_bytes<T, Sys>(cfg.N);
+  if (lds > 64 * 1024) {
+    static thread_local int raised_for = 0;  // the attribute is per kernel: raise it once per size
+    if (raised_for < (int)lds) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_group_iterate<T, Sys>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      raised_for = (int)lds;
+    }
+  }
+  const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
+  hipLaunchKernelGGL((k_group_iterate<T, Sys>), dim3(grid), dim3(64), lds, s, c, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool group_supported(const i2lqr_config& cfg) {
+  if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
+  if (cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR || has_stage_weights(cfg)) return false;
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<double, Bicycle4<double>>(cfg.N)
+                                             : group_lds_bytes<double, Bicycle6<double>>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<float, Bicycle4<float>>(cfg.N)
+                                             : group_lds_bytes<float, Bicycle6<float>>(cfg.N));
+  return lds <= 160 * 1024;
+}
+
+template <> hipError_t group_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                             hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch<double, Bicycle4<double>>(cfg, a, s);
+  return launch<double, Bicycle6<double>>(cfg, a, s);
+}
+template <> hipError_t group_iterate<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                            hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch<float, Bicycle4<float>>(cfg, a, s);
+  return launch<float, Bicycle6<float>>(cfg, a, s);
+}
+
+}  // namespace i2lqr

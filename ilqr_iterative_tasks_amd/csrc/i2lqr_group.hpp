@@ -1,0 +1,668 @@
+// Eight-lanes-per-problem iLQR kernel for gfx950 (MI355X): eight problems share one wavefront.
+//
+// The one-problem-per-wavefront kernel (i2lqr_wave.hpp) gives each of 64 lanes ONE element of the
+// Riccati step's small products, so every multiply-add comes with two LDS reads and the wavefront
+// — alone on its SIMD, one instruction per 4 cycles whatever the instruction — is bound by its
+// instruction count.  Here a lane owns a whole COLUMN of the blocks instead:
+//   lane j (0..n)  of a group holds column j of [Vxx | Vx]   (n values, registers)
+//   lane b (0..n-1) forms column b of H = L + (F^T [Vxx|Vx])[:, :n] F, lane n forms g = l + F^T Vx
+// so that per horizon step
+//   T1[:, j] = F^T Va[:, j]          is lane-local (compile-time sparsity of F = [A | B]),
+//   H[:, b]  = sum_i F[i][b] T1[:, i]  needs other lanes' T1 columns only for the <= 3 rows i != b
+//                                    in which column b of F is non-zero,
+//   [K | k][:, j] = -Quu^-1 H[n:, j]  is lane-local once Quu^-1 is known (every lane forms the
+//                                    m x m block from T1 itself),
+//   Va'[:, j] = H[:n, j] - K^T (Quu [K|k][:, j])  needs the K columns of the other lanes.
+// Two LDS exchanges per step (T1 columns, gain columns) instead of three, each multiply-add fed
+// from registers, about a third of the instructions per step — and eight problems per wavefront,
+// so batches between 1024 and ~16384 problems no longer leave most of the chip idle.
+// The serial forward rollout runs redundantly on the eight lanes of a group, like the 64 lanes of
+// the one-problem-per-wavefront kernel.
+//
+// Requirements on the plant (checked at compile time from Sys::pat): n + m <= 8, and every column b
+// of F = [A | B] is non-zero only in rows 0 and 1 (state-dependent or constant), in row b (the
+// identity of A) and in at most one further row r(b) holding the constant dt — the structure of
+// the kinematic bicycles (systems/kinetic_bicycle.py:30-52).  Q = R = 0 (the reference's defaults,
+// utils/base.py:243-246); other weights take the one-problem-per-wavefront kernel.
+//
+// Reference being replaced: control/iterative_ilqr.py:7-160, control/ilqr_helper.py:9-150 (see
+// i2lqr_wave.hpp for the per-phase citations).  Same algorithm; the association of
+// K^T Quu K differs (K^T (Quu K) instead of (K^T Quu) K), i.e. results agree with the other kernels
+// to round-off, not bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "i2lqr_systems.hpp"
+#include "i2lqr_wave.hpp"
+
+namespace i2lqr {
+
+constexpr int kGroup = 8;                 // lanes per problem
+constexpr int kGroupsPerWave = 64 / kGroup;
+
+// Compile-time description of the columns of F = [A | B] (see the header comment).
+template <class Sys> struct GroupPattern {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR;
+  // the further constant-dt row of column b, or -1
+  static constexpr int dt_row(int b) {
+    for (int i = 2; i < n; i++)
+      if (i != b && Sys::pat(i, b) == 2) return i;
+    return -1;
+  }
+  static constexpr bool column_ok(int b) {
+    int extra = 0;
+    for (int i = 0; i < n; i++) {
+      const int code = Sys::pat(i, b);
+      if (i < 2) {
+        if (code == 2) return false;               // a constant dt in rows 0 / 1 is not encoded
+        if (i == b && code != 1) return false;
+        continue;
+      }
+      if (i == b) {
+        if (code != 1) return false;               // identity of A
+      } else if (code == 2) {
+        extra++;
+      } else if (code != 0) {
+        return false;                              // a state-dependent entry below row 1
+      }
+    }
+    return extra <= 1;
+  }
+  static constexpr bool ok() {
+    if (W > kGroup || n + 1 > kGroup || n < 2) return false;
+    for (int b = 0; b < W; b++)
+      if (!column_ok(b)) return false;
+    return true;
+  }
+};
+
+// LDS layout in words of T.  Per problem:
+//   XU0, XU1  two trajectory buffers, time-major records {x[n], u[m]} of W words (t = 0..N)
+//   Kk        gains, [t][a][KW]: K[a][0..n-1], k[a] at column n, padding
+//   R         per-step record (t = 0..N), RW words:
+//               jv[NV]  state-dependent entries of F_t at (x_{t+1}, u_t)
+//               0, 1    constants (targets of the per-lane coefficient reads)
+//               lu[m], luu[m]  input-barrier gradient / curvature      (control/ilqr_helper.py:83-103)
+//               ob[5]   obstacle-barrier gradient (2) and Gauss-Newton block (3)   (:32-51)
+//   TR0, TR1  sin / cos values the plant step evaluated at x_t (t = 0..N), one array per trajectory
+//             buffer: the rollouts compute them anyway, prep() reads them back instead of
+//             evaluating sincos a second time
+//   T1c       exchange buffer for the T1 columns, [8 columns][W rows]
+// Per wavefront (after the eight problem slices): Qt[n][n].
+template <class Sys> struct GLayout {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
+  static constexpr int KW = (n + 1 + 1) & ~1;  // gain row [K[a][0..n-1], k[a]] padded to 16 bytes (fp64)
+  static constexpr int R_JV = 0, R_ZERO = NV, R_ONE = NV + 1, R_LU = NV + 2, R_LUU = NV + 2 + m,
+                       R_OB = NV + 2 + 2 * m, RW = (NV + 2 + 2 * m + 5 + 1) & ~1;
+  int N;
+  int XU0, XU1, Kk, R, TR0, TR1, T1c, total;
+  __host__ __device__ explicit GLayout(int N_) : N(N_) {
+    int o = 0;
+    XU0 = o; o += W * (N + 1); o = (o + 3) & ~3;
+    XU1 = o; o += W * (N + 1); o = (o + 3) & ~3;
+    Kk = o; o += m * KW * N; o = (o + 3) & ~3;
+    R = o; o += RW * (N + 1);
+    TR0 = o; o += NT * (N + 1); o = (o + 3) & ~3;
+    TR1 = o; o += NT * (N + 1); o = (o + 3) & ~3;
+    T1c = o; o += kGroup * W; o = (o + 3) & ~3;
+    // keep consecutive problem slices on different LDS banks for group-uniform 16-byte reads:
+    // slice stride = 4 * odd words
+    o = (o + 3) & ~3;
+    if (((o / 4) & 1) == 0) o += 4;
+    total = o;
+  }
+  __host__ __device__ int wave_words() const { return kGroupsPerWave * total + n * n; }
+};
+
+template <class T, class Sys> struct GroupWorker {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
+  static constexpr int NA = n + 1;
+  using Cfg = DevCfg<T, n, m>;
+  using GL = GLayout<Sys>;
+  using GP = GroupPattern<Sys>;
+  static_assert(GP::ok(), "plant does not have the column structure this kernel is written for");
+  const Cfg& c;
+  const GL L;
+  T* const S;        // this problem's LDS slice
+  const T* const Qt; // the wavefront's copy of Q_terminal
+  const int g;       // lane inside the group = column index
+  const int N;
+
+  // per-lane column description (constant over the kernel)
+  int off_c0, off_c1;        // record offsets of F[0][g], F[1][g]
+  int off_l0, off_l1;        // record offsets of the cost terms of rows 0, 1
+  int off_lu[m];             // ... of rows n..n+m-1
+  T own, cdt;                // coefficient of the lane's own T1 column / of column r(g)
+  int rsrc;                  // r(g)
+#ifdef I2LQR_STAMPS
+  mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#endif
+
+  __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
+      : c(c_), L(c_.N), S(smem + (lane / kGroup) * GLayout<Sys>(c_.N).total),
+        Qt(smem + kGroupsPerWave * GLayout<Sys>(c_.N).total), g(lane % kGroup), N(c_.N) {
+    off_c0 = GL::R_ZERO; off_c1 = GL::R_ZERO; off_l0 = GL::R_ZERO; off_l1 = GL::R_ZERO;
+#pragma unroll
+    for (int a = 0; a < m; a++) off_lu[a] = GL::R_ZERO;
+    own = T(0); cdt = T(0); rsrc = 0;
+    static_for_i<0, W>([&](auto b_) {
+      constexpr int b = decltype(b_)::value;
+      if (g == b && b < n) {   // lanes 0..n-1: column b of H
+        constexpr int c0 = Sys::pat(0, b), c1 = Sys::pat(1, b);
+        off_c0 = c0 == 0 ? GL::R_ZERO : (c0 == 1 ? GL::R_ONE : GL::R_JV + (c0 - 3));
+        off_c1 = c1 == 0 ? GL::R_ZERO : (c1 == 1 ? GL::R_ONE : GL::R_JV + (c1 - 3));
+        own = (b >= 2) ? T(1) : T(0);
+        constexpr int r = GP::dt_row(b);
+        cdt = r >= 0 ? c.dt : T(0);
+        rsrc = r >= 0 ? r : 0;
+        if (b < 2) {  // obstacle block l_xx[a][b], a, b < 2: ob[2 + a + b]
+          off_l0 = GL::R_OB + 2 + b;
+          off_l1 = GL::R_OB + 3 + b;
+        }
+      }
+    });
+    if (g == n) {  // lane n: g = l + T1[:, n]
+      own = T(1);
+      off_l0 = GL::R_OB + 0;
+      off_l1 = GL::R_OB + 1;
+#pragma unroll
+      for (int a = 0; a < m; a++) off_lu[a] = GL::R_LU + a;
+    }
+  }
+
+  __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
+    T d[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) d[i] = x[i] - xT[i];
+    T acc = T(0);
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+      T col = T(0);
+#pragma unroll
+      for (int i = 0; i < n; i++) col += d[i] * Qt[i * n + j];
+      acc += col * d[j];
+    }
+    return acc;
+  }
+
+  // acc += F[i][a] * v from the compile-time pattern (exact for ones, skipped for zeros)
+  template <int i, int a> __device__ __forceinline__ void f_acc(T& acc, bool& first, T v,
+                                                                const T (&jv)[NV]) const {
+    constexpr int code = Sys::pat(i, a);
+    if constexpr (code == 0) {
+      return;
+    } else if constexpr (code == 1) {
+      acc = first ? v : acc + v;
+      first = false;
+    } else {
+      const T f = code == 2 ? c.dt : jv[code >= 3 ? code - 3 : 0];
+      acc = first ? f * v : t_fma(f, v, acc);
+      first = false;
+    }
+  }
+
+  // -- nominal rollout + cost (control/iterative_ilqr.py:32-48), all lanes of the group redundantly
+  __device__ __forceinline__ T rollout(int XUo, int TRo, const T (&xT)[n]) const {
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[XUo + i];
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = clip(S[XUo + t * W + n + a], -c.u_max[a], c.u_max[a]);
+#pragma unroll
+      for (int a = 0; a < m; a++) S[XUo + t * W + n + a] = u[a];
+      Sys::trig(x, tr);
+#pragma unroll
+      for (int q = 0; q < NT; q++) S[TRo + t * NT + q] = tr[q];
+      Sys::step_tr(c, x, u, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) S[XUo + (t + 1) * W + i] = xn[i];
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    Sys::trig(x, tr);  // at x_N: the Jacobian of the last step is evaluated there
+#pragma unroll
+    for (int q = 0; q < NT; q++) S[TRo + N * NT + q] = tr[q];
+    const T cost = terminal_cost(x, xT);  // Q = R = 0: only the terminal term
+    wave_sync();
+    return cost;
+  }
+
+  // -- per-step records, lanes of the group take the horizon steps in turn --------------------
+  // pa, pb = 1 / width^2, 1 / height^2 of the obstacle: the same for every step, computed once by
+  // the kernel.  The sin / cos of x_{t+1} come from the trajectory's cache (TRo).  Input barrier:
+  //   l_u = q1 q2 (e_hi - e_lo),  l_uu = q1 q2^2 (e_hi + e_lo),
+  //   e_hi = exp(q2 (u - u_max)),  e_lo = exp(q2 (-u_max - u));
+  // the inputs of a rolled-out trajectory lie in [-u_max, u_max], so e_hi e_lo = exp(-2 q2 u_max)
+  // is a constant and (fp64, |2 q2 u_max| < 600) e_lo = ctrl_c / e_hi: one short exp without range
+  // handling and one reciprocal instead of two general exps (a few ulp apart; i2lqr_lane.hpp).
+  // Every lane of the group takes the records g, g + 8, ... in turn; there is NO divergent control
+  // flow: a lane past the end of the horizon recomputes the last record (and stores the same
+  // values again), a problem without obstacle computes the barrier of a dummy ellipse and
+  // stores zeros.
+  __device__ __forceinline__ void prep(int XUo, int TRo, const T (&ob)[6], T pa, T pb) const {
+    const bool has_ob = ob[5] >= T(0);
+    const int opt = has_ob ? (int)ob[5] : 0;
+    const T spd_y = opt == 1 ? ob[4] : T(0), spd_x = opt == 2 ? ob[4] : T(0);
+    const int rounds = (N + kGroup) / kGroup;  // ceil((N + 1) / 8)
+    for (int r = 0; r < rounds; r++) {
+      const int t0 = g + r * kGroup;
+      const int t = t0 < N ? t0 : N;          // record index (obstacle term of x_t)
+      const int ts = t0 < N ? t0 : N - 1;     // step index (Jacobian entries, input barrier)
+      T* Rs = S + L.R + ts * GL::RW;
+      {
+        T xe[n], tr[NT], u[m], jv[NV];
+#pragma unroll
+        for (int i = 0; i < n; i++) xe[i] = S[XUo + (ts + 1) * W + i];
+#pragma unroll
+        for (int a = 0; a < m; a++) u[a] = S[XUo + ts * W + n + a];
+#pragma unroll
+        for (int q = 0; q < NT; q++) tr[q] = S[TRo + (ts + 1) * NT + q];
+        Sys::jac_var(c, xe, u, tr, jv);  // at (x_{t+1}, u_t): control/iterative_ilqr.py:92-99
+#pragma unroll
+        for (int q = 0; q < NV; q++) Rs[GL::R_JV + q] = jv[q];
+#pragma unroll
+        for (int a = 0; a < m; a++) {  // add_control_constraint(): control/ilqr_helper.py:83-103
+          T e_hi, e_lo;
+          if (sizeof(T) == 8 && c.fast_barrier) {
+            e_hi = t_exp_bounded(c.ctrl_q2 * (u[a] - c.u_max[a]));
+            e_lo = c.ctrl_c[a] * t_rcp(e_hi);
+          } else {
+            e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
+            e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+          }
+          Rs[GL::R_LU + a] = c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo;
+          Rs[GL::R_LUU + a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
+                              c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+        }
+      }
+      T* R = S + L.R + t * GL::RW;
+      R[GL::R_ZERO] = T(0);
+      R[GL::R_ONE] = T(1);
+      // obstacle barrier: control/ilqr_helper.py:32-51 (stage) / :121-147 (terminal, index N);
+      // the centre moves by spd per horizon index without dt (:37-43)
+      const T px = S[XUo + t * W + 0], py = S[XUo + t * W + 1];
+      const T dz = opt == 2 ? px - (ob[0] - T(t) * spd_x) : px - ob[0];
+      const T dy = opt == 1 ? py - (ob[1] + T(t) * spd_y) : py - ob[1];
+      const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
+      const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
+      const T e = t_exp(c.obs_q2 * h);
+      const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+      R[GL::R_OB + 0] = has_ob ? c1 * hd0 : T(0);
+      R[GL::R_OB + 1] = has_ob ? c1 * hd1 : T(0);
+      R[GL::R_OB + 2] = has_ob ? c2 * (hd0 * hd0) : T(0);
+      R[GL::R_OB + 3] = has_ob ? c2 * (hd0 * hd1) : T(0);
+      R[GL::R_OB + 4] = has_ob ? c2 * (hd1 * hd1) : T(0);
+    }
+    wave_sync();
+  }
+
+  // regularised inverse of Q_uu, m == 2 (control/iterative_ilqr.py:118-123)
+  __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb, T (&inv)[m * m]) const {
+    static_assert(m == 2, "the eight-lane kernel is written for m == 2 plants");
+    t_quu_inverse2(Quu, lamb, inv);
+  }
+
+  // -- backward pass: control/iterative_ilqr.py:88-130.  Needs prep() on the same trajectory;
+  //    leaves the gains in LDS (Kk).
+  //    GENERAL = false: Quu is inverted in its positive-definite form only and the loop has no
+  //    branch; returns true if some Quu was not positive definite — the caller then repeats the
+  //    pass with GENERAL = true (eigenvalue clamping of control/iterative_ilqr.py:118-123 behind a
+  //    branch).  Where Quu is positive definite both compute the same numbers.
+  template <bool GENERAL>
+  __device__ __forceinline__ bool backward(int XUo, const T (&xT)[n], T lamb) const {
+    bool bad = false;
+    // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150.
+    // va[i] = column g of [Vxx | Vx]
+    T va[n];
+    {
+      const T* Rn = S + L.R + N * GL::RW;
+      T dx[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T vxx = T(0), vx = T(0);
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+          const T q = T(2) * Qt[i * n + r];
+          vxx = (g == r) ? q : vxx;
+          vx += q * dx[r];
+        }
+        va[i] = (g == n) ? vx : vxx;
+      }
+      // obstacle terms of rows 0, 1 (per-lane record offsets, zero for the other lanes)
+      va[0] += Rn[off_l0];
+      va[1] += Rn[off_l1];
+    }
+    T* const T1c = S + L.T1c;
+    const int gcol = g < GL::KW ? g : GL::KW - 1;  // lanes past the gain row write its padding word
+    // The record of a step (uniform and per-lane words) is loaded one step ahead, behind the gain
+    // exchange of the previous step: its LDS latency hides under that step's value update.
+    T jv[NV], luu[m], c0, c1, l0, l1, lrow[m];
+    auto load_record = [&](int t) __attribute__((always_inline)) {
+      const T* R = S + L.R + t * GL::RW;
+#pragma unroll
+      for (int q = 0; q < NV; q++) jv[q] = R[GL::R_JV + q];
+#pragma unroll
+      for (int a = 0; a < m; a++) luu[a] = R[GL::R_LUU + a];
+      c0 = R[off_c0];
+      c1 = R[off_c1];
+      l0 = R[off_l0];
+      l1 = R[off_l1];
+#pragma unroll
+      for (int a = 0; a < m; a++) lrow[a] = R[off_lu[a]];
+    };
+    load_record(N - 1);
+    auto step = [&](const int t) __attribute__((always_inline)) {
+      STAMP_BEGIN();
+      // P1: own column of T1 = F^T [Vxx | Vx]  (f.T @ V of control/iterative_ilqr.py:112-116)
+      T t1[W];
+      static_for_i<0, W>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        T acc = T(0);
+        bool first = true;
+        static_for_i<0, n>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          f_acc<i, a>(acc, first, va[i], jv);
+        });
+        t1[a] = acc;
+      });
+#pragma unroll
+      for (int a = 0; a < W; a++) T1c[g * W + a] = t1[a];
+      wave_sync();
+      STAMP_END(1);
+      // P2: column g of H = L + T1[:, :n] F (lanes < n), g = l + T1[:, n] (lane n)
+      T h[W];
+      {
+        T s0[W], s1[W], sr[W];
+#pragma unroll
+        for (int a = 0; a < W; a++) {
+          s0[a] = T1c[0 * W + a];
+          s1[a] = T1c[1 * W + a];
+          sr[a] = T1c[rsrc * W + a];
+        }
+#pragma unroll
+        for (int a = 0; a < W; a++) {
+          T acc = c0 * s0[a];
+          acc = t_fma(c1, s1[a], acc);
+          acc = t_fma(own, t1[a], acc);
+          acc = t_fma(cdt, sr[a], acc);
+          h[a] = acc;
+        }
+        h[0] += l0;
+        h[1] += l1;
+#pragma unroll
+        for (int a = 0; a < m; a++) h[n + a] += lrow[a];
+      }
+      STAMP_END(2);
+      // Quu (every lane, from the T1 columns its F columns touch) and its regularised inverse
+      T Quu[m * m], Qinv[m * m];
+      static_for_i<0, m>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        static_for_i<0, m>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          T acc = T(0);
+          bool first = true;
+          static_for_i<0, n>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (Sys::pat(i, n + b) != 0) f_acc<i, n + b>(acc, first, T1c[i * W + n + a], jv);
+          });
+          Quu[a * m + b] = (a == b ? luu[a] : T(0)) + acc;
+        });
+      });
+      if constexpr (GENERAL) quu_inverse(Quu, lamb, Qinv);
+      else t_quu_inverse2_pd(Quu, lamb, Qinv, &bad);
+      STAMP_END(3);
+      // own column of [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
+      T kc[m];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], h[n + b], acc);
+        kc[a] = -acc;
+      }
+      T* Kt = S + L.Kk + t * (m * GL::KW);
+#pragma unroll
+      for (int a = 0; a < m; a++) Kt[a * GL::KW + gcol] = kc[a];
+      wave_sync();
+      STAMP_END(4);
+      // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
+      //   Va'[:, g] = H[:n, g] - K^T (Quu [K|k][:, g])
+      T kr[m][n];
+#pragma unroll
+      for (int a = 0; a < m; a++)
+#pragma unroll
+        for (int i = 0; i < n; i++) kr[a][i] = Kt[a * GL::KW + i];
+      load_record(t > 0 ? t - 1 : 0);
+      T qk[m];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) acc = t_fma(Quu[a * m + b], kc[b], acc);
+        qk[a] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T acc = T(0);
+#pragma unroll
+        for (int a = 0; a < m; a++) acc = t_fma(kr[a][i], qk[a], acc);
+        va[i] = h[i] - acc;
+      }
+      STAMP_END(5);
+    };
+    // two horizon steps per loop iteration: a taken branch costs a lone wavefront ~100 cycles
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      step(t);
+      step(t - 1);
+    }
+    if (t == 0) step(0);
+    return bad;
+  }
+
+  // -- forward pass: control/iterative_ilqr.py:133-160; all lanes of the group redundantly ------
+  //    GENERAL = false: short sincos kernel only, *bad set if an angle left its range (the caller
+  //    repeats the pass with GENERAL = true); see t_sincos_fast.
+  template <bool GENERAL>
+  __device__ __forceinline__ T forward(int XUo, int XUn, int TRn, const T (&xT)[n],
+                                       bool* bad) const {
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[XUo + i];
+#pragma unroll
+    for (int i = 0; i < n; i++) S[XUn + i] = x[i];
+    T xo[n], uo[m], kk[m][NA];
+    auto load_step = [&](int t) {
+#pragma unroll
+      for (int j = 0; j < n; j++) xo[j] = S[XUo + t * W + j];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        uo[a] = S[XUo + t * W + n + a];
+#pragma unroll
+        for (int j = 0; j < NA; j++) kk[a][j] = S[L.Kk + (t * m + a) * GL::KW + j];
+      }
+    };
+    load_step(0);
+    auto step = [&](const int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
+        u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
+      }
+      load_step(t + 1 < N ? t + 1 : t);
+#pragma unroll
+      for (int a = 0; a < m; a++) S[XUn + t * W + n + a] = u[a];
+      Sys::template trig_g<GENERAL>(x, tr, bad);
+#pragma unroll
+      for (int q = 0; q < NT; q++) S[TRn + t * NT + q] = tr[q];
+      Sys::step_tr(c, x, u, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) S[XUn + (t + 1) * W + i] = xn[i];
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    };
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      step(t);
+      step(t + 1);
+    }
+    if (t < N) step(t);
+    Sys::template trig_g<GENERAL>(x, tr, bad);
+#pragma unroll
+    for (int q = 0; q < NT; q++) S[TRn + N * NT + q] = tr[q];
+    const T cost = terminal_cost(x, xT);
+    wave_sync();
+    return cost;
+  }
+};
+
+// Grid: ceil(B / 8) workgroups of one wavefront; dynamic LDS = GLayout::wave_words() * sizeof(T).
+template <class T, class Sys>
+__global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sys::m> c,
+                                                      const IterArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m, W = n + m;
+  using GL = GLayout<Sys>;
+  extern __shared__ __align__(16) unsigned char gsmem_raw[];
+  T* smem = reinterpret_cast<T*>(gsmem_raw);
+  const int lane = threadIdx.x;
+  const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + lane / kGroup;
+  // groups past the end of the batch work on a copy of the last problem and store nothing, so
+  // that every lane of the wavefront runs the same control flow
+  const bool real = prob0 < a.B;
+  const int64_t prob = real ? prob0 : a.B - 1;
+  GroupWorker<T, Sys> w(c, smem, lane);
+  const int N = c.N, g = w.g;
+  const GL& L = w.L;
+  T* S = w.S;
+
+  // entry: x0, U, x_term, lamb, obs (HBM, problem-major records) -> LDS / registers
+  {
+    const T* gX = a.X + prob * (int64_t)(n * (N + 1));
+    if (g < n) S[L.XU0 + g] = gX[g * (N + 1)];
+    const T* gU = a.U + prob * (int64_t)(m * N);
+    for (int e = g; e < m * N; e += kGroup) {
+      const int aa = e / N, t = e - aa * N;
+      S[L.XU0 + t * W + n + aa] = gU[e];
+    }
+    for (int e = lane; e < n * n; e += 64) smem[kGroupsPerWave * L.total + e] = c.Qt[e];
+  }
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[prob];
+  wave_sync();
+
+  int cur = 0;
+  const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+  T cost = w.rollout(L.XU0, L.TR0, xT);
+  int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
+  T cost_ret = cost;
+  bool fresh = true, active = a.n_iters > 0;
+  // the problems of a wavefront stop at different iterations (early exits): the loop runs while any
+  // of them is active; finished ones keep computing on their (unchanged) state and commit nothing
+  while (__any(active)) {
+    const int XUo = cur ? L.XU1 : L.XU0, XUn = cur ? L.XU0 : L.XU1;
+    const int TRo = cur ? L.TR1 : L.TR0, TRn = cur ? L.TR0 : L.TR1;
+    // the per-step records depend on the nominal trajectory only: still valid after a rejected step
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_BEGIN();
+      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb);
+      STAMP_END(0);
+    }
+#else
+    if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb);
+#endif
+    // optimistic, branch-free passes first; the general forms only if a lane asked for them
+    if (__builtin_expect(__any(w.template backward<false>(XUo, xT, lamb)), 0))
+      w.template backward<true>(XUo, xT, lamb);
+    T cost_new;
+    {
+#ifdef I2LQR_STAMPS
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_BEGIN();
+#endif
+      bool big = false;
+      cost_new = w.template forward<false>(XUo, XUn, TRn, xT, &big);
+      if (__builtin_expect(__any(big), 0)) cost_new = w.template forward<true>(XUo, XUn, TRn, xT, &big);
+#ifdef I2LQR_STAMPS
+      STAMP_END(6);
+#endif
+    }
+    if (active) {
+      it++;
+      // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
+      fresh = cost_new < cost;
+      if (fresh) {
+        cur ^= 1;
+        lamb /= c.lamb_factor;
+        const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
+        cost_ret = cost_new;
+        cost = cost_new;
+        if (conv) {
+          if (a.early_exit) { status = 1; active = false; }
+          if (status == 0) status = 1;
+        }
+      } else {
+        lamb *= c.lamb_factor;
+        cost_ret = cost;
+        if (lamb > c.max_lamb) {
+          if (a.early_exit) { status = 3; active = false; }
+          if (status == 0) status = 3;
+        }
+      }
+      if (it >= a.n_iters) active = false;
+    } else {
+      fresh = false;
+    }
+  }
+  if (!t_isfinite(cost_ret)) status = 4;
+
+  // exit: X, U, gains, scalars (LDS -> HBM, problem-major records with time contiguous)
+  if (real) {
+    const int XUo = cur ? L.XU1 : L.XU0;
+    T* gX = a.X + prob * (int64_t)(n * (N + 1));
+    for (int e = g; e < n * (N + 1); e += kGroup) {
+      const int i = e / (N + 1), t = e - i * (N + 1);
+      gX[e] = S[XUo + t * W + i];
+    }
+    T* gU = a.U + prob * (int64_t)(m * N);
+    for (int e = g; e < m * N; e += kGroup) {
+      const int aa = e / N, t = e - aa * N;
+      gU[e] = S[XUo + t * W + n + aa];
+    }
+    if (a.K) {
+      T* gK = a.K + prob * (int64_t)(m * n * N);
+      for (int e = g; e < m * n * N; e += kGroup) {
+        const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
+        gK[e] = S[L.Kk + (t * m + aa) * GL::KW + j];
+      }
+      T* gk = a.k + prob * (int64_t)(m * N);
+      for (int e = g; e < m * N; e += kGroup) {
+        const int aa = e / N, t = e - aa * N;
+        gk[e] = S[L.Kk + (t * m + aa) * GL::KW + n];
+      }
+    }
+#ifdef I2LQR_STAMPS
+    if (a.dbg && g == 0)
+      for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = w.st_acc[q];
+#endif
+    if (g == 0) {
+      a.lamb[prob] = lamb;
+      a.cost[prob] = cost_ret;
+      if (a.iters) a.iters[prob] = it;
+      if (a.status) a.status[prob] = status;
+    }
+  }
+}
+
+}  // namespace i2lqr

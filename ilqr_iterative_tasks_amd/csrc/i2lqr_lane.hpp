@@ -341,44 +341,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
                                               T (&inv)[m * m]) const {
     static_assert(m == 2, "lane kernels are built for m == 2 systems");
-    const T a = Quu[0], bq = Quu[1], cc = Quu[2], d = Quu[3];
-    // fast path: Quu positive definite -> inv = (Quu + lamb I)^-1 directly (see i2lqr_wave.hpp)
-    if (a > T(0) && a * d - bq * cc > T(0)) {
-      const T ar = a + lamb, dr = d + lamb;
-      const T r = t_rcp(ar * dr - bq * cc);
-      inv[0] = dr * r;
-      inv[1] = -bq * r;
-      inv[2] = -cc * r;
-      inv[3] = ar * r;
-      return;
-    }
-    const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
-    T disc = hd * hd + bq * cc;
-    disc = disc < T(0) ? T(0) : disc;
-    const T s = t_sqrt_fast(disc);
-    T l1 = (mean >= T(0)) ? mean + s : mean - s;
-    T l2 = (l1 != T(0)) ? (a * d - bq * cc) * t_rcp(l1) : T(0);
-    if (s == T(0)) { l1 = mean; l2 = mean; }
-    const T w[2] = {l1, l2};
-    T vx[2], vy[2], sc[2];
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-      // eigenvector of w[e] = a non-zero column of (Quu - w[other] I); its normalisation is
-      // folded into the eigenvalue division: v v^T / (|v|^2 w)
-      const T lo = w[1 - e];
-      const T c0x = a - lo, c0y = cc, c1x = bq, c1y = d - lo;
-      const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
-      const bool firstc = n0 >= n1;
-      T ex = firstc ? c0x : c1x, ey = firstc ? c0y : c1y, nn = firstc ? n0 : n1;
-      if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
-      vx[e] = ex;
-      vy[e] = ey;
-      sc[e] = t_rcp(nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
-    }
-    inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
-    inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
-    inv[2] = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
-    inv[3] = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
+    t_quu_inverse2(Quu, lamb, inv);
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------

@@ -22,13 +22,20 @@ namespace i2lqr {
 // stays as the fallback for |x| >= 1e5.  fp32: the same scheme in single precision (degree-7 /
 // degree-8 kernels, ~1 ulp, fallback for |x| >= 1e4).
 template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
-template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
-  if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {
-    sincos(x, s, c);
-    return;
-  }
-  const double kf = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
-  double r = __builtin_fma(-kf, 1.57079632679489655800e+00, x);      // pi/2 hi
+// t_sincos_fast: the short kernel alone; *big is set (never cleared) if the argument is outside its
+// range (|x| >= 1e5, NaN) and the result must not be used.  Callers that loop over a horizon run
+// the loop with it and repeat the whole loop with t_sincos if any argument was out of range: the
+// common case has no branch inside the loop at all, so the compiler can interleave the polynomial
+// with the neighbouring arithmetic (a branch ends the scheduling region, and a TAKEN branch costs
+// a wavefront alone on its SIMD ~100 cycles: tools/ubench_issue.hip).
+template <class T> __device__ __forceinline__ void t_sincos_fast(T x, T* s, T* c, bool* big_out);
+template <> __device__ __forceinline__ void t_sincos_fast<double>(double x, double* s, double* c,
+                                                                   bool* big_out) {
+  const bool big = !(__builtin_fabs(x) < 1.0e5);
+  *big_out = *big_out || big;
+  const double xs = big ? 0.0 : x;
+  const double kf = __builtin_rint(xs * 6.36619772367581382433e-01);  // 2/pi
+  double r = __builtin_fma(-kf, 1.57079632679489655800e+00, xs);     // pi/2 hi
   r = __builtin_fma(-kf, 6.12323399573676603587e-17, r);            // pi/2 mid
   r = __builtin_fma(-kf, -1.49738490485916983327e-33, r);           // pi/2 lo
   const int q = (int)kf;
@@ -52,13 +59,29 @@ template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s
   *s = (q & 2) ? -sv : sv;
   *c = ((q + 1) & 2) ? -cv : cv;
 }
-template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
-  if (__builtin_expect(!(__builtin_fabsf(x) < 1.0e4f), 0)) {
-    sincosf(x, s, c);
-    return;
+template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
+  // The short kernel runs unconditionally and the library routine, which only arguments of
+  // |x| >= 1e5 (or NaN) need, sits behind a WAVE-UNIFORM unlikely branch: the common case falls
+  // through instead of jumping over ~170 instructions of Payne-Hanek reduction in every call.
+  bool big = false;
+  double so, co;
+  t_sincos_fast(x, &so, &co, &big);
+  if (__builtin_expect(__any(big), 0)) {
+    double sl, cl;
+    sincos(x, &sl, &cl);
+    so = big ? sl : so;
+    co = big ? cl : co;
   }
-  const float kf = __builtin_rintf(x * 6.36619772367581382433e-01f);
-  float r = __builtin_fmaf(-kf, 1.57079637050628662109375f, x);
+  *s = so;
+  *c = co;
+}
+template <> __device__ __forceinline__ void t_sincos_fast<float>(float x, float* s, float* c,
+                                                                  bool* big_out) {
+  const bool big = !(__builtin_fabsf(x) < 1.0e4f);
+  *big_out = *big_out || big;
+  const float xs = big ? 0.0f : x;
+  const float kf = __builtin_rintf(xs * 6.36619772367581382433e-01f);
+  float r = __builtin_fmaf(-kf, 1.57079637050628662109375f, xs);
   r = __builtin_fmaf(-kf, -4.37113900018624283e-8f, r);
   r = __builtin_fmaf(-kf, -1.71512468793638e-15f, r);
   const int q = (int)kf;
@@ -75,6 +98,19 @@ template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, f
   const float sv = swap ? cr : sr, cv = swap ? sr : cr;
   *s = (q & 2) ? -sv : sv;
   *c = ((q + 1) & 2) ? -cv : cv;
+}
+template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
+  bool big = false;
+  float so, co;
+  t_sincos_fast(x, &so, &co, &big);
+  if (__builtin_expect(__any(big), 0)) {
+    float sl, cl;
+    sincosf(x, &sl, &cl);
+    so = big ? sl : so;
+    co = big ? cl : co;
+  }
+  *s = so;
+  *c = co;
 }
 template <class T> __device__ __forceinline__ T t_exp(T x);
 // fp64 exp: x = k ln2 + r (Cody-Waite), degree-13 Horner on |r| <= ln2/2, v_ldexp (<= ~2 ulp;
@@ -161,6 +197,78 @@ template <> __device__ __forceinline__ double t_sqrt_fast<double>(double x) {
   return __builtin_fma(d, h, g);
 }
 template <> __device__ __forceinline__ float t_sqrt_fast<float>(float x) { return sqrtf(x); }
+// Regularised inverse of a 2 x 2 Q_uu: control/iterative_ilqr.py:118-123
+//   w, V = eig(Quu); w[w<0] = 0; w += lamb; inv = V diag(1/w) V^T.
+// Fast path, the only one taken in practice (l_uu carries the strictly positive input-barrier
+// curvature): Quu positive definite -> no eigenvalue is clamped and V diag(1/(w + lamb)) V^T is
+// the inverse of Quu + lamb I, written out directly.  On the reference's golden calls this is as
+// close to np.linalg.eig's result as the closed-form eigen-decomposition below (G2: 1.1e-9 vs
+// 2.1e-9 max relative deviation, same branches).  It is computed unconditionally; the general
+// form sits behind a wave-uniform unlikely branch (no jump over it in the common case) and
+// follows the reference's NON-symmetric eig in closed form: unit-norm eigenvectors that are not
+// orthogonalised, the normalisation folded into the eigenvalue division (v v^T / (|v|^2 w)).
+// t_quu_inverse2_pd: the positive-definite form alone; *bad is set (never cleared) if Quu is not
+// positive definite and the result must not be used (same protocol as t_sincos_fast).
+template <class T>
+__device__ __forceinline__ void t_quu_inverse2_pd(const T (&Quu)[4], T lamb, T (&inv)[4],
+                                                  bool* bad) {
+  const T a = Quu[0], b = Quu[1], cc = Quu[2], d = Quu[3];
+  const T det = a * d - b * cc;
+  *bad = *bad || !(a > T(0) && det > T(0));
+  const T ar = a + lamb, dr = d + lamb;
+  const T r = t_rcp(ar * dr - b * cc);
+  inv[0] = dr * r;
+  inv[1] = -b * r;
+  inv[2] = -cc * r;
+  inv[3] = ar * r;
+}
+template <class T>
+__device__ __forceinline__ void t_quu_inverse2(const T (&Quu)[4], T lamb, T (&inv)[4]) {
+  const T a = Quu[0], b = Quu[1], cc = Quu[2], d = Quu[3];
+  const T det = a * d - b * cc;
+  const bool pd = a > T(0) && det > T(0);
+  {
+    const T ar = a + lamb, dr = d + lamb;
+    const T r = t_rcp(ar * dr - b * cc);
+    inv[0] = dr * r;
+    inv[1] = -b * r;
+    inv[2] = -cc * r;
+    inv[3] = ar * r;
+  }
+  if (__builtin_expect(__any(!pd), 0)) {
+    const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
+    T disc = hd * hd + b * cc;
+    disc = disc < T(0) ? T(0) : disc;
+    const T s = t_sqrt_fast(disc);
+    T l1 = (mean >= T(0)) ? mean + s : mean - s;
+    T l2 = (l1 != T(0)) ? det * t_rcp(l1) : T(0);
+    if (s == T(0)) { l1 = mean; l2 = mean; }
+    const T w[2] = {l1, l2};
+    T vx[2], vy[2], sc[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      // eigenvector of w[e] = a non-zero column of (Quu - w[other] I)  (Cayley-Hamilton)
+      const T lo = w[1 - e];
+      const T c0x = a - lo, c0y = cc, c1x = b, c1y = d - lo;
+      const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
+      const bool first = n0 >= n1;
+      T ex = first ? c0x : c1x, ey = first ? c0y : c1y, nn = first ? n0 : n1;
+      if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
+      vx[e] = ex;
+      vy[e] = ey;
+      sc[e] = t_rcp(nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
+    }
+    const T g0 = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
+    const T g1 = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
+    const T g2 = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
+    const T g3 = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
+    inv[0] = pd ? inv[0] : g0;
+    inv[1] = pd ? inv[1] : g1;
+    inv[2] = pd ? inv[2] : g2;
+    inv[3] = pd ? inv[3] : g3;
+  }
+}
+
 // The library is built with -ffp-contract=off so that one source expression rounds the same way
 // in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
 // the dot products of the Riccati step ask for the fused multiply-add explicitly.
@@ -182,6 +290,12 @@ template <class T> struct Bicycle4 {
   // {cos(theta), sin(theta)}
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
     t_sincos(xe[3], &tr[1], &tr[0]);
+  }
+  // GENERAL = false: short sincos kernel only, *bad set if its range was left (t_sincos_fast)
+  template <bool GENERAL>
+  static __device__ __forceinline__ void trig_g(const T (&xe)[n], T (&tr)[NTRIG], bool* bad) {
+    if constexpr (GENERAL) t_sincos(xe[3], &tr[1], &tr[0]);
+    else t_sincos_fast(xe[3], &tr[1], &tr[0], bad);
   }
   // kinetic_bicycle(): systems/kinetic_bicycle.py:10-27, with trig(x) supplied
   template <class Cfg>
@@ -248,6 +362,11 @@ template <class T> struct Bicycle6 {
 
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
     t_sincos(xe[3], &tr[1], &tr[0]);
+  }
+  template <bool GENERAL>
+  static __device__ __forceinline__ void trig_g(const T (&xe)[n], T (&tr)[NTRIG], bool* bad) {
+    if constexpr (GENERAL) t_sincos(xe[3], &tr[1], &tr[0]);
+    else t_sincos_fast(xe[3], &tr[1], &tr[0], bad);
   }
   template <class Cfg>
   static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],
@@ -322,6 +441,16 @@ template <class T> struct Quad12 {
     t_sincos(xe[3], &tr[0], &tr[1]);
     t_sincos(xe[4], &tr[2], &tr[3]);
     t_sincos(xe[5], &tr[4], &tr[5]);
+  }
+  template <bool GENERAL>
+  static __device__ __forceinline__ void trig_g(const T (&xe)[n], T (&tr)[NTRIG], bool* bad) {
+    if constexpr (GENERAL) {
+      trig(xe, tr);
+    } else {
+      t_sincos_fast(xe[3], &tr[0], &tr[1], bad);
+      t_sincos_fast(xe[4], &tr[2], &tr[3], bad);
+      t_sincos_fast(xe[5], &tr[4], &tr[5], bad);
+    }
   }
   template <class Cfg>
   static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],

@@ -20,6 +20,10 @@
 
 #include "i2lqr_systems.hpp"
 
+// A wavefront alone on its SIMD pays ~100 cycles for every TAKEN branch (instruction-fetch bubble;
+// tools/ubench_issue.hip): the serial horizon loops take two horizon steps per loop iteration
+// (written out by hand: the compiler does not unroll loops that contain wave barriers).
+
 namespace i2lqr {
 
 enum : int { FLAG_HAS_Q = 1, FLAG_HAS_R = 2 };
@@ -370,54 +374,12 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
 
   // Regularised inverse of Q_uu: control/iterative_ilqr.py:118-123
   //   w, V = eig(Quu); w[w<0] = 0; w += lamb; inv = V diag(1/w) V^T.
-  // m == 2 follows the reference's NON-symmetric eig (unit-norm eigenvectors that are not
-  // orthogonalised) in closed form; the normalisation is folded into the eigenvalue division
-  // (v v^T / (|v|^2 w) instead of (v/|v|)(v/|v|)^T / w: one sqrt and three divisions in all).
+  // m == 2: t_quu_inverse2 (i2lqr_systems.hpp).
   // m > 2 runs cyclic Jacobi on the symmetrised matrix (no reference counterpart).
   __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
                                               T (&inv)[m * m]) const {
     if constexpr (m == 2) {
-      const T a = Quu[0], b = Quu[1], cc = Quu[2], d = Quu[3];
-      // Fast path, the only one taken in practice (l_uu carries the strictly positive input-
-      // barrier curvature): Quu positive definite -> no eigenvalue is clamped and
-      // V diag(1/(w + lamb)) V^T is the inverse of Quu + lamb I, written out directly.  On the
-      // reference's golden calls this is as close to np.linalg.eig's result as the closed-form
-      // eigen-decomposition below (G2: 1.1e-9 vs 2.1e-9 max relative deviation, same branches).
-      if (a > T(0) && a * d - b * cc > T(0)) {
-        const T ar = a + lamb, dr = d + lamb;
-        const T r = t_rcp(ar * dr - b * cc);
-        inv[0] = dr * r;
-        inv[1] = -b * r;
-        inv[2] = -cc * r;
-        inv[3] = ar * r;
-        return;
-      }
-      const T mean = T(0.5) * (a + d), hd = T(0.5) * (a - d);
-      T disc = hd * hd + b * cc;
-      disc = disc < T(0) ? T(0) : disc;
-      const T s = t_sqrt_fast(disc);
-      T l1 = (mean >= T(0)) ? mean + s : mean - s;
-      T l2 = (l1 != T(0)) ? (a * d - b * cc) * t_rcp(l1) : T(0);
-      if (s == T(0)) { l1 = mean; l2 = mean; }
-      const T w[2] = {l1, l2};
-      T vx[2], vy[2], sc[2];
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        // eigenvector of w[e] = a non-zero column of (Quu - w[other] I)  (Cayley-Hamilton)
-        const T lo = w[1 - e];
-        const T c0x = a - lo, c0y = cc, c1x = b, c1y = d - lo;
-        const T n0 = c0x * c0x + c0y * c0y, n1 = c1x * c1x + c1y * c1y;
-        const bool first = n0 >= n1;
-        T ex = first ? c0x : c1x, ey = first ? c0y : c1y, nn = first ? n0 : n1;
-        if (nn == T(0)) { ex = (e == 0) ? T(1) : T(0); ey = (e == 0) ? T(0) : T(1); nn = T(1); }
-        vx[e] = ex;
-        vy[e] = ey;
-        sc[e] = t_rcp(nn * ((w[e] < T(0) ? T(0) : w[e]) + lamb));
-      }
-      inv[0] = vx[0] * sc[0] * vx[0] + vx[1] * sc[1] * vx[1];
-      inv[1] = vx[0] * sc[0] * vy[0] + vx[1] * sc[1] * vy[1];
-      inv[2] = vy[0] * sc[0] * vx[0] + vy[1] * sc[1] * vx[1];
-      inv[3] = vy[0] * sc[0] * vy[0] + vy[1] * sc[1] * vy[1];
+      t_quu_inverse2(Quu, lamb, inv);
     } else {
       // Symmetrised Quu.  Fast path (the only one taken in practice: l_uu carries the strictly
       // positive input-barrier curvature): if Quu is positive definite no eigenvalue is clamped
@@ -670,7 +632,7 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       wave_sync();
     }
 
-    for (int t = N - 1; t >= 0; t--) {
+    auto step = [&](const int t) __attribute__((always_inline)) {
       STAMP_BEGIN();
       // P1: T1 = F^T [Vxx | Vx]   ((n+m) x (n+1)); f.T @ V of control/iterative_ilqr.py:112-116
       const int fo = FSTEP ? t * FW : 0;
@@ -774,7 +736,14 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       if constexpr (!FSTEP) refresh_store();
       wave_sync();
       STAMP_END(5);
+    };
+    // two horizon steps per loop iteration (see the note on taken branches at the top of this file)
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+      step(t);
+      step(t - 1);
     }
+    if (t == 0) step(0);
   }
 
   // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
@@ -800,7 +769,7 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       }
     };
     load_step(0);
-    for (int t = 0; t < N; t++) {
+    auto step = [&](const int t) __attribute__((always_inline)) {
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
@@ -815,7 +784,13 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
+    };
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      step(t);
+      step(t + 1);
     }
+    if (t < N) step(t);
     cost = cost + terminal_cost(x, xT);
     wave_sync();
     return cost;

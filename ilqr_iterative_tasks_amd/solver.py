@@ -149,7 +149,7 @@ class BatchedILQR:
     def set_option(self, name: str, value: int) -> None:
         """Scheduling options (i2lqr_set_option in include/i2lqr.h); -1 restores the automatic
         choice.  Lane layouts: "defer_states", "reroll_nominal", "lds_gain_steps", "wave_tail";
-        problem-major layout: "per_step_jacobians".  All but "wave_tail" leave the
+        problem-major layout: "group_lanes" (8 / 64), "per_step_jacobians".  All but "wave_tail" leave the
         results bit-identical."""
         self._check(self.lib.i2lqr_set_option(self._handle, name.encode(), int(value)))
 

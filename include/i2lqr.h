@@ -175,8 +175,16 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
  *                     settle an accept / reject tie the other way and stop at a different
  *                     iteration).  0: off; automatic: 2048.
- * One problem per wavefront (problem-major layout), i2lqr_iterate / i2lqr_solve:
- *   "per_step_jacobians"  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
+ * Problem-major layout, i2lqr_iterate / i2lqr_solve:
+ *   "group_lanes"     lanes of a wavefront that work on one problem: 64 (one problem per
+ *                     wavefront, each lane one element of the Riccati step's products) or 8 (eight
+ *                     problems per wavefront, each lane one COLUMN of them: about a third of the
+ *                     instructions per horizon step; built for the bicycle plants with
+ *                     Q = R = 0 and horizons whose eight problem slices fit the LDS,
+ *                     I2LQR_ERR_UNSUPPORTED otherwise).  Automatic: 8 from 1024 problems where built.
+ *                     The two agree to round-off (1e-10 on one backward pass), not bit for bit:
+ *                     K^T Quu K is associated differently.
+ *   "per_step_jacobians"  ("group_lanes" 64)  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
  *                     30-52) are written to LDS by the parallel per-step phase, so the serial
  *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.
  *                     Automatic: on while every wavefront of the launch fits on the chip at once

@@ -25,23 +25,32 @@ def torch_mod():
     return torch
 
 
-# problem-major / one problem per wavefront; batch-minor / one per lane; batch-tiled / one per lane
-LAYOUTS = {"wave": 0, "lane": 1, "tiled": 2}
+# problem-major with one problem per wavefront ("wave") or eight problems per wavefront ("group":
+# the automatic choice for the bicycles with Q = R = 0); batch-minor / batch-tiled: one per lane
+LAYOUTS = {"wave": 0, "group": 0, "lane": 1, "tiled": 2}
+GROUP_LANES = {"wave": 64, "group": 8}
 
 
-@pytest.fixture(params=["wave", "lane"])
+@pytest.fixture(params=["wave", "group", "lane"])
 def layout(request):
     return request.param
 
 
+def pin_kernel(solver, layout):
+    """Problem-major solvers: pin the fused kernels to the family the test names."""
+    if layout in GROUP_LANES:
+        solver.set_option("group_lanes", GROUP_LANES[layout])
+    return solver
+
+
 def make_solver(system, N, dtype="f64", dt=1.0, layout="wave", **over):
     from ilqr_iterative_tasks_amd import BatchedILQR, default_config
-    if layout in ("lane", "tiled") and system == "quad12":
-        pytest.skip("quad12 (m = 4) is built for the problem-major layout only")
+    if layout in ("lane", "tiled", "group") and system == "quad12":
+        pytest.skip("quad12 (m = 4) is built for the one-problem-per-wavefront kernels only")
     cfg = default_config(system, N, dtype, dt=dt, layout=LAYOUTS[layout])
     for key, val in over.items():
         setattr(cfg, key, val)
-    return BatchedILQR(cfg), cfg
+    return pin_kernel(BatchedILQR(cfg), layout), cfg
 
 
 def oracle():
@@ -244,7 +253,7 @@ def test_solve_vs_oracle_bicycle6(torch_mod, layout):
 #                       equal on FP32_ITERS of them (measured 94.3 %: at a converged solution
 #                       `cost_new < cost` compares values that agree to fp32 round-off, the tie goes
 #                       either way and the lamb schedule then exits a few iterations apart) and
-#                       never more than 16 apart; every status a legal exit.
+#                       never more than 24 apart; every status a legal exit.
 FP32_COST, FP32_U, FP32_AGREE, FP32_ITERS = 1e-3, 1e-2, 0.95, 0.92
 
 
@@ -267,12 +276,12 @@ def _fp32_vs_oracle(solver, cfg, buf, ref, counts):
     if counts:
         it = buf["iters"].cpu().numpy()
         assert (it == ref["iters"]).mean() >= FP32_ITERS, (it == ref["iters"]).mean()
-        assert np.abs(it - ref["iters"]).max() <= 16
+        assert np.abs(it - ref["iters"]).max() <= 24
         assert it.min() >= 1 and it.max() <= cfg.max_iter
         assert (st == ref["status"]).mean() >= FP32_AGREE
 
 
-@pytest.mark.parametrize("lay", ["wave", "lane", "tiled"])
+@pytest.mark.parametrize("lay", ["wave", "group", "lane", "tiled"])
 def test_fp32_tracks_fp64_oracle(torch_mod, lay):
     """BASELINE configs[2] (n=6, m=2, N=20, fp32) inputs: one backward pass, 10 fused iterations
     and the solve to termination in fp32 against the fp64 oracle, tolerances above."""
@@ -353,8 +362,8 @@ def test_properties_full_size(torch_mod, dtype, B, layout):
     assert (solver.to_problem_major(a["U"]).abs() <= u_max[None, :, None]).all()
 
 
-@pytest.mark.parametrize("lay,B", [("wave", 131072), ("lane", 131072), ("tiled", 131072),
-                                   ("lane", 1 << 20), ("tiled", 1 << 20)])
+@pytest.mark.parametrize("lay,B", [("wave", 131072), ("group", 131072), ("lane", 131072),
+                                   ("tiled", 131072), ("lane", 1 << 20), ("tiled", 1 << 20)])
 def test_config4_sizes_properties_and_oracle_sample(torch_mod, lay, B):
     """BASELINE configs[3]: 2^20 problems over 8 GPUs = 131072 per GPU, and the whole 2^20 on one
     (fp64, n=6, m=2, N=20).  Size-independent properties over the full batch — determinism, returned
@@ -507,7 +516,7 @@ def test_per_step_jacobians_option_is_bit_identical(torch_mod, system, N, dt):
     arithmetic, so iterate() and solve() must agree bit for bit with the option forced off."""
     torch = torch_mod
     from ilqr_iterative_tasks_amd import workloads
-    solver, cfg = make_solver(system, N, dt=dt, layout="wave")
+    solver, cfg = make_solver(system, N, dt=dt, layout="wave")  # pins "group_lanes" to 64
     host = workloads.make_batch(cfg, 512)
     out = {}
     for flag in (0, 1, -1):
@@ -625,8 +634,9 @@ def test_edge_cases(torch_mod, layout):
     host3["x_term"][2, 0] = np.nan
     b4 = solver.solve(dev_batch(solver, host3))
     assert int(b4["status"][2]) == 4 and (b4["status"].cpu().numpy()[[0, 1, 3]] != 4).all()
-    # horizon limits: N = 1 and N = 64 (I2LQR_MAX_HORIZON)
-    for N in (1, 64):
+    # horizon limits: N = 1 and N = 64 (I2LQR_MAX_HORIZON; the eight problem slices of the
+    # eight-lane kernel fit the LDS up to N = 50 for this plant)
+    for N in (1, 50 if layout == "group" else 64):
         s2, c2 = make_solver("bicycle4", N, layout=layout)
         h = workloads.make_batch(c2, 33)
         ref = orc.ilqr_batch(c2, h["X"], h["U"], h["x_term"], h["lamb"], h["obs"], max_iter=5,
@@ -651,6 +661,60 @@ def test_edge_cases(torch_mod, layout):
         BatchedILQR(bad)
 
 
+def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
+    """"group_lanes": 8 (eight problems per wavefront) is the automatic choice for the bicycles with
+    Q = R = 0 and agrees with 64 (one problem per wavefront) to round-off — K^T Quu K is
+    associated differently — with identical iteration counts, statuses and lamb; where it is not
+    built, forcing it is an error and the automatic choice falls back."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    from ilqr_iterative_tasks_amd.solver import I2lqrError
+    for system, N, dt, B in (("bicycle6", 20, 0.25, 1027), ("bicycle4", 6, 1.0, 77),
+                             ("bicycle4", 50, 1.0, 9)):
+        cfg = default_config(system, N, "f64", dt=dt)
+        solver = BatchedILQR(cfg)
+        host = workloads.make_batch(cfg, B)
+        host["lamb"] = 10.0 ** np.random.default_rng(5).integers(-3, 3, B).astype(float)
+        out = {}
+        for lanes in (64, 8, -1):
+            solver.set_option("group_lanes", lanes)
+            out[lanes] = (solver.iterate(dev_batch(solver, host), 7), solver.solve(dev_batch(solver, host)))
+        auto = 8 if B >= 1024 else 64  # the automatic choice: eight lanes from 1024 problems
+        for a, b in zip(out[auto], out[-1]):
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(a[key], b[key]), (system, key)
+        for a, b in zip(out[8], out[64]):
+            same = (a["iters"] == b["iters"]) & (a["lamb"] == b["lamb"])
+            assert float(same.double().mean()) >= 0.99, system
+            assert torch.equal(a["status"][same], b["status"][same])
+            sm = same.cpu().numpy()
+            for key in ("X", "U"):
+                assert batch_rel_err(to_host(solver, a[key])[sm], to_host(solver, b[key])[sm],
+                                     floor=1e-2) < TOL_SOLVE, (system, key)
+    # stage weights: the automatic choice falls back, forcing is an error
+    cfg = default_config("bicycle4", 6)
+    cfg.set_matrix("R", np.diag([0.05, 0.05]))
+    solver = BatchedILQR(cfg)
+    host = workloads.make_batch(cfg, 16)
+    solver.iterate(dev_batch(solver, host), 2)
+    solver.set_option("group_lanes", 8)
+    with pytest.raises(I2lqrError, match="group_lanes"):
+        solver.iterate(dev_batch(solver, host), 2)
+    q = BatchedILQR(default_config("quad12", 10, dt=0.02))
+    q.set_option("group_lanes", 8)
+    with pytest.raises(I2lqrError, match="group_lanes"):
+        q.iterate(dev_batch(q, workloads.make_batch(q.cfg, 4)), 1)
+    with pytest.raises(I2lqrError):
+        q.set_option("group_lanes", 16)
+    # a horizon whose eight problem slices do not fit the LDS: automatic falls back, forcing fails
+    big = BatchedILQR(default_config("bicycle4", 64))
+    hb = workloads.make_batch(big.cfg, 5)
+    big.iterate(dev_batch(big, hb), 2)
+    big.set_option("group_lanes", 8)
+    with pytest.raises(I2lqrError, match="group_lanes"):
+        big.iterate(dev_batch(big, hb), 2)
+
+
 def test_negative_curvature_takes_the_eigenvalue_clamping_path(torch_mod, layout):
     """The kernels invert a positive-definite Quu directly and fall back to the reference's
     eig / clamp-negative / add-lamb construction (control/iterative_ilqr.py:118-123) otherwise.
@@ -659,7 +723,7 @@ def test_negative_curvature_takes_the_eigenvalue_clamping_path(torch_mod, layout
     orc = oracle()
     solver, cfg = make_solver("bicycle4", 6, layout=layout)
     cfg.set_matrix("Qt", 2 * np.diag([1.0, 1.0, 20.0, -2.5]))  # Quu_dd = l_uu + dt^2 Vxx[3][3] < 0
-    solver = BatchedILQR(cfg)
+    solver = pin_kernel(BatchedILQR(cfg), layout)
     host = workloads.make_batch(cfg, 192)
     rng = np.random.default_rng(11)
     host["U"] = rng.uniform(-1, 1, host["U"].shape) * np.array(cfg.u_max[:2])[None, :, None]
@@ -687,6 +751,9 @@ def test_nonzero_stage_weights_vs_oracle(torch_mod, layout):
     (nominal cost measured to xtarget, forward cost to x_terminal: iterative_ilqr.py:43 vs :151)."""
     from ilqr_iterative_tasks_amd import workloads
     orc = oracle()
+    if layout == "group":
+        pytest.skip("the eight-lane kernel is built for Q = R = 0 (other weights take the "
+                    "one-problem-per-wavefront kernel automatically)")
     solver, cfg = make_solver("bicycle4", 6, layout=layout)
     cfg.set_matrix("Q", np.diag([0.01, 0.02, 0.1, 0.05]) + 0.001)
     cfg.set_matrix("R", np.array([[0.05, 0.01], [0.01, 0.08]]))

@@ -18,6 +18,8 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
 iters = 10 if wl == "config2" else 4
 cfg = workloads.config_for(wl, sys.argv[1] if len(sys.argv) > 1 else "f64")
 solver = BatchedILQR(cfg)
+lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # "group_lanes": 64 or 8
+solver.set_option("group_lanes", lanes)
 host = workloads.make_batch(cfg, B)
 buf = solver.alloc(B)
 for key in ("X", "U", "x_term", "lamb"):
@@ -28,7 +30,10 @@ solver.lib.i2lqr_set_workspace(solver._handle, C.c_void_p(dbg.data_ptr()), dbg.n
 solver.iterate(buf, iters)
 torch.cuda.synchronize()
 d = dbg.double().mean(0).cpu().numpy() / iters
-names = ["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
+names = (["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
+         if lanes == 64 else
+         ["prep", "bwd P1 + T1 exchange", "bwd P2 (H column)", "bwd Quu + inverse",
+          "bwd gains + exchange", "bwd value update", "forward", "-"])
 tot = d.sum()
 for nm, v in zip(names, d):
     print(f"{nm:20s} {v:9.0f} cycles/iteration  {100 * v / tot:5.1f} %")
