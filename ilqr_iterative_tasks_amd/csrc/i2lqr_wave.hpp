@@ -513,7 +513,13 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
   // Needs prep() on the same trajectory.  Leaves the gains in LDS (Kk).  Three LDS round trips
   // per horizon step; every lane's role in each phase is fixed, so its indices are hoisted.
-  __device__ __forceinline__ void backward(int Xo, int Uo, const T (&xT)[n], T lamb) const {
+  // GENERAL = false (m == 2 plants): Quu is inverted in its positive-definite form only, the loop
+  // has no branch, and the return value says whether some Quu was not positive definite — the
+  // caller then repeats the pass with GENERAL = true.  Where Quu is positive definite both
+  // compute the same numbers (t_quu_inverse2_pd / t_quu_inverse2).
+  template <bool GENERAL = true>
+  __device__ __forceinline__ bool backward(int Xo, int Uo, const T (&xT)[n], T lamb) const {
+    bool bad = false;
     constexpr int NA = n + 1;                               // width of [Vxx | Vx], [K | k]
     constexpr int P1N = W * NA, P2N = W * W, P4N = n * NA;  // elements per phase
     constexpr int P1P = (P1N + LANES - 1) / LANES, P2P = (P2N + LANES - 1) / LANES,
@@ -700,7 +706,8 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
         Qv[r] = S[p4_q[r]];
       }
       if constexpr (!FSTEP) refresh_load(t > 0 ? t - 1 : 0);  // reads of the next step's refresh
-      quu_inverse(Quu, lamb, Qinv);
+      if constexpr (!GENERAL && m == 2) t_quu_inverse2_pd(Quu, lamb, Qinv, &bad);
+      else quu_inverse(Quu, lamb, Qinv);
       STAMP_END(3);
 #pragma unroll
       for (int r = 0; r < P4P; r++) {
@@ -744,11 +751,18 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       step(t - 1);
     }
     if (t == 0) step(0);
+    return bad;
   }
 
   // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
   // (Xo, Uo) nominal -> (Xn, Un) candidate; returns cost_new (stage cost measured to x_terminal).
-  __device__ __forceinline__ T forward(int Xo, int Uo, int Xn, int Un, const T (&xT)[n]) const {
+  // GENERAL = false: short sincos kernel only, *bad set if an angle left its range (the caller
+  // repeats the pass with GENERAL = true; see t_sincos_fast).
+  template <bool GENERAL = true>
+  __device__ __forceinline__ T forward(int Xo, int Uo, int Xn, int Un, const T (&xT)[n],
+                                       bool* bad = nullptr) const {
+    bool bad_local = false;
+    bool* const badp = bad ? bad : &bad_local;
     T x[n], u[m], xn[n];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = S[Xo + i];
@@ -779,7 +793,9 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
       }
       load_step(t + 1 < N ? t + 1 : t);
       publish<m>(Un + t * m, u);
-      Sys::step(c, x, u, xn);
+      T tr[NT];
+      Sys::template trig_g<GENERAL>(x, tr, badp);
+      Sys::step_tr(c, x, u, tr, xn);
       publish<n>(Xn + (t + 1) * n, xn);
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
@@ -868,11 +884,15 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
 #ifdef I2LQR_STAMPS
     STAMP_END(0);
 #endif
-    w.backward(Xo, Uo, xT, lamb);
+    // optimistic, branch-free passes first; the general forms only if a lane asked for them
+    if (__builtin_expect(__any(w.template backward<false>(Xo, Uo, xT, lamb)), 0))
+      w.template backward<true>(Xo, Uo, xT, lamb);
 #ifdef I2LQR_STAMPS
     STAMP_BEGIN();
 #endif
-    const T cost_new = w.forward(Xo, Uo, Xn, Un, xT);
+    bool big = false;
+    T cost_new = w.template forward<false>(Xo, Uo, Xn, Un, xT, &big);
+    if (__builtin_expect(__any(big), 0)) cost_new = w.template forward<true>(Xo, Uo, Xn, Un, xT);
 #ifdef I2LQR_STAMPS
     STAMP_END(6);
     if (a.dbg && w.sl == 0) {
