@@ -53,7 +53,7 @@ struct i2lqr_handle {
   int64_t ws_bytes;
   int64_t compact_min_batch;  // i2lqr_solve uses the chunked, compacting form from this batch; 0: never; -1: automatic
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
-  int opt_defer, opt_reroll, opt_lds_steps;
+  int opt_defer, opt_reroll, opt_lds_steps, opt_merge;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
@@ -268,6 +268,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (a.lds_steps > N) a.lds_steps = N;
     a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
     a.defer = 1;  // the forward pass stores no states; accepted steps re-roll them (see i2lqr_lane.hpp)
+    // ... and merge the accepted candidate inputs into the one input buffer.  fp64 (HBM-bound):
+    // 7.56 -> 7.23 KB per problem-iteration, +4.8 % it/s at 2^20 problems; fp32 (instruction-bound):
+    // the extra row writes cost 6 %, so the per-lane buffer swap stays (tools/ab_bench.py).
+    a.merge = sizeof(T) == 8 ? 1 : 0;
+    if (h->opt_merge >= 0) a.merge = h->opt_merge;
     a.dbg = nullptr;
 #ifdef I2LQR_STAMPS
     if (const char* e = getenv("I2LQR_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -788,6 +793,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
+  h->opt_merge = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -851,6 +857,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "defer_states")) h->opt_defer = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "reroll_nominal")) h->opt_reroll = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
+  else if (!strcmp(name, "merge_inputs")) h->opt_merge = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "group_lanes")) {

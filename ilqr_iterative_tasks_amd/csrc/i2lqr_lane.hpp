@@ -48,6 +48,7 @@ template <class T> struct LaneArgs {
   int defer;      // forward pass stores no states; an accepted step re-rolls them
   int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
   int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
+  int merge;      // deferred mode: accepted candidate inputs are merged into ONE input buffer
 };
 
 // words of T the workspace needs for B problems
@@ -214,7 +215,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // next block's inputs have arrived.  On gfx950 loads and stores share vmcnt and a wait with both
   // kinds pending drains the counter: this way everything pending at the one wait per block was
   // issued a whole block (RB steps) earlier.
-  __device__ __forceinline__ void restore_states_blocked(T* X, const T* U) const {
+  // MERGE (deferred mode): the inputs of the lanes that ACCEPTED come from the candidate buffer
+  // Un, the others keep theirs; every lane writes its current inputs back to U, so that U stays
+  // ONE buffer with full 64-lane rows for the whole wavefront whatever the lanes decided (per-lane
+  // buffer swapping split every input row of a wavefront with mixed decisions over two buffers:
+  // twice the lines per access).
+  template <bool MERGE = false>
+  __device__ __forceinline__ void restore_states_blocked(T* X, T* U, const T* Un = nullptr,
+                                                         bool acc = false) const {
     constexpr int RB = 4;
     T x[n], xn[n], tr[NT];
 #pragma unroll
@@ -225,7 +233,13 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       for (int j = 0; j < RB; j++)
         if (b * RB + j < N) {
 #pragma unroll
-          for (int a = 0; a < m; a++) ul[j][a] = at(U, ru(a, b * RB + j));
+          for (int a = 0; a < m; a++) {
+            ul[j][a] = at(U, ru(a, b * RB + j));
+            if constexpr (MERGE) {
+              const T un = at(Un, ru(a, b * RB + j));
+              ul[j][a] = acc ? un : ul[j][a];
+            }
+          }
         }
     };
     auto block = [&](const int b, T (&ucur)[RB][m], T (&unext)[RB][m])
@@ -241,6 +255,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         for (int j = 0; j < RB; j++)
 #pragma unroll
           for (int i = 0; i < n; i++) at(X, rx(i, (b - 1) * RB + j + 1)) = xs[j][i];
+      }
+      if constexpr (MERGE) {
+#pragma unroll
+        for (int j = 0; j < RB; j++)
+          if (b * RB + j < N) {
+#pragma unroll
+            for (int a = 0; a < m; a++) at(U, ru(a, b * RB + j)) = u[j][a];
+          }
       }
 #pragma unroll
       for (int j = 0; j < RB; j++)
@@ -271,18 +293,31 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
   }
 
-  __device__ __forceinline__ void restore_states_paired(T* X, const T* U) const {
+  template <bool MERGE = false>
+  __device__ __forceinline__ void restore_states_paired(T* X, T* U, const T* Un = nullptr,
+                                                        bool acc = false) const {
     T x[n], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
     // two input register sets take turns, each re-loaded for step t+2 right after step t read it
+    auto load_u = [&](const int t, T (&ul)[m]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        ul[a] = at(U, ru(a, t));
+        if constexpr (MERGE) {
+          const T un = at(Un, ru(a, t));
+          ul[a] = acc ? un : ul[a];
+        }
+      }
+    };
     auto body = [&](const int t, T (&ul)[m]) __attribute__((always_inline)) {
       T u[m];
 #pragma unroll
       for (int a = 0; a < m; a++) u[a] = ul[a];
-      if (t + 2 < N) {
+      if (t + 2 < N) load_u(t + 2, ul);
+      if constexpr (MERGE) {
 #pragma unroll
-        for (int a = 0; a < m; a++) ul[a] = at(U, ru(a, t + 2));
+        for (int a = 0; a < m; a++) at(U, ru(a, t)) = u[a];
       }
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
@@ -293,12 +328,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
     };
     T ua[m], ub[m];
-#pragma unroll
-    for (int a = 0; a < m; a++) ua[a] = at(U, ru(a, 0));
-    if (N >= 2) {
-#pragma unroll
-      for (int a = 0; a < m; a++) ub[a] = at(U, ru(a, 1));
-    }
+    load_u(0, ua);
+    if (N >= 2) load_u(1, ub);
     int t = 0;
     for (; t + 1 < N; t += 2) {
       body(t, ua);
@@ -309,9 +340,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 
   // fp32 (DEEP) takes the blocked form (+3-4 %); in fp64 its 40 extra live registers cost more
   // AGPR traffic than the waits it saves (-1.5 %)
-  __device__ __forceinline__ void restore_states(T* X, const T* U) const {
+  __device__ __forceinline__ void restore_states(T* X, T* U) const {
     if constexpr (DEEP) restore_states_blocked(X, U);
     else restore_states_paired(X, U);
+  }
+  // deferred mode: merge the accepted candidates into U (one buffer, full rows) and re-roll
+  __device__ __forceinline__ void merge_and_restore(T* X, T* U, const T* Un, bool acc) const {
+    if constexpr (DEEP) restore_states_blocked<true>(X, U, Un, acc);
+    else restore_states_paired<true>(X, U, Un, acc);
   }
 
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
@@ -762,14 +798,20 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 #endif
     it++;
     const bool accepted = cost_new < cost;
-    if (accepted) {
-      T* tp = Uc; Uc = Un; Un = tp;
-    }
     // X must hold the states of each lane's CURRENT inputs: deferred mode owes them to the lanes
     // that accepted, in-place mode to the lanes that rejected.  If any lane of the wavefront needs
     // it, ALL of them re-roll and store (the others rewrite what is already there, bit for bit):
     // full 64-lane rows instead of masked partial ones, which cost a read-modify-write in HBM.
-    if (__any(a.defer ? accepted : !accepted)) w.restore_states(X, Uc);
+    if (a.defer && a.merge) {
+      // the current inputs stay in ONE buffer for the whole wavefront: accepted candidates are
+      // merged into it during the re-roll (Uc == U0, Un == workspace throughout)
+      if (__any(accepted)) w.merge_and_restore(X, Uc, Un, accepted);
+    } else {
+      if (accepted) {
+        T* tp = Uc; Uc = Un; Un = tp;
+      }
+      if (__any(a.defer ? accepted : !accepted)) w.restore_states(X, Uc);
+    }
     if (accepted) {  // control/iterative_ilqr.py:74-80
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;

@@ -163,6 +163,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     (rejected steps cost no state traffic at all).  0: candidate states are
  *                     written in place and a rejected step re-rolls the nominal ones.
  *                     Automatic: 1 for i2lqr_iterate, 0 for i2lqr_solve.
+ *   "merge_inputs"    ("defer_states" 1) 1: the re-roll of a wavefront in which some lane accepted
+ *                     also merges the accepted candidate inputs into the one input buffer (every
+ *                     lane rewrites its row entry), so all input rows of a wavefront stay full
+ *                     64-lane rows of ONE buffer.  0: per-lane buffer swap (no copy, but after
+ *                     mixed decisions every input row access touches two buffers).  Automatic: 1 in
+ *                     fp64 (bandwidth-bound), 0 in fp32 (instruction-bound).
  *   "reroll_nominal"  1: the forward pass re-rolls the nominal states it needs for the feedback
  *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
  *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the

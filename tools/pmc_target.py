@@ -17,10 +17,14 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--layout", default="wave")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--launches", type=int, default=5)
+ap.add_argument("--options", default="", help="i2lqr_set_option settings: 'name=value name=value'")
 args = ap.parse_args()
 cfg = workloads.config_for(args.workload, args.dtype)
 cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[args.layout]
 solver = BatchedILQR(cfg)
+for kv in args.options.split():
+    key, val = kv.split("=")
+    solver.set_option(key, int(val))
 host = workloads.make_batch(cfg, args.batch)
 dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
 bufs = []
