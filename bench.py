@@ -107,19 +107,27 @@ def spawn_ranks(args) -> int:
 # one rank
 # ------------------------------------------------------------------------------------------------
 
-LANE_THRESHOLD = 4096  # per-GPU batch from which the one-problem-per-lane kernels win
+# per-GPU batch from which the one-problem-per-lane kernels win over the eight-problems-per-
+# wavefront kernel (tools/ab_bench.py, tools/solve_bench.py; fp64, n=6, N=20):
+#   iterate: 8192: 165 vs 152 M it/s, 12288: 171 vs 223;  solve: 8192: 1.18 vs 1.68 ms,
+#   16384: 1.80 vs 1.81 ms, 65536: 5.6 vs 2.5 ms
+LANE_THRESHOLD = 10240
+LANE_THRESHOLD_SOLVE = 16384
 LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
-LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",
+LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",  # eight from 1024 problems
                "lane": "batch-minor (one problem per lane)",
                "tiled": "batch-tiled x64 (one problem per lane)"}
 
 
-def pick_layout(args, B):
-    """wave: one problem per wavefront (latency path); lane / tiled: one problem per lane over
-    batch-minor rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
+def pick_layout(args, B, solve=False, cfg=None):
+    """wave: problem-major (one problem per wavefront below 1024 problems, eight per wavefront from
+    there: the library's automatic choice); lane / tiled: one problem per lane over batch-minor
+    rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
     if args.layout != "auto":
         return args.layout
-    if B < LANE_THRESHOLD:
+    if cfg is not None and cfg.system_id == 2:
+        return "wave"  # quad12 (m = 4) is built for the problem-major kernels
+    if B < (LANE_THRESHOLD_SOLVE if solve else LANE_THRESHOLD):
         return "wave"
     return "lane" if B % 64 else "tiled"
 
@@ -153,7 +161,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     import torch.distributed as dist
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    layout = pick_layout(args, B)
+    layout = pick_layout(args, B, cfg=cfg)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     host = workloads.make_batch(cfg, B, offset=rank * B)
@@ -227,9 +235,11 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
     # every problem executes exactly `iters` iterations (no early exit): check on the last set
     assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
+    kernel = solver.iterate_kernel(B)
     res = dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps,
-               rank_seconds=rank_seconds, layout=LAYOUT_NAME[layout],
-               kernel="k_iterate" if layout == "wave" else "k_lane_iterate")
+               rank_seconds=rank_seconds, kernel=kernel,
+               layout=(LAYOUT_NAME[layout] if kernel != "k_group_iterate" else
+                       "problem-major (eight problems per wavefront)"))
     if exchange is not None:
         res["exchange_ms"] = sum(a.elapsed_time(b) for a, b in zip(xv0, xv1)) / steps
         # the pick is the same on every rank and is the arg-min of the gathered vector
@@ -249,7 +259,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
 def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    layout = pick_layout(args, B)
+    layout = pick_layout(args, B, solve=True)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     if single_launch:
@@ -267,12 +277,12 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     ms = e0.elapsed_time(e1) / reps
     it = sets[1]["iters"].double()
     executed = float(it.sum())
+    kernel = solver.iterate_kernel(B)
+    if kernel == "k_lane_iterate" and not single_launch:
+        kernel = "k_lane_iterate chunks + k_lane_compact + k_iterate tail"
     solver.close()
     return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
-            "iterations_mean": executed / B, "iterations_max": int(it.max()),
-            "kernel": "k_iterate" if layout == "wave" else (
-                "k_lane_iterate" if single_launch else
-                "k_lane_iterate chunks + k_lane_compact + k_iterate tail")}
+            "iterations_mean": executed / B, "iterations_max": int(it.max()), "kernel": kernel}
 
 
 def lib_sha256():
@@ -462,7 +472,7 @@ def run_rank(args) -> int:
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
     key = f"{args.workload}:{dtype}:B{B}:it{args.iters}"
-    waves = B if res["kernel"] == "k_iterate" else (B + 63) // 64
+    waves = {"k_iterate": B, "k_group_iterate": (B + 7) // 8}.get(res["kernel"], (B + 63) // 64)
 
     out = {
         "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"
@@ -520,7 +530,8 @@ def run_rank(args) -> int:
             "exchange_ms_per_step": r.get("exchange_ms"), "nccl_world": r.get("nccl_world")}
     if world == 1 and not args.no_extra:
         # secondary single-GPU workloads (not the headline): large batches of the same problem
-        for name, eb, edt in (("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32"),
+        for name, eb, edt in (("B4096_f64", 4096, "f64"), ("B8192_f64", 8192, "f64"),
+                              ("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32"),
                               ("B1048576_f64", 1 << 20, "f64"), ("B1048576_f32", 1 << 20, "f32")):
             ecfg = workloads.config_for(args.workload, edt)
             nst = 3 if eb > 100000 else 6
@@ -532,6 +543,18 @@ def run_rank(args) -> int:
                            "kernel_ms": r["kernel_ms"], "achieved_GBs": ach,
                            "hbm_frac": ach / HBM_PEAK_GBS,
                            "traffic": pmc.get(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
+        # BASELINE configs[4]: quadrotor-sized n=12, m=4, N=50, B=65536, fp64 (33912 algorithmic
+        # bytes per iteration); 4 fused iterations per launch
+        qcfg = workloads.config_for("config5", "f64")
+        qargs = argparse.Namespace(**{**vars(args), "iters": 4})
+        r = run_gpu(qargs, qcfg, 65536, 0, 1, torch, dist_mod, 2, 1, with_tail=False)
+        qb = workloads.algorithmic_bytes_per_iteration(qcfg)
+        ach = qb * 65536 * 4 / (r["kernel_ms"] * 1e-3) / 1e9
+        extra["config5_quad12_B65536_f64"] = {
+            "iterations_per_s": r["iterations"] / r["seconds"], "kernel": r["kernel"],
+            "layout": r["layout"], "kernel_ms": r["kernel_ms"], "iterations_per_launch": 4,
+            "algorithmic_bytes_per_iteration": qb, "achieved_GBs": ach,
+            "hbm_frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("config5:f64:B65536:it4")}
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
         # problem is done, so this is below the fixed-count rate.  Default = chunked solve with

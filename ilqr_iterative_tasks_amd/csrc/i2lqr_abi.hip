@@ -868,6 +868,15 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   return I2LQR_OK;
 }
 
+const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) {
+  if (!h) return "";
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return "k_lane_iterate";
+  const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
+  const bool can = m2 && group_supported(h->cfg);
+  if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
+  return "k_iterate";
+}
+
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes) {
   if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
   if (bytes < 0 || (bytes > 0 && !workspace) || ((uintptr_t)workspace & 15))

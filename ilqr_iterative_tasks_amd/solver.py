@@ -153,6 +153,10 @@ class BatchedILQR:
         results bit-identical."""
         self._check(self.lib.i2lqr_set_option(self._handle, name.encode(), int(value)))
 
+    def iterate_kernel(self, B: int) -> str:
+        """Name of the kernel iterate() / solve() launch for B problems (rocprofv3 traces)."""
+        return self.lib.i2lqr_iterate_kernel(self._handle, int(B)).decode()
+
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,
                            device=self.device)

@@ -198,6 +198,11 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  */
 int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 
+/* Name of the kernel i2lqr_iterate / i2lqr_solve launch for a batch of B problems with the handle's
+ * current options ("k_iterate", "k_group_iterate", "k_lane_iterate"): what to look for in a
+ * rocprofv3 kernel trace.  Host only; "" for a NULL handle. */
+const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B);
+
 /*
  * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.
  * In: X[.,:,0] = x0, U.  Out: U clipped in place, X[.,:,1..N], cost[B] (stage cost to xtarget +

@@ -1,36 +1,60 @@
 #!/bin/bash
 # One-shot refresh of profiles/ on the GPU box (run from the repo root through gpurun):
-#   1. HBM traffic of the dominant kernels (tools/collect_pmc.sh: separate --pmc passes)
-#   2. the bench.py JSON line (reads the fresh traffic numbers)
-#   3. rocprofv3 --kernel-trace --stats of the same bench command (no counters in this pass)
+#   per workload:  rocprofv3 --kernel-trace --stats           -> kstats_<workload>.csv
+#                  rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ cycle counters | SQ instruction counters
+#                  (four SEPARATE passes, never combined with traces: MI355X_MICROARCH.md §HBM)
+#   then           summarise (tools/summarise_profiles.py) -> pmc_traffic.json stamped with the
+#                  sha256 of the library the counters were collected on
+#                  bench.py JSON line + kernel stats of the bench command itself
 # Results land in gpurun_out/profiles_new/ — copy them into profiles/ afterwards.
+#   bash tools/collect_profiles.sh [round tag, default r02]
 set -u
 ROOT=$(pwd)
+TAG=${1:-r02}
 NEW=$ROOT/gpurun_out/profiles_new
-mkdir -p "$NEW"
-bash tools/collect_pmc.sh > "$NEW/collect_pmc.log" 2>&1
-cp "$ROOT/gpurun_out/pmc/summary.json" "$NEW/pmc_hbm_traffic_summary.json"
-python3 - "$NEW/pmc_hbm_traffic_summary.json" "$ROOT/profiles/pmc_traffic.json" <<'PY'
-import json, sys
-s = json.load(open(sys.argv[1]))
-out = {"_source": "tools/collect_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
-       "FETCH_SIZE x2.0 calibrated on 8 B/lane and 4 B/lane streaming copies of known size; "
-       "WRITE_SIZE exact); bytes per launch of 10 fused iterations"}
-for key, src, kern in (("config2:f64:B1024:it10", "wave_f64_B1024", "k_iterate (wave)"),
-                       ("config2:f64:B65536:it10", "lane_f64_B65536",
-                        "k_lane_iterate (batch-minor; tiled measures the same)"),
-                       ("config2:f32:B65536:it10", "tiled_f32_B65536", "k_lane_iterate (tiled)"),
-                       ("config2:f64:B1048576:it10", "tiled_f64_B1048576", "k_lane_iterate (tiled)")):
-    out[key] = {"hbm_bytes_per_launch": s[src]["hbm_bytes_per_launch"], "kernel": kern}
-    if "sq_shares_of_wave_cycles" in s[src]:  # third --pmc pass: SQ counters
-        out[key]["sq_shares_of_wave_cycles"] = s[src]["sq_shares_of_wave_cycles"]
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-PY
-cp "$ROOT/profiles/pmc_traffic.json" "$NEW/pmc_traffic.json"
-python3 bench.py 2> "$NEW/bench.err" | tail -1 > "$NEW/bench.json"
+RAW=$ROOT/gpurun_out/prof_raw
+rm -rf "$NEW" "$RAW"; mkdir -p "$NEW" "$RAW"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$NEW/kstats" -- \
-  python3 "$ROOT/bench.py" --no-cpu-baseline --steps 20 > "$NEW/kstats.log" 2>&1
-find "$NEW/kstats" -name "*kernel_stats.csv" -exec cp {} "$NEW/kernel_stats_bench.csv" \;
-rm -rf "$NEW/kstats"
-head -c 600 "$NEW/bench.json"; echo; head -8 "$NEW/kernel_stats_bench.csv"
+# name            workload dtype batch    layout iters launches
+WORKLOADS="
+config2_f64_B1024    config2 f64 1024    wave  10 20
+config2_f64_B4096    config2 f64 4096    wave  10 10
+config2_f64_B65536   config2 f64 65536   tiled 10 6
+config2_f32_B65536   config2 f32 65536   tiled 10 6
+config2_f64_B1048576 config2 f64 1048576 tiled 10 3
+config2_f32_B1048576 config2 f32 1048576 tiled 10 3
+config5_f64_B65536   config5 f64 65536   wave  4  2
+"
+SQ_CYC="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES"
+SQ_INS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH"
+target() { echo python3 $ROOT/tools/pmc_target.py --workload $1 --dtype $2 --batch $3 --layout $4 --iters $5 --launches $6; }
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --output-format csv -d "$RAW/calib_$ctr" -- python3 $ROOT/tools/pmc_calib.py \
+    > "$RAW/calib_$ctr.log" 2>&1
+done
+echo "$WORKLOADS" | while read name wl dt b lay it ln; do
+  [ -z "$name" ] && continue
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/${name}_kstats" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_kstats.log" 2>&1
+  find "$RAW/${name}_kstats" -name "*kernel_stats.csv" -exec cp {} "$NEW/${TAG}_kstats_${name}.csv" \;
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$RAW/${name}_FETCH_SIZE" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_FETCH_SIZE.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$RAW/${name}_WRITE_SIZE" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_WRITE_SIZE.log" 2>&1
+  rocprofv3 --pmc $SQ_CYC --output-format csv -d "$RAW/${name}_SQCYC" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_SQCYC.log" 2>&1
+  rocprofv3 --pmc $SQ_INS --output-format csv -d "$RAW/${name}_SQINS" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_SQINS.log" 2>&1
+  echo "collected $name"
+done
+cd "$ROOT"
+python3 tools/summarise_profiles.py "$RAW" "$NEW" "$TAG" > "$NEW/summarise.log" 2>&1
+cp "$NEW/pmc_traffic.json" "$ROOT/profiles/pmc_traffic.json"   # bench.py reads it from profiles/
+python3 bench.py 2> "$NEW/bench.err" | tail -1 > "$NEW/${TAG}_bench.json"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/bench_kstats" -- \
+  python3 "$ROOT/bench.py" --no-cpu-baseline --no-extra > "$RAW/bench_kstats.log" 2>&1
+find "$RAW/bench_kstats" -name "*kernel_stats.csv" -exec cp {} "$NEW/${TAG}_kstats_bench_headline.csv" \;
+cd "$ROOT"
+cat "$NEW/summarise.log" | tail -30
+head -c 900 "$NEW/${TAG}_bench.json"; echo
