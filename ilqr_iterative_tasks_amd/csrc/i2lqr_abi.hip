@@ -143,6 +143,22 @@ template <class T, class Sys> struct Launch {
     } else if (h->opt_group == 8) {
       return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 is built for the m = 2 plants only");
     }
+    // Sixteen lanes per problem, four problems per wavefront (i2lqr_quad.hpp): the n + m = 16 plant.
+    // Needs the caller's workspace (i2lqr_workspace_bytes); automatic whenever it is registered.
+    if constexpr (n + m == 16) {
+      const bool can = quad_supported(h->cfg);
+      const bool have_ws = h->ws && h->ws_bytes >= quad_workspace_bytes(h->cfg, B);
+      if (h->opt_group == 16 && !(can && have_ws))
+        return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 16 needs Q = R = 0 and a registered "
+                    "workspace of i2lqr_workspace_bytes() (%lld B for this batch)",
+                    (long long)quad_workspace_bytes(h->cfg, B));
+      if ((h->opt_group == 16 || h->opt_group < 0) && can && have_ws) {
+        HIP_TRY(quad_iterate<T>(h->cfg, a, h->ws, s));
+        return I2LQR_OK;
+      }
+    } else if (h->opt_group == 16) {
+      return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 16 is built for the n + m = 16 plant only");
+    }
     // Per-step F matrices (prep() writes them in parallel over t; the serial recursion then has no
     // Jacobian refresh) double the LDS slice: taken when every wavefront of the launch still fits
     // on the chip at once, i.e. in the latency-bound regime this variant exists for.
@@ -823,7 +839,8 @@ int i2lqr_destroy(i2lqr_handle* h) {
 }
 
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
-  if (!h || B < 0 || h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) return 0;
+  if (!h || B < 0) return 0;
+  if (h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) return quad_workspace_bytes(h->cfg, B);
   const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
   const int N = h->cfg.N;
   const bool f64 = h->cfg.dtype == I2LQR_F64;
@@ -861,7 +878,8 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "group_lanes")) {
-    if (v != -1 && v != 8 && v != 64) return fail(I2LQR_ERR_INVALID, "\"group_lanes\" is 8, 64 or -1");
+    if (v != -1 && v != 8 && v != 16 && v != 64)
+      return fail(I2LQR_ERR_INVALID, "\"group_lanes\" is 8, 16, 64 or -1");
     h->opt_group = v;
   }
   else return fail(I2LQR_ERR_INVALID, "unknown option '%s'", name);
@@ -874,6 +892,9 @@ const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) {
   const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
   const bool can = m2 && group_supported(h->cfg);
   if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
+  if ((h->opt_group == 16 || h->opt_group < 0) && quad_supported(h->cfg) && h->ws &&
+      h->ws_bytes >= quad_workspace_bytes(h->cfg, B))
+    return "k_quad_iterate";
   return "k_iterate";
 }
 

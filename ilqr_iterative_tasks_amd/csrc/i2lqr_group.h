@@ -1,5 +1,5 @@
-// Launcher of the eight-lanes-per-problem kernel (i2lqr_group.hpp), compiled in its own translation
-// unit (i2lqr_group.hip).
+// Launchers of the eight- / sixteen-lanes-per-problem kernels (i2lqr_group.hpp, i2lqr_quad.hpp),
+// compiled in their own translation units (i2lqr_group.hip, i2lqr_quad.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,5 +14,12 @@ bool group_supported(const i2lqr_config& cfg);
 // error of the attribute call / launch.
 template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                             hipStream_t stream);
+
+// Sixteen lanes per problem (i2lqr_quad.hpp; the n + m = 16 plant quad12, Q = R = 0): needs a
+// caller-provided HBM workspace of quad_workspace_bytes() for B problems.
+bool quad_supported(const i2lqr_config& cfg);
+int64_t quad_workspace_bytes(const i2lqr_config& cfg, int64_t B);
+template <class T> hipError_t quad_iterate(const i2lqr_config& cfg, const IterArgs<T>& a, void* ws,
+                                           hipStream_t stream);
 
 }  // namespace i2lqr

@@ -269,6 +269,149 @@ __device__ __forceinline__ void t_quu_inverse2(const T (&Quu)[4], T lamb, T (&in
   }
 }
 
+// Regularised inverse of an m x m Q_uu, m > 2 (control/iterative_ilqr.py:118-123: eigen-
+// decomposition, negative eigenvalues clamped, lamb added; no reference counterpart at m > 2,
+// the oracle follows the same construction).  GENERAL = false: the positive-definite form alone,
+// *bad set (never cleared) if Quu is not positive definite (protocol of t_sincos_fast).
+template <class T, int m, bool GENERAL>
+__device__ __forceinline__ void t_quu_inverse_m(const T (&Quu)[m * m], T lamb, T (&inv)[m * m],
+                                                bool* bad) {
+  // Symmetrised Quu.  Fast path (the only one taken in practice: l_uu carries the strictly
+  // positive input-barrier curvature): if Quu is positive definite no eigenvalue is clamped
+  // and inv = (Quu + lamb I)^-1, computed by Cholesky.  Otherwise: cyclic Jacobi, clamp, add.
+  T Sm[m * m];
+#pragma unroll
+  for (int i = 0; i < m; i++)
+#pragma unroll
+    for (int j = 0; j < m; j++) Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
+  // Square-root-free LDL^T of Sm (positive-definiteness test: all pivots > 0) and of
+  // Sm + lamb I; unit lower factors Lp, Lr, pivots dp, dr (reciprocals ip, ir).
+  T Lp[m * m], Lr[m * m], ir[m];
+  bool pd = true;
+#pragma unroll
+  for (int j = 0; j < m; j++) {
+    T dp = Sm[j * m + j], dr = Sm[j * m + j] + lamb;
+    T wp[m], wr[m];  // L_jk d_k
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      wp[k] = Lp[j * m + k];
+      wr[k] = Lr[j * m + k];
+    }
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      // Lp/Lr hold L_jk d_k below the diagonal until column j is finished (see below)
+      dp -= wp[k] * Lp[k * m + j];
+      dr -= wr[k] * Lr[k * m + j];
+    }
+    pd = pd && (dp > T(0));
+    const T ipj = t_rcp(dp > T(0) ? dp : T(1));
+    ir[j] = t_rcp(dr > T(0) ? dr : T(1));
+#pragma unroll
+    for (int i = j + 1; i < m; i++) {
+      T vp = Sm[i * m + j], vr = Sm[i * m + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) {
+        vp -= Lp[i * m + k] * Lp[k * m + j];
+        vr -= Lr[i * m + k] * Lr[k * m + j];
+      }
+      // lower triangle keeps W_ij = L_ij d_j, upper triangle keeps L_ij (transposed slot)
+      Lp[i * m + j] = vp;
+      Lr[i * m + j] = vr;
+      Lp[j * m + i] = vp * ipj;
+      Lr[j * m + i] = vr * ir[j];
+    }
+  }
+  // Li = Lr^-1 (unit lower), then inv = Li^T diag(ir) Li.  L_ij lives at Lr[j * m + i].
+  T Li[m * m];
+#pragma unroll
+  for (int i = 0; i < m; i++)
+#pragma unroll
+    for (int j = 0; j < m; j++) Li[i * m + j] = (i == j) ? T(1) : T(0);
+#pragma unroll
+  for (int j = 0; j < m; j++) {
+#pragma unroll
+    for (int i = j + 1; i < m; i++) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = j; k < i; k++) acc += Lr[k * m + i] * Li[k * m + j];
+      Li[i * m + j] = -acc;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < m; i++)
+#pragma unroll
+    for (int j = i; j < m; j++) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = j; k < m; k++) acc += Li[k * m + i] * ir[k] * Li[k * m + j];
+      inv[i * m + j] = acc;
+      inv[j * m + i] = acc;
+    }
+  if constexpr (!GENERAL) {
+    *bad = *bad || !pd;
+  } else if (__builtin_expect(__any(!pd), 0)) {
+    // cyclic Jacobi on the symmetrised matrix, clamp, add lamb (lanes with a positive-definite
+    // Quu keep the form above)
+    T ginv[m * m];
+    {
+      T V[m * m];
+#pragma unroll
+      for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) V[i * m + j] = (i == j) ? T(1) : T(0);
+      for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+        for (int p = 0; p < m - 1; p++)
+#pragma unroll
+          for (int q = p + 1; q < m; q++) {
+            const T apq = Sm[p * m + q];
+            const T app = Sm[p * m + p], aqq = Sm[q * m + q];
+            // rotation angle; apq == 0 gives the identity rotation
+            const T tau = (aqq - app) / (T(2) * apq);
+            T tt = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
+            tt = (apq == T(0)) ? T(0) : tt;
+            const T cs = T(1) / t_sqrt(T(1) + tt * tt), sn = tt * cs;
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T skp = Sm[k * m + p], skq = Sm[k * m + q];
+              Sm[k * m + p] = cs * skp - sn * skq;
+              Sm[k * m + q] = sn * skp + cs * skq;
+            }
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T spk = Sm[p * m + k], sqk = Sm[q * m + k];
+              Sm[p * m + k] = cs * spk - sn * sqk;
+              Sm[q * m + k] = sn * spk + cs * sqk;
+            }
+#pragma unroll
+            for (int k = 0; k < m; k++) {
+              const T vkp = V[k * m + p], vkq = V[k * m + q];
+              V[k * m + p] = cs * vkp - sn * vkq;
+              V[k * m + q] = sn * vkp + cs * vkq;
+            }
+          }
+      }
+      T wr[m];
+#pragma unroll
+      for (int e = 0; e < m; e++) {
+        const T we = Sm[e * m + e];
+        wr[e] = T(1) / ((we < T(0) ? T(0) : we) + lamb);
+      }
+#pragma unroll
+      for (int i = 0; i < m; i++)
+#pragma unroll
+        for (int j = 0; j < m; j++) {
+          T acc = T(0);
+#pragma unroll
+          for (int e = 0; e < m; e++) acc += V[i * m + e] * wr[e] * V[j * m + e];
+          ginv[i * m + j] = acc;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < m * m; e++) inv[e] = pd ? inv[e] : ginv[e];
+  }
+}
+
 // The library is built with -ffp-contract=off so that one source expression rounds the same way
 // in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
 // the dot products of the Riccati step ask for the fused multiply-add explicitly.
@@ -530,6 +673,31 @@ template <class T> struct Quad12 {
       v[29 + j] = ay;
       v[33 + j] = az;
     }
+  }
+  // compile-time pattern of F = [A | B]: 0 zero, 1 one, 2 dt, 3 + v = varying entry v,
+  // 100 + q = plant constant q (plant_const below)
+  static constexpr int NCONST = 6;
+  static constexpr int pat(int i, int j) {
+    for (int v = 0; v < NVAR; v++)
+      if (var_idx_c(v) == i * (n + m) + j) return 3 + v;
+    if (j < n) {
+      if (i == j) return 1;
+      if (i < 3 && j == i + 6) return 2;  // d pos / d vel
+      if (i == 3 && j == 9) return 2;     // d phi / d p
+      return 0;
+    }
+    const int a = j - n;
+    if (i == 9) return a == 1 ? 100 : (a == 3 ? 101 : 0);
+    if (i == 10) return a == 2 ? 102 : (a == 0 ? 103 : 0);
+    if (i == 11) return (a & 1) == 0 ? 104 : 105;
+    return 0;
+  }
+  // {dt arm / Ix, -, dt arm / Iy, -, dt ctau / Iz, -}: the constant entries of B (jac_const)
+  template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg& c, int q) {
+    const T dt = c.dt, arm = c.sys_par[2], Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
+    const T ct = c.sys_par[6];
+    const T v = q < 2 ? dt * arm / Ix : (q < 4 ? dt * arm / Iy : dt * ct / Iz);
+    return (q & 1) ? -v : v;
   }
   static constexpr int var_idx_c(int v) {
     constexpr int W = n + m;

@@ -381,132 +381,8 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
     if constexpr (m == 2) {
       t_quu_inverse2(Quu, lamb, inv);
     } else {
-      // Symmetrised Quu.  Fast path (the only one taken in practice: l_uu carries the strictly
-      // positive input-barrier curvature): if Quu is positive definite no eigenvalue is clamped
-      // and inv = (Quu + lamb I)^-1, computed by Cholesky.  Otherwise: cyclic Jacobi, clamp, add.
-      T Sm[m * m];
-#pragma unroll
-      for (int i = 0; i < m; i++)
-#pragma unroll
-        for (int j = 0; j < m; j++) Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
-      // Square-root-free LDL^T of Sm (positive-definiteness test: all pivots > 0) and of
-      // Sm + lamb I; unit lower factors Lp, Lr, pivots dp, dr (reciprocals ip, ir).
-      T Lp[m * m], Lr[m * m], ir[m];
-      bool pd = true;
-#pragma unroll
-      for (int j = 0; j < m; j++) {
-        T dp = Sm[j * m + j], dr = Sm[j * m + j] + lamb;
-        T wp[m], wr[m];  // L_jk d_k
-#pragma unroll
-        for (int k = 0; k < j; k++) {
-          wp[k] = Lp[j * m + k];
-          wr[k] = Lr[j * m + k];
-        }
-#pragma unroll
-        for (int k = 0; k < j; k++) {
-          // Lp/Lr hold L_jk d_k below the diagonal until column j is finished (see below)
-          dp -= wp[k] * Lp[k * m + j];
-          dr -= wr[k] * Lr[k * m + j];
-        }
-        pd = pd && (dp > T(0));
-        const T ipj = t_rcp(dp > T(0) ? dp : T(1));
-        ir[j] = t_rcp(dr > T(0) ? dr : T(1));
-#pragma unroll
-        for (int i = j + 1; i < m; i++) {
-          T vp = Sm[i * m + j], vr = Sm[i * m + j];
-#pragma unroll
-          for (int k = 0; k < j; k++) {
-            vp -= Lp[i * m + k] * Lp[k * m + j];
-            vr -= Lr[i * m + k] * Lr[k * m + j];
-          }
-          // lower triangle keeps W_ij = L_ij d_j, upper triangle keeps L_ij (transposed slot)
-          Lp[i * m + j] = vp;
-          Lr[i * m + j] = vr;
-          Lp[j * m + i] = vp * ipj;
-          Lr[j * m + i] = vr * ir[j];
-        }
-      }
-      if (pd) {
-        // Li = Lr^-1 (unit lower), then inv = Li^T diag(ir) Li.  L_ij lives at Lr[j * m + i].
-        T Li[m * m];
-#pragma unroll
-        for (int i = 0; i < m; i++)
-#pragma unroll
-          for (int j = 0; j < m; j++) Li[i * m + j] = (i == j) ? T(1) : T(0);
-#pragma unroll
-        for (int j = 0; j < m; j++) {
-#pragma unroll
-          for (int i = j + 1; i < m; i++) {
-            T acc = T(0);
-#pragma unroll
-            for (int k = j; k < i; k++) acc += Lr[k * m + i] * Li[k * m + j];
-            Li[i * m + j] = -acc;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < m; i++)
-#pragma unroll
-          for (int j = i; j < m; j++) {
-            T acc = T(0);
-#pragma unroll
-            for (int k = j; k < m; k++) acc += Li[k * m + i] * ir[k] * Li[k * m + j];
-            inv[i * m + j] = acc;
-            inv[j * m + i] = acc;
-          }
-      } else {
-        T V[m * m];
-#pragma unroll
-        for (int i = 0; i < m; i++)
-#pragma unroll
-          for (int j = 0; j < m; j++) V[i * m + j] = (i == j) ? T(1) : T(0);
-        for (int sweep = 0; sweep < 12; sweep++) {
-#pragma unroll
-          for (int p = 0; p < m - 1; p++)
-#pragma unroll
-            for (int q = p + 1; q < m; q++) {
-              const T apq = Sm[p * m + q];
-              const T app = Sm[p * m + p], aqq = Sm[q * m + q];
-              // rotation angle; apq == 0 gives the identity rotation
-              const T tau = (aqq - app) / (T(2) * apq);
-              T tt = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
-              tt = (apq == T(0)) ? T(0) : tt;
-              const T cs = T(1) / t_sqrt(T(1) + tt * tt), sn = tt * cs;
-#pragma unroll
-              for (int k = 0; k < m; k++) {
-                const T skp = Sm[k * m + p], skq = Sm[k * m + q];
-                Sm[k * m + p] = cs * skp - sn * skq;
-                Sm[k * m + q] = sn * skp + cs * skq;
-              }
-#pragma unroll
-              for (int k = 0; k < m; k++) {
-                const T spk = Sm[p * m + k], sqk = Sm[q * m + k];
-                Sm[p * m + k] = cs * spk - sn * sqk;
-                Sm[q * m + k] = sn * spk + cs * sqk;
-              }
-#pragma unroll
-              for (int k = 0; k < m; k++) {
-                const T vkp = V[k * m + p], vkq = V[k * m + q];
-                V[k * m + p] = cs * vkp - sn * vkq;
-                V[k * m + q] = sn * vkp + cs * vkq;
-              }
-            }
-        }
-        T wr[m];
-#pragma unroll
-        for (int e = 0; e < m; e++) {
-          const T we = Sm[e * m + e];
-          wr[e] = T(1) / ((we < T(0) ? T(0) : we) + lamb);
-        }
-#pragma unroll
-        for (int i = 0; i < m; i++)
-#pragma unroll
-          for (int j = 0; j < m; j++) {
-            T acc = T(0);
-#pragma unroll
-            for (int e = 0; e < m; e++) acc += V[i * m + e] * wr[e] * V[j * m + e];
-            inv[i * m + j] = acc;
-          }
-      }
+      bool unused = false;
+      t_quu_inverse_m<T, m, true>(Quu, lamb, inv, &unused);
     }
   }
 

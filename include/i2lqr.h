@@ -127,11 +127,13 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
 int i2lqr_destroy(i2lqr_handle* h);
 
 /*
- * Scratch for the batch-minor (one problem per lane) kernels: the candidate trajectory of the
- * forward pass, the per-step trig caches and, when the caller does not ask for K/k, the gains.
- * The caller owns the memory (device pointer, 16-byte aligned) and registers it on the handle;
- * i2lqr_workspace_bytes() is 0 for the problem-major layout.  A call whose batch needs more than
- * the registered size fails with I2LQR_ERR_INVALID.
+ * Scratch in HBM.  Batch-minor / batch-tiled layouts (one problem per lane): candidate inputs, the
+ * gains when the caller does not ask for K/k, the work sets of the chunked solve; a call whose
+ * batch needs more than the registered size fails with I2LQR_ERR_INVALID.  Problem-major layout:
+ * 0 for the bicycles; for quad12 (n = 12, m = 4) the per-step records, gains and candidate
+ * trajectory of the sixteen-lanes-per-problem kernel ("group_lanes" 16: ~60 KB per problem at
+ * N = 50) — optional there: without it the one-problem-per-wavefront kernel runs.
+ * The caller owns the memory (device pointer, 16-byte aligned) and registers it on the handle.
  */
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B);
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
@@ -183,9 +185,10 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     iteration).  0: off; automatic: 2048.
  * Problem-major layout, i2lqr_iterate / i2lqr_solve:
  *   "group_lanes"     lanes of a wavefront that work on one problem: 64 (one problem per
- *                     wavefront, each lane one element of the Riccati step's products) or 8 (eight
- *                     problems per wavefront, each lane one COLUMN of them: about a third of the
- *                     instructions per horizon step; built for the bicycle plants with
+ *                     wavefront, each lane one element of the Riccati step's products), 8 (eight
+ *                     problems per wavefront, each lane one COLUMN of them; the bicycles) or 16
+ *                     (four problems per wavefront, quad12 with Q = R = 0 and a registered
+ *                     workspace; automatic then).  8 is built for the bicycle plants with
  *                     Q = R = 0 and horizons whose eight problem slices fit the LDS,
  *                     I2LQR_ERR_UNSUPPORTED otherwise).  Automatic: 8 from 1024 problems where built.
  *                     The two agree to round-off (1e-10 on one backward pass), not bit for bit:

@@ -717,6 +717,60 @@ def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
         big.iterate(dev_batch(big, hb), 2)
 
 
+@pytest.mark.parametrize("B,iters", [(67, 4), (1, 3), (256, 6)])
+def test_quad12_sixteen_lane_kernel_vs_oracle_and_wave_kernel(torch_mod, B, iters):
+    """BASELINE configs[4] shape (n=12, m=4, N=50, fp64): "group_lanes" 16 — four problems per
+    wavefront, each lane a column of the Riccati blocks, records / gains / candidate in the HBM
+    workspace — against the CPU oracle (fused iterations and the solve to termination, ragged batch
+    sizes) and against the one-problem-per-wavefront kernel.  It is the automatic choice once the
+    workspace is registered (BatchedILQR does that)."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    orc = oracle()
+    cfg = default_config("quad12", 50, "f64", dt=0.02)
+    solver = BatchedILQR(cfg)
+    host = workloads.make_batch(cfg, B)
+    host["lamb"] = 10.0 ** np.random.default_rng(2).integers(-2, 2, B).astype(float)
+    out = {}
+    for lanes in (64, 16, -1):
+        solver.set_option("group_lanes", lanes)
+        out[lanes] = (solver.iterate(dev_batch(solver, host), iters), solver.solve(dev_batch(solver, host)))
+        assert solver.iterate_kernel(B) == ("k_iterate" if lanes == 64 else "k_quad_iterate")
+    for a, b in zip(out[16], out[-1]):  # automatic == 16 (workspace registered): bit for bit
+        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+            assert torch.equal(a[key], b[key]), key
+    ref_it = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"],
+                            max_iter=iters, early_exit=False)
+    ref_so = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"])
+    for lanes in (16, 64):
+        it, so = out[lanes]
+        assert (it["iters"].cpu().numpy() == iters).all()
+        same = it["lamb"].cpu().numpy() == ref_it["lamb"]
+        assert same.mean() >= 0.97, (lanes, same.mean())
+        _check_flipped(it, ref_it, same, 1e-6)
+        for key in ("X", "U"):
+            assert batch_rel_err(to_host(solver, it[key])[same], ref_it[key][same]) < TOL_SOLVE, (lanes, key)
+        np.testing.assert_allclose(it["cost"].cpu().numpy()[same], ref_it["cost"][same], rtol=1e-7)
+        assert batch_rel_err(to_host(solver, it["K"])[same], ref_it["K"][same]) < 1e-6, lanes
+        assert batch_rel_err(to_host(solver, it["k"])[same], ref_it["k"][same], floor=1.0) < 1e-6
+        same = (so["iters"].cpu().numpy() == ref_so["iters"]) & (so["lamb"].cpu().numpy() == ref_so["lamb"])
+        assert same.mean() >= 0.97, (lanes, same.mean())
+        _check_flipped(so, ref_so, same, cfg.eps)
+        assert (so["status"].cpu().numpy()[same] == ref_so["status"][same]).all()
+        assert batch_rel_err(to_host(solver, so["X"])[same], ref_so["X"][same]) < TOL_SOLVE, lanes
+    # without a registered workspace the automatic choice is the one-problem-per-wavefront kernel
+    # and forcing sixteen lanes is an error
+    import ctypes as C
+    from ilqr_iterative_tasks_amd.solver import I2lqrError
+    bare = BatchedILQR(cfg)
+    assert bare.iterate_kernel(B) == "k_iterate"
+    bare.set_option("group_lanes", 16)
+    buf = dev_batch(bare, host)
+    bare.ensure_workspace = lambda B: None  # keep the handle without a workspace
+    with pytest.raises(I2lqrError, match="group_lanes"):
+        bare.iterate(buf, 1)
+
+
 def test_negative_curvature_takes_the_eigenvalue_clamping_path(torch_mod, layout):
     """The kernels invert a positive-definite Quu directly and fall back to the reference's
     eig / clamp-negative / add-lamb construction (control/iterative_ilqr.py:118-123) otherwise.
