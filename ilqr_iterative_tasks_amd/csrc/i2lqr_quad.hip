@@ -1,6 +1,8 @@
 // Instantiations and launcher of the sixteen-lanes-per-problem kernel (i2lqr_quad.hpp).
 #include "i2lqr_group.h"
 
+#include <cstdlib>
+
 #include "i2lqr_devcfg.hpp"
 #include "i2lqr_quad.hpp"
 
@@ -29,6 +31,13 @@ template <class T> hipError_t launch_quad(const i2lqr_config& cfg, const IterArg
     if (e != hipSuccess) return e;
   }
   const unsigned grid = (unsigned)((a.B + kQPW - 1) / kQPW);
+#ifdef I2LQR_STAMPS
+  IterArgs<T> a2 = a;  // diagnostic build: [B][8] u64 phase sums at the address in I2LQR_DBG_PTR
+  a2.dbg = nullptr;
+  if (const char* e = getenv("I2LQR_DBG_PTR")) a2.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+  hipLaunchKernelGGL((k_quad_iterate<T, Sys>), dim3(grid), dim3(64), lds, s, c, a2, (T*)ws);
+  return hipGetLastError();
+#endif
   hipLaunchKernelGGL((k_quad_iterate<T, Sys>), dim3(grid), dim3(64), lds, s, c, a, (T*)ws);
   return hipGetLastError();
 }

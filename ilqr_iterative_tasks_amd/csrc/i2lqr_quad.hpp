@@ -154,7 +154,13 @@ template <class T, class Sys> struct QuadWorker {
     });
   }
 
+  // Q_terminal: n^2 uniform words of the kernel argument (there is no LDS left to stage them in).
+  // (Hiding the pointer from the compiler so that the loads stay at their uses, and pacing the LDS
+  // reads of the H columns with scheduling barriers, both measured slower: 23.7 / 23.0 ms against
+  // 21.3 ms per 4-iteration launch at 65536 problems.)
+  __device__ __forceinline__ const T* qt_ptr() const { return c.Qt; }
   __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
+    const T* Qt = qt_ptr();
     T d[n];
 #pragma unroll
     for (int i = 0; i < n; i++) d[i] = x[i] - xT[i];
@@ -163,7 +169,7 @@ template <class T, class Sys> struct QuadWorker {
     for (int j = 0; j < n; j++) {
       T col = T(0);
 #pragma unroll
-      for (int i = 0; i < n; i++) col += d[i] * c.Qt[i * n + j];
+      for (int i = 0; i < n; i++) col += d[i] * Qt[i * n + j];
       acc += col * d[j];
     }
     return acc;
@@ -296,6 +302,7 @@ template <class T, class Sys> struct QuadWorker {
     T va[n];
     {
       const T* Rn = Wp + L.REC + N * QL::RW;
+      const T* Qt = qt_ptr();
       T dx[n];
 #pragma unroll
       for (int i = 0; i < n; i++) dx[i] = S[L.XU + N * W + i] - xT[i];
@@ -304,7 +311,7 @@ template <class T, class Sys> struct QuadWorker {
         T vxx = T(0), vx = T(0);
 #pragma unroll
         for (int r = 0; r < n; r++) {
-          const T q = T(2) * c.Qt[i * n + r];
+          const T q = T(2) * Qt[i * n + r];
           vxx = (g == r) ? q : vxx;
           vx += q * dx[r];
         }
@@ -360,13 +367,22 @@ template <class T, class Sys> struct QuadWorker {
       wave_sync();
       // P2: column g of H = L + T1[:, :n] F
       T h[W];
+      {
+        T colA[W], colB[W];
+        auto load_col = [&](int s_, T (&dst)[W]) __attribute__((always_inline)) {
+          const T* col = EX + srcw[s_];
 #pragma unroll
-      for (int a = 0; a < W; a++) h[a] = T(0);
+          for (int a = 0; a < W; a++) dst[a] = col[a];
+        };
+        load_col(0, colA);
+        static_for_i<0, NZ>([&](auto s_) {
+          constexpr int s2 = decltype(s_)::value;
+          T (&cur)[W] = (s2 & 1) ? colB : colA;
+          T (&nxt)[W] = (s2 & 1) ? colA : colB;
+          if constexpr (s2 + 1 < NZ) load_col(s2 + 1, nxt);
 #pragma unroll
-      for (int s = 0; s < NZ; s++) {
-        const T* col = EX + srcw[s];
-#pragma unroll
-        for (int a = 0; a < W; a++) h[a] = (s == 0) ? cf[0] * col[a] : t_fma(cf[s], col[a], h[a]);
+          for (int a = 0; a < W; a++) h[a] = (s2 == 0) ? cf[0] * cur[a] : t_fma(cf[s2], cur[a], h[a]);
+        });
       }
       h[0] += l0;
       h[1] += l1;
@@ -445,30 +461,36 @@ template <class T, class Sys> struct QuadWorker {
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = S[L.XU + i];
     T* XC = Wp + XCn;
-    T kk[m][NA];
+    // The feedback law u'_a = clip(u_a + k_a + K_a (x' - x)) of the m inputs runs on m lanes at
+    // once (lane q takes input q & (m - 1): one gain row, n multiply-adds) and the sin / cos of
+    // the three angles on three lanes; the results travel along the 16-lane row by DPP
+    // broadcasts.  Same arithmetic as the all-lanes-redundant form, a third of the instructions.
+    static_assert((m & (m - 1)) == 0, "m must be a power of two");
+    const int ga = g & (m - 1);
+    T umax_l = c.u_max[0];
+#pragma unroll
+    for (int a = 1; a < m; a++) umax_l = (ga == a) ? c.u_max[a] : umax_l;
+    auto bc = [](auto lane_, T v) { return row_bcast<decltype(lane_)::value>(v); };
+    T kr[NA];  // the lane's gain row [K_a | k_a]
     auto load_gains = [&](int t) __attribute__((always_inline)) {
-      const T* Gt = Wp + L.GK + t * (m * QL::GW);
+      const T* Gt = Wp + L.GK + t * (m * QL::GW) + ga * QL::GW;
 #pragma unroll
-      for (int a = 0; a < m; a++)
-#pragma unroll
-        for (int j = 0; j < NA; j++) kk[a][j] = Gt[a * QL::GW + j];
+      for (int j = 0; j < NA; j++) kr[j] = Gt[j];
     };
     load_gains(0);
     auto step = [&](const int t) __attribute__((always_inline)) {
-      T dx[n];
+      T acc = T(0);
 #pragma unroll
-      for (int j = 0; j < n; j++) dx[j] = x[j] - S[L.XU + t * W + j];
-#pragma unroll
-      for (int a = 0; a < m; a++) {
-        T acc = T(0);
-#pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], dx[j], acc);
-        u[a] = clip(S[L.XU + t * W + n + a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
-      }
+      for (int j = 0; j < n; j++) acc = t_fma(kr[j], x[j] - S[L.XU + t * W + j], acc);
+      const T ul = clip(S[L.XU + t * W + n + ga] + kr[n] + acc, -umax_l, umax_l);
       load_gains(t + 1 < N ? t + 1 : t);
+      static_for_i<0, m>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        u[a] = row_bcast<a>(ul);
+      });
 #pragma unroll
       for (int a = 0; a < m; a++) S[L.UC + t * m + a] = u[a];
-      Sys::template trig_g<GENERAL>(x, tr, bad);
+      Sys::template trig_row<GENERAL>(x, tr, bad, g, bc);
       if (g == 0) {
 #pragma unroll
         for (int i = 0; i < n; i++) XC[t * QL::XCW + i] = x[i];
@@ -485,7 +507,7 @@ template <class T, class Sys> struct QuadWorker {
       step(t + 1);
     }
     if (t < N) step(t);
-    Sys::template trig_g<GENERAL>(x, tr, bad);
+    Sys::template trig_row<GENERAL>(x, tr, bad, g, bc);
     if (g == 0) {
 #pragma unroll
       for (int i = 0; i < n; i++) XC[N * QL::XCW + i] = x[i];
@@ -503,10 +525,23 @@ template <class T, class Sys> struct QuadWorker {
   // an accepted step: the candidate becomes the nominal (states from the HBM record, inputs from UC)
   __device__ __forceinline__ void adopt(int XCn, bool acc) const {
     const T* XC = Wp + XCn;
-    for (int e = g; e < (N + 1) * n; e += kQG) {
-      const int t = e / n, i = e - t * n;
-      const T v = XC[t * QL::XCW + i];
-      if (acc) S[L.XU + t * W + i] = v;
+    constexpr int CH = 8;  // loads in flight per lane (a dependent load-store loop pays the HBM
+                           // / L2 latency once per element)
+    const int total = (N + 1) * n;
+    for (int base = 0; base < total; base += CH * kQG) {
+      T v[CH];
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        const int e = base + q * kQG + g, ec = e < total ? e : total - 1;
+        const int t = ec / n, i = ec - t * n;
+        v[q] = XC[t * QL::XCW + i];
+      }
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        const int e = base + q * kQG + g;
+        const int t = e / n, i = e - t * n;
+        if (acc && e < total) S[L.XU + t * W + i] = v[q];
+      }
     }
     for (int e = g; e < N * m; e += kQG) {
       const int t = e / m, a = e - t * m;
@@ -556,6 +591,9 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
   wave_sync();
 
+#ifdef I2LQR_STAMPS
+  STAMP_DECL;
+#endif
   int cur = 0;  // which HBM candidate buffer holds the sin / cos values of the nominal
   T cost = w.rollout(L.XC0, xT);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -567,12 +605,24 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   bool fresh = true, active = a.n_iters > 0;
   while (__any(active)) {
     const int XCo = cur ? L.XC1 : L.XC0, XCn = cur ? L.XC0 : L.XC1;
+#ifdef I2LQR_STAMPS
+    STAMP_BEGIN();
+#endif
     if (__any(fresh)) w.prep(XCo, ob, ob_pa, ob_pb);
+#ifdef I2LQR_STAMPS
+    STAMP_END(0);
+#endif
     if (__builtin_expect(__any(w.template backward<false>(xT, lamb)), 0))
       w.template backward<true>(xT, lamb);
+#ifdef I2LQR_STAMPS
+    STAMP_END(1);
+#endif
     bool big = false;
     T cost_new = w.template forward<false>(XCn, xT, &big);
     if (__builtin_expect(__any(big), 0)) cost_new = w.template forward<true>(XCn, xT, &big);
+#ifdef I2LQR_STAMPS
+    STAMP_END(2);
+#endif
     bool accepted = false;
     if (active) {
       it++;
@@ -602,8 +652,15 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
       fresh = false;
     }
     if (__any(accepted)) w.adopt(XCn, accepted);
+#ifdef I2LQR_STAMPS
+    STAMP_END(3);
+#endif
   }
   if (!t_isfinite(cost_ret)) status = 4;
+#ifdef I2LQR_STAMPS
+  if (a.dbg && g == 0 && real)
+    for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = st_acc[q];
+#endif
 
   if (real) {
     T* gX = a.X + prob * (int64_t)(n * (N + 1));

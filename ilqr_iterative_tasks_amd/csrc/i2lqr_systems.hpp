@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace i2lqr {
 
 // sin and cos of one argument.  fp64: Cody-Waite reduction by pi/2 in three FMA steps (exact for
@@ -595,14 +597,39 @@ template <class T> struct Quad12 {
       t_sincos_fast(xe[5], &tr[4], &tr[5], bad);
     }
   }
+  // The three angles on three lanes at once: `g` is the lane's index inside a 16-lane DPP row whose
+  // lanes all hold the same xe; lane q < 3 evaluates angle q, the results are broadcast along the
+  // row (BC<L>(v) = value of lane L of the row).  Same arithmetic as trig_g, a third of the
+  // instructions; *bad is per lane (the caller votes over the wavefront).
+  template <bool GENERAL, class BC>
+  static __device__ __forceinline__ void trig_row(const T (&xe)[n], T (&tr)[NTRIG], bool* bad, int g,
+                                                  BC&& bc) {
+    const T ang = g == 0 ? xe[3] : (g == 1 ? xe[4] : xe[5]);
+    T sv, cv;
+    if constexpr (GENERAL) t_sincos(ang, &sv, &cv);
+    else t_sincos_fast(ang, &sv, &cv, bad);
+    tr[0] = bc(std::integral_constant<int, 0>{}, sv);
+    tr[1] = bc(std::integral_constant<int, 0>{}, cv);
+    tr[2] = bc(std::integral_constant<int, 1>{}, sv);
+    tr[3] = bc(std::integral_constant<int, 1>{}, cv);
+    tr[4] = bc(std::integral_constant<int, 2>{}, sv);
+    tr[5] = bc(std::integral_constant<int, 2>{}, cv);
+  }
   template <class Cfg>
   static __device__ __forceinline__ void step_tr(const Cfg& c, const T (&x)[n], const T (&u)[m],
                                                  const T (&tr)[NTRIG], T (&xn)[n]) {
+    // Divisions by plant constants are multiplications by their (loop-invariant) reciprocals and
+    // the two divisions by cos(theta) share one reciprocal: an IEEE fp64 division is a dozen
+    // instructions on this hardware, six of them per step were a fifth of the rollout.  (A few ulp
+    // from the textbook form; every kernel and every rollout uses this one function.)
     const T mass = c.sys_par[0], g = c.sys_par[1], arm = c.sys_par[2];
     const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5], ct = c.sys_par[6];
+    const T inv_mass = T(1) / mass, arm_ix = arm / Ix, arm_iy = arm / Iy, ct_iz = ct / Iz;
     const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
-    const T tth = sth / cth;
+    const T icth = t_rcp(cth);
+    const T tth = sth * icth;
     const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
+    const T Tm = Tt * inv_mass;
     const T p = x[9], q = x[10], r = x[11], dt = c.dt;
     T f[n];
     f[0] = x[6];
@@ -610,13 +637,13 @@ template <class T> struct Quad12 {
     f[2] = x[8];
     f[3] = p + q * sph * tth + r * cph * tth;
     f[4] = q * cph - r * sph;
-    f[5] = (q * sph + r * cph) / cth;
-    f[6] = (Tt / mass) * (cph * sth * cps + sph * sps);
-    f[7] = (Tt / mass) * (cph * sth * sps - sph * cps);
-    f[8] = (Tt / mass) * (cph * cth) - g;
-    f[9] = ((Iy - Iz) / Ix) * q * r + arm * (u[1] - u[3]) / Ix;
-    f[10] = ((Iz - Ix) / Iy) * p * r + arm * (u[2] - u[0]) / Iy;
-    f[11] = ((Ix - Iy) / Iz) * p * q + ct * (u[0] - u[1] + u[2] - u[3]) / Iz;
+    f[5] = (q * sph + r * cph) * icth;
+    f[6] = Tm * (cph * sth * cps + sph * sps);
+    f[7] = Tm * (cph * sth * sps - sph * cps);
+    f[8] = Tm * (cph * cth) - g;
+    f[9] = ((Iy - Iz) / Ix) * q * r + arm_ix * (u[1] - u[3]);
+    f[10] = ((Iz - Ix) / Iy) * p * r + arm_iy * (u[2] - u[0]);
+    f[11] = ((Ix - Iy) / Iz) * p * q + ct_iz * (u[0] - u[1] + u[2] - u[3]);
 #pragma unroll
     for (int i = 0; i < n; i++) xn[i] = x[i] + dt * f[i];
   }
@@ -632,10 +659,12 @@ template <class T> struct Quad12 {
                                                  const T (&tr)[NTRIG], T (&v)[NVAR]) {
     const T mass = c.sys_par[0], g = c.sys_par[1];
     const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
+    const T inv_mass = T(1) / mass;
     const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
-    const T tth = sth / cth, sec2 = T(1) / (cth * cth);
+    const T icth = t_rcp(cth);  // one reciprocal for every division by cos(theta) (see step_tr)
+    const T tth = sth * icth, sec2 = icth * icth;
     const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
-    const T Tm = Tt / mass, dt = c.dt;
+    const T Tm = Tt * inv_mass, dt = c.dt;
     const T p = xe[9], q = xe[10], r = xe[11];
     // A = I + dt * dF/dx
     v[0] = T(1) + dt * ((q * cph - r * sph) * tth);       // [3][3]
@@ -645,10 +674,10 @@ template <class T> struct Quad12 {
     v[4] = dt * (-q * sph - r * cph);                     // [4][3]
     v[5] = dt * cph;                                      // [4][10]
     v[6] = dt * (-sph);                                   // [4][11]
-    v[7] = dt * ((q * cph - r * sph) / cth);              // [5][3]
+    v[7] = dt * ((q * cph - r * sph) * icth);             // [5][3]
     v[8] = dt * ((q * sph + r * cph) * sth * sec2);       // [5][4]
-    v[9] = dt * (sph / cth);                              // [5][10]
-    v[10] = dt * (cph / cth);                             // [5][11]
+    v[9] = dt * (sph * icth);                             // [5][10]
+    v[10] = dt * (cph * icth);                            // [5][11]
     v[11] = dt * (Tm * (-sph * sth * cps + cph * sps));   // [6][3]
     v[12] = dt * (Tm * (cph * cth * cps));                // [6][4]
     v[13] = dt * (Tm * (-cph * sth * sps + sph * cps));   // [6][5]
@@ -664,9 +693,9 @@ template <class T> struct Quad12 {
     v[23] = dt * (((Ix - Iy) / Iz) * q);                  // [11][9]
     v[24] = dt * (((Ix - Iy) / Iz) * p);                  // [11][10]
     // B rows 6..8: dt * a{x,y,z} for each of the 4 inputs
-    const T ax = dt * ((cph * sth * cps + sph * sps) / mass);
-    const T ay = dt * ((cph * sth * sps - sph * cps) / mass);
-    const T az = dt * ((cph * cth) / mass);
+    const T ax = dt * ((cph * sth * cps + sph * sps) * inv_mass);
+    const T ay = dt * ((cph * sth * sps - sph * cps) * inv_mass);
+    const T az = dt * ((cph * cth) * inv_mass);
 #pragma unroll
     for (int j = 0; j < m; j++) {
       v[25 + j] = ax;

@@ -26,12 +26,19 @@ for key in ("X", "U", "x_term", "lamb"):
     buf[key].copy_(torch.as_tensor(host[key]).to(solver.device, solver.dtype))
 buf["obs"] = torch.as_tensor(host["obs"]).to(solver.device, solver.dtype)
 dbg = torch.zeros(B, 8, dtype=torch.int64, device=solver.device)
-solver.lib.i2lqr_set_workspace(solver._handle, C.c_void_p(dbg.data_ptr()), dbg.numel() * 8)
+if lanes == 16:  # the sixteen-lane kernel keeps its real workspace: debug buffer through the env
+    import os
+    os.environ["I2LQR_DBG_PTR"] = str(dbg.data_ptr())
+    solver.ensure_workspace(B)
+else:
+    solver.lib.i2lqr_set_workspace(solver._handle, C.c_void_p(dbg.data_ptr()), dbg.numel() * 8)
+    solver.ensure_workspace = lambda B: None
 solver.iterate(buf, iters)
 torch.cuda.synchronize()
 d = dbg.double().mean(0).cpu().numpy() / iters
 names = (["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
-         if lanes == 64 else
+         if lanes == 64 else ["record phase", "backward", "forward", "accept + adopt", "-", "-", "-", "-"]
+         if lanes == 16 else
          ["prep", "bwd P1 + T1 exchange", "bwd P2 (H column)", "bwd Quu + inverse",
           "bwd gains + exchange", "bwd value update", "forward", "-"])
 tot = d.sum()
