@@ -53,7 +53,7 @@ struct i2lqr_handle {
   int64_t ws_bytes;
   int64_t compact_min_batch;  // i2lqr_solve uses the chunked, compacting form from this batch; 0: never; -1: automatic
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
-  int opt_defer, opt_reroll, opt_lds_steps, opt_merge;
+  int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
@@ -289,6 +289,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // the extra row writes cost 6 %, so the per-lane buffer swap stays (tools/ab_bench.py).
     a.merge = sizeof(T) == 8 ? 1 : 0;
     if (h->opt_merge >= 0) a.merge = h->opt_merge;
+    a.ckpt = 0;  // decided in finish_options() once the other options are final
     a.dbg = nullptr;
 #ifdef I2LQR_STAMPS
     if (const char* e = getenv("I2LQR_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -296,6 +297,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (h->opt_reroll >= 0) a.reroll = h->opt_reroll;
     if (h->opt_defer >= 0) a.defer = h->opt_defer;
     if (h->opt_lds_steps >= 0 && h->opt_lds_steps < a.lds_steps) a.lds_steps = h->opt_lds_steps;
+    finish_options(h, B, a);
     if (!cv) return;
     for (int q = 0; q < 2; q++) {
       LaneSet<T>& st = cv->set[q];
@@ -319,9 +321,30 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     cv->ustatus = ip; ip += B;
     cv->count = ip;
   }
+  // LDS of the state checkpointing: the states of one segment of kSeg steps for 64 lanes
+  static constexpr int kSegBytes = (kSeg + 1) * n * 64 * (int)sizeof(T);
+  // State checkpointing (i2lqr_lane.hpp): fp64 with deferred, merged states and the re-rolling
+  // forward pass, Q = R = 0; automatic from 262144 problems (where the kernel sits on the HBM
+  // roof).  Its segment buffer takes the place of LDS-resident gain steps.  Must be called again
+  // after any later change of defer / reroll / merge (the early-exit path does).
+  static void finish_options(const i2lqr_handle* h, int64_t B, LaneArgs<T>& a) {
+    bool hasqr = false;
+    for (int i = 0; i < I2LQR_MAX_N * I2LQR_MAX_N && !hasqr; i++) hasqr = h->cfg.Q[i] != 0.0;
+    for (int i = 0; i < I2LQR_MAX_M * I2LQR_MAX_M && !hasqr; i++) hasqr = h->cfg.R[i] != 0.0;
+    const bool can = sizeof(T) == 8 && !hasqr && a.defer && a.merge && a.reroll && h->cfg.N >= 2;
+    // (tools/ab_bench.py: -4 % at 65536 problems, -2 % at 131072, +5.7 % at 262144, +4-6 % at
+    // 2^20; HBM bytes per problem-iteration at 2^20: 7224 -> 6457)
+    a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= 262144);
+    if (a.ckpt) {
+      const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
+      int steps = (36 * 1024 - kSegBytes) / per_step;
+      if (steps < 0) steps = 0;
+      if (a.lds_steps > steps) a.lds_steps = steps;
+    }
+  }
   template <bool TL>
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
-    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T);
+    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + (a.ckpt ? kSegBytes : 0);
     if (c.flags)
       hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
     else
@@ -446,6 +469,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (early_exit) {  // solve() is bound by its slowest problem's latency, not by HBM traffic
       if (h->opt_reroll < 0) a.reroll = 0;
       if (h->opt_defer < 0) a.defer = 0;
+      finish_options(h, B, a);
     }
     launch_iterate<TILED>(c, a, B, s);
     HIP_TRY(hipGetLastError());
@@ -809,7 +833,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
-  h->opt_merge = -1;
+  h->opt_merge = h->opt_ckpt = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -875,6 +899,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "reroll_nominal")) h->opt_reroll = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
   else if (!strcmp(name, "merge_inputs")) h->opt_merge = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "checkpoint_states")) h->opt_ckpt = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "group_lanes")) {

@@ -49,7 +49,16 @@ template <class T> struct LaneArgs {
   int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
   int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
   int merge;      // deferred mode: accepted candidate inputs are merged into ONE input buffer
+  int ckpt;       // only every kSeg-th state lives in HBM between the passes (see backward<.., CK>)
 };
+
+// State checkpointing (fp64, large batches: the kernel sits on the HBM roof).  Between the passes of
+// an iteration only the states x_0, x_4, x_8, ... are kept in HBM; the backward pass re-rolls the
+// states of one segment of kSeg horizon steps at a time from the segment's checkpoint into LDS
+// (bit-identical to what a full rollout stores: same code, same inputs) and reads them from
+// there.  X traffic per iteration drops from n (N+1) read + n N written to a quarter of that, for
+// one more plant step per horizon step; the caller's X is completed by one full re-roll at exit.
+constexpr int kSeg = 4;
 
 // words of T the workspace needs for B problems
 template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int N, int64_t B) {
@@ -184,7 +193,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   }
 
   // -- nominal rollout + cost (control/iterative_ilqr.py:32-48) --------------------------------
-  __device__ __forceinline__ T rollout(T* X, T* U, const T (&xT)[n]) const {
+  // ckx: only the checkpoint states (t % kSeg == 0) are stored (state checkpointing, below)
+  __device__ __forceinline__ T rollout(T* X, T* U, const T (&xT)[n], bool ckx = false) const {
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = at(X, rx(i, 0));
@@ -197,8 +207,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
+      if (!ckx || ((t + 1) & (kSeg - 1)) == 0) {
 #pragma unroll
-      for (int i = 0; i < n; i++) at(X, rx(i, t + 1)) = xn[i];
+        for (int i = 0; i < n; i++) at(X, rx(i, t + 1)) = xn[i];
+      }
       cost = cost + stage_cost(x, c.xtarget, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
@@ -293,7 +305,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
   }
 
-  template <bool MERGE = false>
+  // CKX: only the checkpoint states (t % kSeg == 0) are stored
+  template <bool MERGE = false, bool CKX = false>
   __device__ __forceinline__ void restore_states_paired(T* X, T* U, const T* Un = nullptr,
                                                         bool acc = false) const {
     T x[n], xn[n], tr[NT];
@@ -321,9 +334,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
       Sys::trig(x, tr);
       Sys::step_tr(c, x, u, tr, xn);
+      const bool keep = !CKX || ((t + 1) % kSeg == 0);
 #pragma unroll
       for (int i = 0; i < n; i++) {
-        at(X, rx(i, t + 1)) = xn[i];
+        if (keep) at(X, rx(i, t + 1)) = xn[i];
         x[i] = xn[i];
       }
     };
@@ -345,9 +359,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     else restore_states_paired(X, U);
   }
   // deferred mode: merge the accepted candidates into U (one buffer, full rows) and re-roll
+  template <bool CKX = false>
   __device__ __forceinline__ void merge_and_restore(T* X, T* U, const T* Un, bool acc) const {
     if constexpr (DEEP) restore_states_blocked<true>(X, U, Un, acc);
-    else restore_states_paired<true>(X, U, Un, acc);
+    else restore_states_paired<true, CKX>(X, U, Un, acc);
   }
 
   // obstacle barrier terms at (px, py), horizon index t: control/ilqr_helper.py:32-51, :121-147
@@ -390,16 +405,51 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   static constexpr bool SYM = true;
   static constexpr bool DEEP = sizeof(T) == 4 && I2LQR_DEEP_PREFETCH;
 
-  template <bool FASTBAR = false>
+  // CK: checkpointed states (kSeg above); seg = (kSeg + 1) n 64 words of LDS for this wavefront.
+  template <bool FASTBAR = false, bool CK = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
-                                           const T (&ob)[6], T lamb, T* gK, T* gk) const {
+                                           const T (&ob)[6], T lamb, T* gK, T* gk,
+                                           T* seg = nullptr) const {
+    static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+    const unsigned l64 = threadIdx.x & 63;
+    // state k of the current segment (k = 0: the checkpoint), component i: conflict-free LDS words
+    auto seg_at = [&](int k, int i) -> T& { return seg[(k * n + i) * 64 + l64]; };
+    T useg[kSeg][m];  // inputs of the current segment
+    // re-roll segment sg (steps sg kSeg .. sg kSeg + len - 1) from its checkpoint into LDS
+    auto roll_segment = [&](const int sg, const int len) __attribute__((always_inline)) {
+      T x[n], xn[n], tr[NT];
+      const int t0 = sg * kSeg;
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = at(X, rx(i, t0));
+#pragma unroll
+      for (int k = 0; k < kSeg; k++)
+        if (k < len) {
+#pragma unroll
+          for (int a = 0; a < m; a++) useg[k][a] = at(U, ru(a, t0 + k));
+        }
+#pragma unroll
+      for (int i = 0; i < n; i++) seg_at(0, i) = x[i];
+#pragma unroll
+      for (int k = 0; k < kSeg; k++)
+        if (k < len) {
+          Sys::trig(x, tr);
+          Sys::step_tr(c, x, useg[k], tr, xn);
+#pragma unroll
+          for (int i = 0; i < n; i++) {
+            seg_at(k + 1, i) = xn[i];
+            x[i] = xn[i];
+          }
+        }
+    };
+    const int last_sg = (N - 1) / kSeg, last_len = N - last_sg * kSeg;
+    if constexpr (CK) roll_segment(last_sg, last_len);
     T Va[n][n + 1];  // [Vxx | Vx]; with SYM only Va[i][j >= i] and the last column are live
     {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
 #pragma unroll
-      for (int i = 0; i < n; i++) xN[i] = at(X, rx(i, N));
+      for (int i = 0; i < n; i++) xN[i] = CK ? seg_at(last_len, i) : at(X, rx(i, N));
       obstacle(ob, ob_pa, ob_pb, xN[0], xN[1], N, o);
 #pragma unroll
       for (int i = 0; i < n; i++) {
@@ -424,12 +474,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     // alone on its SIMD cannot hide the rest); fp64 sits on the HBM roof either way.
     constexpr int D = DEEP ? 2 : 1;  // prefetch distance in horizon steps
     T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t
+    if constexpr (!CK) {
 #pragma unroll
-    for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
+      for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
 #pragma unroll
-    for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
+      for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
 #pragma unroll
-    for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
+      for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
+    }
     auto body = [&](const int t, T (&xp)[n], T (&u)[m]) __attribute__((always_inline)) {
       T jv[NV], o[5], tr[NT];
       STAMP_BEGIN();
@@ -473,13 +525,15 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
         lxq[a] = l;
       }
+      if constexpr (!CK) {
 #pragma unroll
-      for (int i = 0; i < n; i++) xe[i] = xp[i];
-      if (t >= D) {
+        for (int i = 0; i < n; i++) xe[i] = xp[i];
+        if (t >= D) {
 #pragma unroll
-        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - D));
+          for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - D));
 #pragma unroll
-        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - D));
+          for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - D));
+        }
       }
 
       STAMP_END(0);
@@ -603,6 +657,24 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         body(t - 1, xq, uq);
       }
       if (t == 0) body(0, xp, u);
+    } else if constexpr (CK) {
+      for (int sg = last_sg; sg >= 0; sg--) {
+        const int len = sg == last_sg ? last_len : kSeg;
+        if (sg != last_sg) roll_segment(sg, len);
+        static_for<0, kSeg>([&](auto kk_) {
+          constexpr int k = kSeg - 1 - decltype(kk_)::value;  // steps of the segment, last first
+          if (k < len) {
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+              xe[i] = seg_at(k + 1, i);
+              xp[i] = seg_at(k, i);
+            }
+#pragma unroll
+            for (int a = 0; a < m; a++) u[a] = useg[k][a];
+            body(sg * kSeg + k, xp, u);
+          }
+        });
+      }
     } else {
       for (int t = N - 1; t >= 0; t--) body(t, xp, u);
     }
@@ -770,12 +842,21 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
-  T cost = w.rollout(X, Uc, xT);
+  // checkpointed states (fp64 only; host: deferred + merged + re-rolling forward pass, Q = R = 0)
+  constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR;
+  const bool ckpt = kCanCkpt && a.ckpt;
+  T cost = w.rollout(X, Uc, xT, ckpt);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
+  T* const seg = reinterpret_cast<T*>(lane_smem) + (size_t)a.lds_steps * 64 * m * (n + 1);
   while (it < a.n_iters && it0 + it < a.max_total) {
-    w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
+    if constexpr (kCanCkpt) {
+      if (ckpt) w.template backward<true, true>(X, Uc, xT, ob, lamb, gK, gk, seg);
+      else w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
+    } else {
+      w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
+    }
 #ifdef I2LQR_STAMPS
     {
       auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
@@ -805,7 +886,24 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     if (a.defer && a.merge) {
       // the current inputs stay in ONE buffer for the whole wavefront: accepted candidates are
       // merged into it during the re-roll (Uc == U0, Un == workspace throughout)
-      if (__any(accepted)) w.merge_and_restore(X, Uc, Un, accepted);
+      if (__all(accepted)) {
+        // every lane of the wavefront accepted: the two input buffers change roles for the whole
+        // wavefront (still ONE buffer with full rows, no copy) and the states are re-rolled
+        T* tp = Uc; Uc = Un; Un = tp;
+        if constexpr (kCanCkpt) {
+          if (ckpt) w.template restore_states_paired<false, true>(X, Uc);
+          else w.restore_states(X, Uc);
+        } else {
+          w.restore_states(X, Uc);
+        }
+      } else if (__any(accepted)) {
+        if constexpr (kCanCkpt) {
+          if (ckpt) w.template merge_and_restore<true>(X, Uc, Un, accepted);
+          else w.merge_and_restore(X, Uc, Un, accepted);
+        } else {
+          w.merge_and_restore(X, Uc, Un, accepted);
+        }
+      }
     } else {
       if (accepted) {
         T* tp = Uc; Uc = Un; Un = tp;
@@ -844,6 +942,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   if (a.dbg && threadIdx.x == 0)
     for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
 #endif
+  if constexpr (kCanCkpt) {
+    if (ckpt) w.restore_states(X, Uc);  // the caller's X in full: one re-roll per launch
+  }
   w.flush_gains(gK, gk);
   if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
     for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];

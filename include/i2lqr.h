@@ -171,6 +171,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     64-lane rows of ONE buffer.  0: per-lane buffer swap (no copy, but after
  *                     mixed decisions every input row access touches two buffers).  Automatic: 1 in
  *                     fp64 (bandwidth-bound), 0 in fp32 (instruction-bound).
+ *   "checkpoint_states"  (fp64, "defer_states" 1, "merge_inputs" 1, "reroll_nominal" 1, Q = R = 0)
+ *                     1: between the passes of an iteration only every fourth state is kept in
+ *                     HBM; the backward pass re-rolls the states of four horizon steps at a time
+ *                     from their checkpoint into LDS (bit-identical values).  A quarter of the
+ *                     state traffic for one more plant step per horizon step; the segment buffer
+ *                     replaces two LDS-resident gain steps.  Automatic: 1 from 262144 problems.
  *   "reroll_nominal"  1: the forward pass re-rolls the nominal states it needs for the feedback
  *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
  *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the

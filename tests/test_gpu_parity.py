@@ -540,22 +540,24 @@ def test_lane_scheduling_options_do_not_change_results(torch_mod, lay, dtype):
     solver, cfg = make_solver("bicycle6", 20, dtype, dt=0.25, layout=lay)
     host = workloads.make_batch(cfg, 2048)
 
-    def run(defer, reroll, lds, merge=-1):
+    def run(defer, reroll, lds, merge=-1, ckpt=-1):
         solver.set_option("defer_states", defer)
         solver.set_option("reroll_nominal", reroll)
         solver.set_option("lds_gain_steps", lds)
         solver.set_option("merge_inputs", merge)
+        solver.set_option("checkpoint_states", ckpt)
         it = solver.iterate(dev_batch(solver, host), 7)
         so = solver.solve(dev_batch(solver, host))
         return it, so
 
     ref_it, ref_so = run(0, 0, 0)
-    for defer, reroll, lds, merge in ((1, 1, -1, 1), (1, 0, 3, 0), (0, 1, -1, -1), (-1, -1, -1, -1),
-                                      (1, 1, 2, 0)):
-        it, so = run(defer, reroll, lds, merge)
+    for defer, reroll, lds, merge, ckpt in ((1, 1, -1, 1, 0), (1, 0, 3, 0, -1), (0, 1, -1, -1, -1),
+                                            (-1, -1, -1, -1, -1), (1, 1, 2, 0, 1), (1, 1, -1, 1, 1),
+                                            (1, 1, 1, 1, 1)):
+        it, so = run(defer, reroll, lds, merge, ckpt)
         for got, want in ((it, ref_it), (so, ref_so)):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
-                assert torch.equal(got[key], want[key]), (key, defer, reroll, lds, merge)
+                assert torch.equal(got[key], want[key]), (key, defer, reroll, lds, merge, ckpt)
     with pytest.raises(I2lqrError):
         solver.set_option("no_such_option", 1)
 
