@@ -57,6 +57,7 @@ struct i2lqr_handle {
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
+  int opt_spec;   // eight-lane kernel: speculative form (three wavefronts per eight problems); -1 = automatic
 };
 
 namespace {
@@ -136,6 +137,22 @@ template <class T, class Sys> struct Launch {
       if (h->opt_group == 8 && !can)
         return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 "
                     "and a horizon whose eight problem slices fit the 160 KiB of LDS");
+      // Speculative form (k_group_spec; opt-in): three wavefronts per eight problems run the
+      // iterations that follow 0, 1, 2 rejects at once; bit-identical results.  Measured SLOWER
+      // than the plain kernels on the benchmark workload (0.275 vs 0.215 ms per 10 iterations at
+      // 1024 problems): the eight problems of a wavefront advance in lockstep rounds, so a round
+      // saves time only if ALL eight have a reject to skip, and three wavefronts per CU contend
+      // for LDS.  Kept as an option for workloads dominated by long reject chains.
+      const bool can_spec = can && group_spec_supported(h->cfg);
+      if (h->opt_spec == 1 && !can_spec)
+        return fail(I2LQR_ERR_UNSUPPORTED, "\"speculate\" = 1 needs the eight-lane kernel and a "
+                    "horizon whose speculative buffers fit the 160 KiB of LDS");
+      const bool spec = can_spec && h->opt_group != 64 &&
+                        h->opt_spec == 1;
+      if (spec) {
+        HIP_TRY(group_spec_iterate<T>(h->cfg, a, s));
+        return I2LQR_OK;
+      }
       if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
         HIP_TRY(group_iterate<T>(h->cfg, a, s));
         return I2LQR_OK;
@@ -833,7 +850,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
-  h->opt_merge = h->opt_ckpt = -1;
+  h->opt_merge = h->opt_ckpt = h->opt_spec = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -902,6 +919,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "checkpoint_states")) h->opt_ckpt = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
+  else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_lanes")) {
     if (v != -1 && v != 8 && v != 16 && v != 64)
       return fail(I2LQR_ERR_INVALID, "\"group_lanes\" is 8, 16, 64 or -1");
@@ -916,6 +934,8 @@ const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) {
   if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return "k_lane_iterate";
   const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
   const bool can = m2 && group_supported(h->cfg);
+  if (can && group_spec_supported(h->cfg) && h->opt_group != 64 && h->opt_spec == 1)
+    return "k_group_spec";
   if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
   if ((h->opt_group == 16 || h->opt_group < 0) && quad_supported(h->cfg) && h->ws &&
       h->ws_bytes >= quad_workspace_bytes(h->cfg, B))

@@ -15,6 +15,12 @@ bool group_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                             hipStream_t stream);
 
+// The speculative form of the eight-lane kernel (k_group_spec: three wavefronts per eight problems,
+// wavefront v runs the iteration that follows v rejects): small batches only.
+bool group_spec_supported(const i2lqr_config& cfg);
+template <class T> hipError_t group_spec_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
+                                                 hipStream_t stream);
+
 // Sixteen lanes per problem (i2lqr_quad.hpp; the n + m = 16 plant quad12, Q = R = 0): needs a
 // caller-provided HBM workspace of quad_workspace_bytes() for B problems.
 bool quad_supported(const i2lqr_config& cfg);

@@ -40,7 +40,52 @@ hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) 
   return hipGetLastError();
 }
 
+constexpr int kSpecV = 3;  // wavefronts per group of eight problems in the speculative kernel
+
+template <class T, class Sys> size_t spec_lds_bytes(int N) {
+  return (size_t)GSpecLayout<Sys, kSpecV>(N).group_words() * sizeof(T);
+}
+
+template <class T, class Sys>
+hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
+  const size_t lds = spec_lds_bytes<T, Sys>(cfg.N);
+  if (lds > 64 * 1024) {
+    static thread_local int raised_for = 0;
+    if (raised_for < (int)lds) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, kSpecV>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      raised_for = (int)lds;
+    }
+  }
+  const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
+  hipLaunchKernelGGL((k_group_spec<T, Sys, kSpecV>), dim3(grid), dim3(64 * kSpecV), lds, s, c, a);
+  return hipGetLastError();
+}
+
 }  // namespace
+
+bool group_spec_supported(const i2lqr_config& cfg) {
+  if (!group_supported(cfg)) return false;
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>>(cfg.N)
+                                             : spec_lds_bytes<double, Bicycle6<double>>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>>(cfg.N)
+                                             : spec_lds_bytes<float, Bicycle6<float>>(cfg.N));
+  return lds <= 160 * 1024;
+}
+
+template <> hipError_t group_spec_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                                  hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec<double, Bicycle4<double>>(cfg, a, s);
+  return launch_spec<double, Bicycle6<double>>(cfg, a, s);
+}
+template <> hipError_t group_spec_iterate<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                                 hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec<float, Bicycle4<float>>(cfg, a, s);
+  return launch_spec<float, Bicycle6<float>>(cfg, a, s);
+}
 
 bool group_supported(const i2lqr_config& cfg) {
   if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;

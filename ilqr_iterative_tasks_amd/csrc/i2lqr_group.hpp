@@ -128,6 +128,8 @@ template <class T, class Sys> struct GroupWorker {
   const T* const Qt; // the wavefront's copy of Q_terminal
   const int g;       // lane inside the group = column index
   const int N;
+  int oR, oKk, oT1c;  // where the records, the gains and the exchange buffer sit in the slice
+                      // (the layout's by default; the speculative kernel gives each wavefront its own)
 
   // per-lane column description (constant over the kernel)
   int off_c0, off_c1;        // record offsets of F[0][g], F[1][g]
@@ -140,8 +142,13 @@ template <class T, class Sys> struct GroupWorker {
 #endif
 
   __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
-      : c(c_), L(c_.N), S(smem + (lane / kGroup) * GLayout<Sys>(c_.N).total),
-        Qt(smem + kGroupsPerWave * GLayout<Sys>(c_.N).total), g(lane % kGroup), N(c_.N) {
+      : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N).total,
+                    smem + kGroupsPerWave * GLayout<Sys>(c_.N).total, lane % kGroup) {}
+
+  // slice: this problem's LDS slice; qt: Q_terminal in LDS
+  __device__ GroupWorker(const Cfg& c_, T* slice, const T* qt, int g_)
+      : c(c_), L(c_.N), S(slice), Qt(qt), g(g_), N(c_.N) {
+    oR = L.R; oKk = L.Kk; oT1c = L.T1c;
     off_c0 = GL::R_ZERO; off_c1 = GL::R_ZERO; off_l0 = GL::R_ZERO; off_l1 = GL::R_ZERO;
 #pragma unroll
     for (int a = 0; a < m; a++) off_lu[a] = GL::R_ZERO;
@@ -241,16 +248,19 @@ template <class T, class Sys> struct GroupWorker {
   // flow: a lane past the end of the horizon recomputes the last record (and stores the same
   // values again), a problem without obstacle computes the barrier of a dummy ellipse and
   // stores zeros.
-  __device__ __forceinline__ void prep(int XUo, int TRo, const T (&ob)[6], T pa, T pb) const {
+  // first / stride: which records this lane takes (g, 8 in the plain kernel; the speculative
+  // kernel spreads them over the lanes of all its wavefronts)
+  __device__ __forceinline__ void prep(int XUo, int TRo, const T (&ob)[6], T pa, T pb, int first,
+                                       int stride) const {
     const bool has_ob = ob[5] >= T(0);
     const int opt = has_ob ? (int)ob[5] : 0;
     const T spd_y = opt == 1 ? ob[4] : T(0), spd_x = opt == 2 ? ob[4] : T(0);
-    const int rounds = (N + kGroup) / kGroup;  // ceil((N + 1) / 8)
+    const int rounds = (N + stride) / stride;  // ceil((N + 1) / stride)
     for (int r = 0; r < rounds; r++) {
-      const int t0 = g + r * kGroup;
+      const int t0 = first + r * stride;
       const int t = t0 < N ? t0 : N;          // record index (obstacle term of x_t)
       const int ts = t0 < N ? t0 : N - 1;     // step index (Jacobian entries, input barrier)
-      T* Rs = S + L.R + ts * GL::RW;
+      T* Rs = S + oR + ts * GL::RW;
       {
         T xe[n], tr[NT], u[m], jv[NV];
 #pragma unroll
@@ -277,7 +287,7 @@ template <class T, class Sys> struct GroupWorker {
                               c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
         }
       }
-      T* R = S + L.R + t * GL::RW;
+      T* R = S + oR + t * GL::RW;
       R[GL::R_ZERO] = T(0);
       R[GL::R_ONE] = T(1);
       // obstacle barrier: control/ilqr_helper.py:32-51 (stage) / :121-147 (terminal, index N);
@@ -310,14 +320,16 @@ template <class T, class Sys> struct GroupWorker {
   //    branch; returns true if some Quu was not positive definite — the caller then repeats the
   //    pass with GENERAL = true (eigenvalue clamping of control/iterative_ilqr.py:118-123 behind a
   //    branch).  Where Quu is positive definite both compute the same numbers.
+  //    commit = false (a problem that has already terminated while others of its wavefront still
+  //    run): the gains in LDS are left as the problem's last iteration wrote them.
   template <bool GENERAL>
-  __device__ __forceinline__ bool backward(int XUo, const T (&xT)[n], T lamb) const {
+  __device__ __forceinline__ bool backward(int XUo, const T (&xT)[n], T lamb, bool commit) const {
     bool bad = false;
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150.
     // va[i] = column g of [Vxx | Vx]
     T va[n];
     {
-      const T* Rn = S + L.R + N * GL::RW;
+      const T* Rn = S + oR + N * GL::RW;
       T dx[n];
 #pragma unroll
       for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
@@ -336,13 +348,13 @@ template <class T, class Sys> struct GroupWorker {
       va[0] += Rn[off_l0];
       va[1] += Rn[off_l1];
     }
-    T* const T1c = S + L.T1c;
+    T* const T1c = S + oT1c;
     const int gcol = g < GL::KW ? g : GL::KW - 1;  // lanes past the gain row write its padding word
     // The record of a step (uniform and per-lane words) is loaded one step ahead, behind the gain
     // exchange of the previous step: its LDS latency hides under that step's value update.
     T jv[NV], luu[m], c0, c1, l0, l1, lrow[m];
     auto load_record = [&](int t) __attribute__((always_inline)) {
-      const T* R = S + L.R + t * GL::RW;
+      const T* R = S + oR + t * GL::RW;
 #pragma unroll
       for (int q = 0; q < NV; q++) jv[q] = R[GL::R_JV + q];
 #pragma unroll
@@ -424,9 +436,10 @@ template <class T, class Sys> struct GroupWorker {
         for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], h[n + b], acc);
         kc[a] = -acc;
       }
-      T* Kt = S + L.Kk + t * (m * GL::KW);
+      T* Kt = S + oKk + t * (m * GL::KW);
 #pragma unroll
-      for (int a = 0; a < m; a++) Kt[a * GL::KW + gcol] = kc[a];
+      for (int a = 0; a < m; a++)
+        if (commit) Kt[a * GL::KW + gcol] = kc[a];
       wave_sync();
       STAMP_END(4);
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
@@ -483,7 +496,7 @@ template <class T, class Sys> struct GroupWorker {
       for (int a = 0; a < m; a++) {
         uo[a] = S[XUo + t * W + n + a];
 #pragma unroll
-        for (int j = 0; j < NA; j++) kk[a][j] = S[L.Kk + (t * m + a) * GL::KW + j];
+        for (int j = 0; j < NA; j++) kk[a][j] = S[oKk + (t * m + a) * GL::KW + j];
       }
     };
     load_step(0);
@@ -576,15 +589,15 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
     {
       auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
       STAMP_BEGIN();
-      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb);
+      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
       STAMP_END(0);
     }
 #else
-    if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb);
+    if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
 #endif
     // optimistic, branch-free passes first; the general forms only if a lane asked for them
-    if (__builtin_expect(__any(w.template backward<false>(XUo, xT, lamb)), 0))
-      w.template backward<true>(XUo, xT, lamb);
+    if (__builtin_expect(__any(w.template backward<false>(XUo, xT, lamb, active)), 0))
+      w.template backward<true>(XUo, xT, lamb, active);
     T cost_new;
     {
 #ifdef I2LQR_STAMPS
@@ -656,6 +669,199 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
     if (a.dbg && g == 0)
       for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = w.st_acc[q];
 #endif
+    if (g == 0) {
+      a.lamb[prob] = lamb;
+      a.cost[prob] = cost_ret;
+      if (a.iters) a.iters[prob] = it;
+      if (a.status) a.status[prob] = status;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Speculative form for small batches (<= 2048 problems: at most one workgroup per CU).
+//
+// An iLQR iteration ends in accept (new nominal, lamb / 10) or reject (same nominal, lamb * 10):
+// control/iterative_ilqr.py:74-84.  After a reject the next iteration runs the backward and forward
+// pass on the SAME nominal trajectory with lamb * 10 — work that does not depend on the outcome of
+// the current iteration except through "was it a reject".  With the eight-lane kernel a batch of
+// 1024 problems occupies an eighth of the chip's SIMDs; the speculative kernel puts V wavefronts
+// on each group of eight problems, wavefront v running the iteration that follows v rejects
+// (lamb * 10^v).  After every round the chain of outcomes is resolved in order: the iterations up
+// to and including the first accept (or all V if none accepts) count, the rest is discarded.  The
+// iterations a problem executes, their order and their arithmetic are exactly those of the
+// sequential kernel — results are bit-identical — but a run of r rejects followed by one accept costs one
+// round instead of r + 1.  Rejects are frequent (the lamb schedule probes until a step is
+// accepted, and converged problems reject until lamb overflows): ~1.8 iterations per round at
+// V = 3 on the benchmark workload.
+//
+// LDS per problem: V + 1 trajectory buffers (nominal + one candidate per wavefront; a per-problem
+// table says which is which, an accepted candidate becomes the nominal by swapping two table
+// entries), the records (shared, written by all wavefronts' lanes together), and per wavefront
+// its gains and exchange buffer.  Workgroup barriers: after the record phase and after the
+// forward pass.
+// ---------------------------------------------------------------------------------------------
+template <class Sys, int V> struct GSpecLayout {
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
+  using GL = GLayout<Sys>;
+  int N;
+  int traj_words, R, var0, var_words, Kk_in_var, T1c_in_var, total;
+  __host__ __device__ explicit GSpecLayout(int N_) : N(N_) {
+    const int xu = (W * (N + 1) + 3) & ~3, tr = (NT * (N + 1) + 3) & ~3;
+    traj_words = xu + tr;  // buffer b: XU at b * traj_words, TR right behind it (+ xu)
+    int o = (V + 1) * traj_words;
+    R = o; o += GL::RW * (N + 1); o = (o + 3) & ~3;
+    var0 = o;
+    Kk_in_var = 0;
+    T1c_in_var = (m * GL::KW * N + 3) & ~3;
+    var_words = (T1c_in_var + kGroup * W + 3) & ~3;
+    o += V * var_words;
+    if (((o / 4) & 1) == 0) o += 4;
+    total = o;
+  }
+  __host__ __device__ int xu_off(int b) const { return b * traj_words; }
+  __host__ __device__ int tr_off(int b) const { return b * traj_words + ((W * (N + 1) + 3) & ~3); }
+  // + Q_terminal + the V x 8 candidate costs of a round + the rollout cost
+  __host__ __device__ int group_words() const { return kGroupsPerWave * total + n * n + (V + 1) * kGroupsPerWave; }
+};
+
+template <class T, class Sys, int V>
+__global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, Sys::m> c,
+                                                       const IterArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m, W = n + m;
+  using GL = GLayout<Sys>;
+  using SL = GSpecLayout<Sys, V>;
+  extern __shared__ __align__(16) unsigned char gsmem_raw[];
+  T* smem = reinterpret_cast<T*>(gsmem_raw);
+  const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = lane / kGroup, g = lane % kGroup;
+  const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + p;
+  const bool real = prob0 < a.B;
+  const int64_t prob = real ? prob0 : a.B - 1;
+  const SL SLay(c.N);
+  const int N = c.N;
+  T* const S = smem + p * SLay.total;
+  T* const QtL = smem + kGroupsPerWave * SLay.total;
+  T* const CN = QtL + n * n;  // [V + 1][8]: candidate cost of wavefront v / rollout cost at row V
+  GroupWorker<T, Sys> w(c, S, QtL, g);
+  w.oR = SLay.R;
+  w.oKk = SLay.var0 + v * SLay.var_words + SLay.Kk_in_var;
+  w.oT1c = SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;
+
+  // entry (wavefront 0): x0, U into buffer 0, Q_terminal; nominal rollout
+  if (v == 0) {
+    const T* gX = a.X + prob * (int64_t)(n * (N + 1));
+    if (g < n) S[SLay.xu_off(0) + g] = gX[g * (N + 1)];
+    const T* gU = a.U + prob * (int64_t)(m * N);
+    for (int e = g; e < m * N; e += kGroup) {
+      const int aa = e / N, t = e - aa * N;
+      S[SLay.xu_off(0) + t * W + n + aa] = gU[e];
+    }
+    for (int e = lane; e < n * n; e += 64) QtL[e] = c.Qt[e];
+  }
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[prob];
+  const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+  __syncthreads();
+  if (v == 0) {
+    const T c0 = w.rollout(SLay.xu_off(0), SLay.tr_off(0), xT);
+    if (g == 0) CN[V * kGroupsPerWave + p] = c0;
+  }
+  __syncthreads();
+  T cost = CN[V * kGroupsPerWave + p];
+
+  // which buffer is the nominal, which is wavefront k's candidate (identical in every wavefront)
+  int nb = 0, cb[V];
+#pragma unroll
+  for (int k = 0; k < V; k++) cb[k] = k + 1;
+  int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/, gsel = 0;
+  T cost_ret = cost;
+  bool fresh = true, active = a.n_iters > 0;
+  while (__any(active)) {
+    if (__any(fresh)) {
+      w.prep(SLay.xu_off(nb), SLay.tr_off(nb), ob, ob_pa, ob_pb, v * kGroup + g, V * kGroup);
+      __syncthreads();
+    }
+    // this wavefront's iteration: the one that follows v rejects
+    T lamb_v = lamb;
+    for (int k = 0; k < v; k++) lamb_v *= c.lamb_factor;
+    int mycb = cb[0];
+#pragma unroll
+    for (int k = 1; k < V; k++) mycb = (v == k) ? cb[k] : mycb;
+    const int XUo = SLay.xu_off(nb), XUn = SLay.xu_off(mycb), TRn = SLay.tr_off(mycb);
+    if (__builtin_expect(__any(w.template backward<false>(XUo, xT, lamb_v, active)), 0))
+      w.template backward<true>(XUo, xT, lamb_v, active);
+    bool big = false;
+    T cost_new = w.template forward<false>(XUo, XUn, TRn, xT, &big);
+    if (__builtin_expect(__any(big), 0)) cost_new = w.template forward<true>(XUo, XUn, TRn, xT, &big);
+    if (g == 0) CN[v * kGroupsPerWave + p] = cost_new;
+    __syncthreads();
+    // resolve the chain: control/iterative_ilqr.py:74-84 for iteration it, it + 1, ...
+    fresh = false;
+    bool chain = active;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      if (chain) {
+        const T cn = CN[k * kGroupsPerWave + p];
+        it++;
+        gsel = k;
+        if (cn < cost) {
+          const int tb = nb; nb = cb[k]; cb[k] = tb;  // the candidate becomes the nominal
+          lamb /= c.lamb_factor;
+          const bool conv = t_abs((cn - cost) / cost) < c.eps;
+          cost_ret = cn;
+          cost = cn;
+          fresh = true;
+          chain = false;  // the later wavefronts worked on the old nominal
+          if (conv) {
+            if (a.early_exit) { status = 1; active = false; }
+            if (status == 0) status = 1;
+          }
+        } else {
+          lamb *= c.lamb_factor;
+          cost_ret = cost;
+          if (lamb > c.max_lamb) {
+            if (a.early_exit) { status = 3; active = false; chain = false; }
+            if (status == 0) status = 3;
+          }
+        }
+        if (it >= a.n_iters) { active = false; chain = false; }
+      }
+    }
+    __syncthreads();  // every wavefront has read the costs before the next round overwrites them
+  }
+  if (!t_isfinite(cost_ret)) status = 4;
+
+  // exit (wavefront 0): X, U from the nominal buffer, the gains of the last executed iteration
+  if (real && v == 0) {
+    const int XUo = SLay.xu_off(nb);
+    T* gX = a.X + prob * (int64_t)(n * (N + 1));
+    for (int e = g; e < n * (N + 1); e += kGroup) {
+      const int i = e / (N + 1), t = e - i * (N + 1);
+      gX[e] = S[XUo + t * W + i];
+    }
+    T* gU = a.U + prob * (int64_t)(m * N);
+    for (int e = g; e < m * N; e += kGroup) {
+      const int aa = e / N, t = e - aa * N;
+      gU[e] = S[XUo + t * W + n + aa];
+    }
+    if (a.K) {
+      const int oK = SLay.var0 + gsel * SLay.var_words + SLay.Kk_in_var;
+      T* gK = a.K + prob * (int64_t)(m * n * N);
+      for (int e = g; e < m * n * N; e += kGroup) {
+        const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
+        gK[e] = S[oK + (t * m + aa) * GL::KW + j];
+      }
+      T* gk = a.k + prob * (int64_t)(m * N);
+      for (int e = g; e < m * N; e += kGroup) {
+        const int aa = e / N, t = e - aa * N;
+        gk[e] = S[oK + (t * m + aa) * GL::KW + n];
+      }
+    }
     if (g == 0) {
       a.lamb[prob] = lamb;
       a.cost[prob] = cost_ret;

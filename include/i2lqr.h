@@ -199,6 +199,17 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     I2LQR_ERR_UNSUPPORTED otherwise).  Automatic: 8 from 1024 problems where built.
  *                     The two agree to round-off (1e-10 on one backward pass), not bit for bit:
  *                     K^T Quu K is associated differently.
+ *   "speculate"       ("group_lanes" 8 / automatic) 1: the speculative form of the eight-lane
+ *                     kernel — three wavefronts per eight problems, wavefront v runs the iteration
+ *                     that follows v rejects (same nominal trajectory, lamb * 10^v:
+ *                     control/iterative_ilqr.py:81-82); after each round the outcomes are resolved
+ *                     in order and everything behind the first accept is discarded.  Same
+ *                     iterations, same order, same arithmetic: bit-identical results; a run of r
+ *                     rejects and one accept costs one round instead of r + 1.  Uses SIMDs a small
+ *                     batch leaves idle, but the eight problems of a wavefront advance in
+ *                     lockstep rounds: on the benchmark workload it measures slower than the
+ *                     plain kernel (0.275 vs 0.215 ms per 10 iterations at 1024 problems).
+ *                     Opt-in; automatic: 0.
  *   "per_step_jacobians"  ("group_lanes" 64)  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
  *                     30-52) are written to LDS by the parallel per-step phase, so the serial
  *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.

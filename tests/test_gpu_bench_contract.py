@@ -35,8 +35,10 @@ def test_bench_json_line_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["traffic_stale"] in (True, False) and (r["traffic"] is None or not r["traffic_stale"])
     ri = d["roofline_issue"]
-    assert ri["bound"] == "issue" and ri["simds_occupied"] == 1024
-    assert abs(ri["peak"] - 1024 * 2.4 / 4) < 1e-9
+    # 1024 problems on the eight-problems-per-wavefront kernel: 128 wavefronts, one SIMD each
+    assert ri["bound"] == "issue" and ri["simds_occupied"] == 128
+    assert abs(ri["peak"] - 128 * 2.4 / 4) < 1e-9
+    assert r["kernel"] == "k_group_iterate"
     assert ri["frac"] is None or 0 < ri["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

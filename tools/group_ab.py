@@ -21,10 +21,13 @@ for B in (64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
     base = solver.alloc(B)
     base["x_term"].copy_(dev(host["x_term"]))
     base["obs"] = dev(host["obs"])
-    times = {64: [], 8: []}
+    times = {64: [], 8: [], "spec": []}
     for rep in range(12):
-        for lanes in (64, 8):
-            solver.set_option("group_lanes", lanes)
+        for lanes in (64, 8, "spec"):
+            solver.set_option("group_lanes", 8 if lanes == "spec" else lanes)
+            solver.set_option("speculate", 1 if lanes == "spec" else 0)
+            if lanes == "spec" and B > 4096:
+                continue
             base["X"].copy_(X0); base["U"].copy_(U0); base["lamb"].copy_(l0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -34,5 +37,7 @@ for B in (64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
             if rep >= 2:
                 times[lanes].append(e0.elapsed_time(e1))
     t64, t8 = np.median(times[64]), np.median(times[8])
+    ts = np.median(times["spec"]) if times["spec"] else float("nan")
     print(f"B={B:6d} {dtype}: wave {t64:8.4f} ms ({B * 10 / t64 / 1e3:8.1f} M it/s)   "
-          f"group {t8:8.4f} ms ({B * 10 / t8 / 1e3:8.1f} M it/s)   x{t64 / t8:.2f}")
+          f"group {t8:8.4f} ms ({B * 10 / t8 / 1e3:8.1f} M it/s)   spec {ts:8.4f} ms "
+          f"({B * 10 / ts / 1e3:8.1f} M it/s)")
