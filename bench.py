@@ -173,9 +173,25 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 for _ in range(steps + warmup)]
     main_stream = torch.cuda.current_stream()
     grouped = dist.is_available() and dist.is_initialized()
-    exchange = None
+    exchange, native_error = None, None
     if grouped and with_tail:
-        exchange = dist_mod.CostExchange(solver) if args.exchange == "native" else "torch"
+        exchange = "torch"
+        if args.exchange == "native":
+            # the communicator behind i2lqr_allgather_costs is created here by every rank at once;
+            # if RCCL cannot be bound or bootstrapped that way on this node, all ranks fall back
+            # to torch.distributed's all-gather together and the JSON line says so
+            try:
+                exchange = dist_mod.CostExchange(solver)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                native_error, ok = f"{type(e).__name__}: {e}", 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=solver.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if exchange != "torch" and not isinstance(exchange, str):
+                    exchange.close()
+                exchange = "torch"
+                native_error = native_error or "another rank could not create the communicator"
     comm_stream = torch.cuda.Stream() if exchange is not None else None
     cost_alls = ([torch.zeros(B * world, dtype=solver.dtype, device=solver.device)
                   for _ in range(steps + warmup)] if exchange is not None else None)
@@ -249,9 +265,13 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         assert int(idx.item()) == first and float(val.item()) == best, "exchange / pick mismatch"
         if exchange != "torch":
             res["nccl_world"] = exchange.comm_world
+            res["exchange_path"] = "native"
             exchange.close()
         else:
             res["nccl_world"] = dist.get_world_size()
+            res["exchange_path"] = "torch"
+            if native_error:
+                res["native_exchange_error"] = native_error
     solver.close()
     return res
 
@@ -507,10 +527,12 @@ def run_rank(args) -> int:
     if "exchange_ms" in res:
         out["exchange"] = {"ms_per_step": res["exchange_ms"], "nccl_world": res["nccl_world"],
                            "path": "i2lqr_allgather_costs (RCCL ncclAllGather via the C-ABI) + "
-                                   "i2lqr_argmin on a side stream" if args.exchange == "native"
+                                   "i2lqr_argmin on a side stream" if res["exchange_path"] == "native"
                            else "torch.distributed.all_gather_into_tensor + i2lqr_argmin on a "
                                 "side stream",
                            "bytes_per_rank": B * (8 if dtype == "f64" else 4)}
+        if "native_exchange_error" in res:
+            out["exchange"]["native_exchange_error"] = res["native_exchange_error"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B, args.iters, args.cpu_seconds)

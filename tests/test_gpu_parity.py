@@ -801,6 +801,48 @@ def test_quad12_sixteen_lane_kernel_vs_oracle_and_wave_kernel(torch_mod, B, iter
         bare.iterate(buf, 1)
 
 
+def test_quad12_full_size_properties_and_oracle_sample(torch_mod):
+    """BASELINE configs[4] at its full size: n=12, m=4, N=50, B=65536, fp64 on the sixteen-lane
+    kernel.  Size-independent properties over the whole batch (determinism, 2 + 2 == 4 fused
+    iterations bit-exactly, returned X is bit-exactly the rollout of returned U, cost is its
+    terminal cost, inputs inside the box) and the CPU oracle on a strided sample of 256 problems
+    that spans the index range (workspace slots and record addressing of the last wavefronts)."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    cfg = default_config("quad12", 50, "f64", dt=0.02)
+    solver = BatchedILQR(cfg)
+    B, iters = 65536, 4
+    host = workloads.make_batch(cfg, B)
+    assert solver.iterate_kernel(B) == "k_iterate"  # before the workspace is registered
+    a = solver.iterate(dev_batch(solver, host), iters)
+    assert solver.iterate_kernel(B) == "k_quad_iterate"
+    b = solver.iterate(dev_batch(solver, host), iters)
+    for key in ("X", "U", "lamb", "cost", "K", "k"):
+        assert torch.equal(a[key], b[key]), key
+    c = solver.iterate(solver.iterate(dev_batch(solver, host), 2), 2)
+    for key in ("X", "U", "lamb", "cost", "K", "k"):
+        assert torch.equal(a[key], c[key]), key
+    del b, c
+    assert int(a["iters"].min()) == iters == int(a["iters"].max())
+    X2, U2 = a["X"].clone(), a["U"].clone()
+    cost2 = solver.rollout(X2, U2, a["x_term"])
+    assert torch.equal(U2, a["U"]) and torch.equal(X2, a["X"]) and torch.equal(cost2, a["cost"])
+    assert torch.isfinite(a["cost"]).all() and (a["cost"] >= 0).all()
+    u_max = torch.tensor(list(cfg.u_max)[:cfg.m], dtype=solver.dtype, device=solver.device)
+    assert (a["U"].abs() <= u_max[None, :, None]).all()
+    idx = np.unique(np.concatenate([np.arange(0, B, B // 255), [B - 1, B - 2, B - 3]]))
+    ref = oracle().ilqr_batch(cfg, host["X"][idx], host["U"][idx], host["x_term"][idx],
+                              host["lamb"][idx], host["obs"][idx], max_iter=iters, early_exit=False)
+    tidx = torch.as_tensor(idx, device=solver.device)
+    same = a["lamb"][tidx].cpu().numpy() == ref["lamb"]
+    assert same.mean() >= 0.97
+    _check_flipped({key: a[key][tidx] for key in ("cost", "status")}, ref, same, 1e-6)
+    for key in ("X", "U"):
+        assert batch_rel_err(a[key][tidx].cpu().numpy()[same], ref[key][same]) < TOL_SOLVE, key
+    assert batch_rel_err(a["K"][tidx].cpu().numpy()[same], ref["K"][same]) < 1e-6
+    assert batch_rel_err(a["k"][tidx].cpu().numpy()[same], ref["k"][same], floor=1.0) < 1e-6
+
+
 def test_negative_curvature_takes_the_eigenvalue_clamping_path(torch_mod, layout):
     """The kernels invert a positive-definite Quu directly and fall back to the reference's
     eig / clamp-negative / add-lamb construction (control/iterative_ilqr.py:118-123) otherwise.
