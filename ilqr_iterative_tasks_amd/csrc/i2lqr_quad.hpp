@@ -5,12 +5,14 @@
 // problems per wavefront:
 //   lane j (0..n)   holds column j of [Vxx | Vx] and forms T1[:, j] = F^T Va[:, j] from the
 //                   compile-time sparsity of F = [A | B] (Sys::pat),
-//   lane b (0..15)  forms column b of H = L + T1[:, :n] F as a sum over the <= NZ rows in which
-//                   column b of F is non-zero: per-lane (source column, coefficient) lists,
-//                   uniform code; lane n additionally forms g = l + T1[:, n],
-//   Quu             = rows / columns n.. of H: held by lanes n..15, broadcast to all sixteen lanes
-//                   with DPP row broadcasts (a 16-lane group is one DPP row: no LDS round trip),
-//   [K | k][:, j]   = -Quu^-1 H[n:, j] lane-local; Va'[:, j] needs the other lanes' K columns.
+//   lane b (0..n-1) forms column b of H = L + T1[:, :n] F: its own T1 column (still in registers)
+//                   times F[b][b] plus a sum over the <= NZ other rows in which column b of F is
+//                   non-zero: per-lane (source column, coefficient) lists, uniform code; lane n
+//                   runs the same code with coefficients (1; 0, ..) and forms g = l + T1[:, n],
+//   Quu             every lane, from rows n.. of the exchanged T1 columns that the B columns of
+//                   F touch (compile-time pattern), LDL^T-factored in every lane,
+//   [K | k][:, j]   = -(Quu + lamb I)^-1 H[n:, j] by a lane-local solve; Va'[:, j] needs the other
+//                   lanes' K columns.
 // What does not fit next to it in LDS lives in a caller-provided HBM workspace
 // (i2lqr_workspace_bytes): the per-step records (Jacobian entries, barrier terms: written by the
 // record phase, read one step ahead by the backward pass), the gains (written by the backward
@@ -36,6 +38,15 @@ namespace i2lqr {
 constexpr int kQG = 16;              // lanes per problem (= one DPP row)
 constexpr int kQPW = 64 / kQG;       // problems per wavefront
 
+// Exchange buffer of the T1 columns, [row pair][column][2] words: the sixteen columns of a row pair
+// fill one 256-byte LDS bank row, 16 bytes each, so lanes that fetch DIFFERENT columns with
+// ds_read_b128 hit different banks (column-major, 128-byte columns, put every column on one of two
+// bank groups: 65 % of the LDS cycles of the kernel were bank conflicts).  `colw` = 2 * (column
+// rotated by the problem's bank phase, see QuadWorker).
+__device__ __forceinline__ int ex_word(int colw, int row) {
+  return (row >> 1) * (2 * kQG) + colw + (row & 1);
+}
+
 // value of lane `L` of each 16-lane row, in every lane of that row
 template <int L> __device__ __forceinline__ double row_bcast(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -52,20 +63,31 @@ template <int L> __device__ __forceinline__ float row_bcast(float v) {
 // Compile-time column lists of F = [A | B]
 template <class Sys> struct QPattern {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR;
+  // The diagonal entry F[b][b] of a state column multiplies the lane's OWN T1 column, which is
+  // still in its registers: it is kept out of the lists of columns fetched through LDS.
+  static constexpr bool has_own(int b) { return b < n && Sys::pat(b, b) != 0; }
+  static constexpr int own_code(int b) { return has_own(b) ? Sys::pat(b, b) : 0; }
+  static constexpr bool listed(int i, int b) { return Sys::pat(i, b) != 0 && !(has_own(b) && i == b); }
   static constexpr int nnz(int b) {
     int c = 0;
-    for (int i = 0; i < n; i++) c += Sys::pat(i, b) != 0;
+    for (int i = 0; i < n; i++) c += listed(i, b);
     return c;
   }
-  static constexpr int NZ = [] {
+  static constexpr int NZ = [] {  // over the state columns: the lanes that form H columns
     int mx = 0;
-    for (int b = 0; b < W; b++) mx = nnz(b) > mx ? nnz(b) : mx;
+    for (int b = 0; b < n; b++) mx = nnz(b) > mx ? nnz(b) : mx;
     return mx;
   }();
-  static constexpr int src(int b, int s) {  // s-th non-zero row of column b (0 past the end)
+  // does some B column of F touch row i?  (the T1 columns Quu is formed from)
+  static constexpr bool in_b(int i) {
+    for (int b = n; b < W; b++)
+      if (Sys::pat(i, b) != 0) return true;
+    return false;
+  }
+  static constexpr int src(int b, int s) {  // s-th listed row of column b (0 past the end)
     int c = 0;
     for (int i = 0; i < n; i++)
-      if (Sys::pat(i, b) != 0) {
+      if (listed(i, b)) {
         if (c == s) return i;
         c++;
       }
@@ -125,26 +147,53 @@ template <class T, class Sys> struct QuadWorker {
   const int N;
   T pc[NC];      // plant constants
   // per-lane column description
-  int off_c[NZ];  // record offsets of the coefficients of column g's non-zero rows
-  int srcw[NZ];   // word offsets of the T1 columns they multiply (EX[col][row])
-  int off_l0, off_l1;  // record offsets of the obstacle block terms of rows 0, 1 (lanes 0, 1)
+  int off_c[NZ];  // record offsets of the coefficients of column g's listed rows
+  int srcw[NZ];   // exchange-buffer column words (ex_word) of the T1 columns they multiply
+  int off_own;    // record offset of the coefficient of the lane's own T1 column
+  int ownw;       // exchange-buffer column word of the lane's own T1 column
+  int off_l0, off_l1;  // record offsets of the cost terms of rows 0, 1 (lanes 0, 1: obstacle block;
+                       // lane n: obstacle gradient)
+  int off_lu[m];       // ... of rows n..n+m-1 (lane n: input-barrier gradient)
+  int rotw;            // 2 * column rotation of this problem's exchange buffer
+#ifdef I2LQR_STAMPS
+  mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#endif
 
   __device__ QuadWorker(const Cfg& c_, T* smem, T* ws, int lane, int64_t prob)
       : c(c_), L(c_.N), S(smem + (lane / kQG) * QLayout<Sys>(c_.N).lds_total),
         Wp(ws + prob * (int64_t)QLayout<Sys>(c_.N).ws_total), g(lane % kQG), N(c_.N) {
 #pragma unroll
     for (int q = 0; q < NC; q++) pc[q] = Sys::plant_const(c, q);
+    // Bank phase: a ds_read_b128 is served in lane groups that hold eight lanes of one problem
+    // and eight of its neighbour; the columns are rotated so that problem p's column c sits in
+    // 16-byte slot (c + 12 p) mod 16 of the bank row whatever the slice size is (the rotation that
+    // leaves the fewest shared slots for this plant's column lists).
+    const int slot0 = (int)(((unsigned)(uintptr_t)(S + L.EX) >> 4) & 15u);
+    const int rot = (12 * (lane / kQG) - slot0) & 15;
 #pragma unroll
-    for (int s = 0; s < NZ; s++) { off_c[s] = QL::R_ZERO; srcw[s] = 0; }
+    for (int s = 0; s < NZ; s++) { off_c[s] = QL::R_ZERO; srcw[s] = 2 * (rot & 15); }
     off_l0 = QL::R_ZERO;
     off_l1 = QL::R_ZERO;
-    static_for_i<0, W>([&](auto b_) {
+#pragma unroll
+    for (int a = 0; a < m; a++) off_lu[a] = QL::R_ZERO;
+    off_own = QL::R_ZERO;
+    ownw = 2 * ((g + rot) & 15);
+    rotw = 2 * rot;
+    if (g == n) {  // lane n: g = l + T1[:, n]
+      off_own = QL::R_ONE;
+      off_l0 = QL::R_OB + 0;
+      off_l1 = QL::R_OB + 1;
+#pragma unroll
+      for (int a = 0; a < m; a++) off_lu[a] = QL::R_LU + a;
+    }
+    static_for_i<0, n>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
       if (g == b) {
+        off_own = QL::rec_off(QP::own_code(b));
         static_for_i<0, NZ>([&](auto s_) {
           constexpr int s = decltype(s_)::value;
           off_c[s] = QL::rec_off(QP::code(b, s));
-          srcw[s] = QP::src(b, s) * W;
+          srcw[s] = 2 * ((QP::src(b, s) + rot) & 15);
         });
         if (b < 2) {  // obstacle block l_xx[a][b], a, b < 2: ob[2 + a + b]
           off_l0 = QL::R_OB + 2 + b;
@@ -317,31 +366,29 @@ template <class T, class Sys> struct QuadWorker {
         }
         va[i] = (g == n) ? vx : vxx;
       }
-      const T ob0 = Rn[QL::R_OB + 0], ob1 = Rn[QL::R_OB + 1];
-      va[0] += (g == n) ? ob0 : Rn[off_l0];
-      va[1] += (g == n) ? ob1 : Rn[off_l1];
+      va[0] += Rn[off_l0];
+      va[1] += Rn[off_l1];
     }
     T* const EX = S + L.EX;
     // the record of a step is loaded one step ahead (HBM / L2 latency under the previous step)
-    T jv[NV], lu[m], luu[m], ob01[2], cf[NZ], l0, l1;
+    T jv[NV], luu[m], cf[NZ], cf_own, l0, l1, lrow[m];
     auto load_record = [&](int t) __attribute__((always_inline)) {
       const T* R = Wp + L.REC + t * QL::RW;
 #pragma unroll
       for (int q = 0; q < NV; q++) jv[q] = R[q];
 #pragma unroll
-      for (int a = 0; a < m; a++) {
-        lu[a] = R[QL::R_LU + a];
-        luu[a] = R[QL::R_LUU + a];
-      }
-      ob01[0] = R[QL::R_OB + 0];
-      ob01[1] = R[QL::R_OB + 1];
+      for (int a = 0; a < m; a++) luu[a] = R[QL::R_LUU + a];
 #pragma unroll
       for (int s = 0; s < NZ; s++) cf[s] = R[off_c[s]];
+      cf_own = R[off_own];
       l0 = R[off_l0];
       l1 = R[off_l1];
+#pragma unroll
+      for (int a = 0; a < m; a++) lrow[a] = R[off_lu[a]];
     };
     load_record(N - 1);
     auto step = [&](const int t) __attribute__((always_inline)) {
+      STAMP_BEGIN();
       // P1: own column of T1 = F^T [Vxx | Vx]
       T t1[W];
       static_for_i<0, W>([&](auto a_) {
@@ -355,64 +402,87 @@ template <class T, class Sys> struct QuadWorker {
         t1[a] = acc;
       });
 #pragma unroll
-      for (int a = 0; a < W; a++) EX[g * W + a] = t1[a];
-      // g = l + T1[:, n] (meaningful in lane n): l_x obstacle part (rows 0, 1), l_u (rows n..)
-      T gv[W];
-#pragma unroll
-      for (int a = 0; a < W; a++) gv[a] = t1[a];
-      gv[0] += ob01[0];
-      gv[1] += ob01[1];
-#pragma unroll
-      for (int a = 0; a < m; a++) gv[n + a] += lu[a];
+      for (int a = 0; a < W; a++) EX[ex_word(ownw, a)] = t1[a];
       wave_sync();
-      // P2: column g of H = L + T1[:, :n] F
+      STAMP_END(1);
+      // P2: column g of H = L + T1[:, :n] F (lanes < n), g = l + T1[:, n] (lane n)
       T h[W];
       {
         T colA[W], colB[W];
         auto load_col = [&](int s_, T (&dst)[W]) __attribute__((always_inline)) {
           const T* col = EX + srcw[s_];
 #pragma unroll
-          for (int a = 0; a < W; a++) dst[a] = col[a];
+          for (int a = 0; a < W; a++) dst[a] = col[ex_word(0, a)];
         };
         load_col(0, colA);
+#pragma unroll
+        for (int a = 0; a < W; a++) h[a] = cf_own * t1[a];  // own column: no LDS round trip
         static_for_i<0, NZ>([&](auto s_) {
           constexpr int s2 = decltype(s_)::value;
           T (&cur)[W] = (s2 & 1) ? colB : colA;
           T (&nxt)[W] = (s2 & 1) ? colA : colB;
           if constexpr (s2 + 1 < NZ) load_col(s2 + 1, nxt);
 #pragma unroll
-          for (int a = 0; a < W; a++) h[a] = (s2 == 0) ? cf[0] * cur[a] : t_fma(cf[s2], cur[a], h[a]);
+          for (int a = 0; a < W; a++) h[a] = t_fma(cf[s2], cur[a], h[a]);
         });
       }
       h[0] += l0;
       h[1] += l1;
 #pragma unroll
-      for (int a = 0; a < m; a++) h[n + a] += (g == n + a) ? luu[a] : T(0);
+      for (int a = 0; a < m; a++) h[n + a] += lrow[a];
+      // Quu (every lane): l_uu + B^T T1[n.., :n]^T, from the T1 columns the B columns of F touch
+      T Quu[m * m];
+      {
+        T tb[n][m];  // T1[n + a][i] for the rows i of B that are not structurally zero
+        static_for_i<0, n>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          if constexpr (QP::in_b(i)) {
+            const T* col = EX + ((rotw + 2 * i) & 31);
+#pragma unroll
+            for (int a = 0; a < m; a++) tb[i][a] = col[ex_word(0, n + a)];
+          }
+        });
+        static_for_i<0, m>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          static_for_i<0, m>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            T acc = T(0);
+            bool first = true;
+            static_for_i<0, n>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              if constexpr (Sys::pat(i, n + b) != 0) f_acc<i, n + b>(acc, first, tb[i][a], jv);
+            });
+            Quu[a * m + b] = (a == b ? luu[a] : T(0)) + acc;
+          });
+        });
+      }
+      STAMP_END(4);
       // every value of this step's record has been consumed: fetch the next one now, its HBM / L2
-      // latency hides under the inverse, the gain exchange and the value update
+      // latency hides under the factorisation, the gain exchange and the value update
       load_record(t > 0 ? t - 1 : 0);
-      // Quu: rows n.. of the columns held by lanes n..15, broadcast to the whole group
-      T Quu[m * m], Qinv[m * m];
-      static_for_i<0, m>([&](auto b_) {
-        constexpr int b = decltype(b_)::value;
-#pragma unroll
-        for (int a = 0; a < m; a++) Quu[a * m + b] = row_bcast<n + b>(h[n + a]);
-      });
-      if constexpr (m == 2) {
-        if constexpr (GENERAL) t_quu_inverse2(Quu, lamb, Qinv);
-        else t_quu_inverse2_pd(Quu, lamb, Qinv, &bad);
-      } else {
-        t_quu_inverse_m<T, m, GENERAL>(Quu, lamb, Qinv, &bad);
-      }
-      // own column of [K | k] = -Quu_inv [Qux | Qu] (lane n: from g)
+      // own column of [K | k] = -(regularised Quu)^-1 [Qux | Qu]: control/iterative_ilqr.py:118-126
       T kc[m];
+      if constexpr (GENERAL) {
+        T Qinv[m * m];
+        if constexpr (m == 2) t_quu_inverse2(Quu, lamb, Qinv);
+        else t_quu_inverse_m<T, m, true>(Quu, lamb, Qinv, &bad);
 #pragma unroll
-      for (int a = 0; a < m; a++) {
-        T acc = T(0);
+        for (int a = 0; a < m; a++) {
+          T acc = T(0);
 #pragma unroll
-        for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], (g == n) ? gv[n + b] : h[n + b], acc);
-        kc[a] = -acc;
+          for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], h[n + b], acc);
+          kc[a] = -acc;
+        }
+      } else {
+        T Lf[m * m], ir[m], hu[m], sol[m];
+        t_quu_factor_pd<T, m>(Quu, lamb, Lf, ir, &bad);
+#pragma unroll
+        for (int b = 0; b < m; b++) hu[b] = h[n + b];
+        t_quu_solve<T, m>(Lf, ir, hu, sol);
+#pragma unroll
+        for (int a = 0; a < m; a++) kc[a] = -sol[a];
       }
+      STAMP_END(5);
       wave_sync();  // every lane is done reading the T1 columns: EX now carries the gain columns
       T* Gt = Wp + L.GK + t * (m * QL::GW);
 #pragma unroll
@@ -435,9 +505,10 @@ template <class T, class Sys> struct QuadWorker {
         T acc = T(0);
 #pragma unroll
         for (int a = 0; a < m; a++) acc = t_fma(EX[a * QL::GW + i], qk[a], acc);
-        va[i] = ((g == n) ? gv[i] : h[i]) - acc;
+        va[i] = h[i] - acc;
       }
       wave_sync();  // EX is free for the next step's T1 columns
+      STAMP_END(6);
     };
     int t = N - 1;
     for (; t >= 1; t -= 2) {
@@ -592,7 +663,8 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   wave_sync();
 
 #ifdef I2LQR_STAMPS
-  STAMP_DECL;
+  auto& st_acc = w.st_acc; auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1;
+  STAMP_BEGIN();
 #endif
   int cur = 0;  // which HBM candidate buffer holds the sin / cos values of the nominal
   T cost = w.rollout(L.XC0, xT);
@@ -603,6 +675,9 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
   T cost_ret = cost;
   bool fresh = true, active = a.n_iters > 0;
+#ifdef I2LQR_STAMPS
+  STAMP_END(7);
+#endif
   while (__any(active)) {
     const int XCo = cur ? L.XC1 : L.XC0, XCn = cur ? L.XC0 : L.XC1;
 #ifdef I2LQR_STAMPS
@@ -615,7 +690,7 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
     if (__builtin_expect(__any(w.template backward<false>(xT, lamb)), 0))
       w.template backward<true>(xT, lamb);
 #ifdef I2LQR_STAMPS
-    STAMP_END(1);
+    STAMP_BEGIN();
 #endif
     bool big = false;
     T cost_new = w.template forward<false>(XCn, xT, &big);
@@ -658,10 +733,8 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   }
   if (!t_isfinite(cost_ret)) status = 4;
 #ifdef I2LQR_STAMPS
-  if (a.dbg && g == 0 && real)
-    for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = st_acc[q];
+  STAMP_BEGIN();
 #endif
-
   if (real) {
     T* gX = a.X + prob * (int64_t)(n * (N + 1));
     for (int e = g; e < n * (N + 1); e += kQG) {
@@ -674,16 +747,41 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
       gU[e] = S[L.XU + t * W + n + aa];
     }
     if (a.K) {  // gains of the last backward pass: workspace [t][a][16] -> K[m][n][N], k[m][N]
+      // Eight gathers in flight per lane: a load-store loop that waits for every element pays the
+      // L2 / HBM latency 150 times per problem.
       const T* GK = w.Wp + L.GK;
       T* gK = a.K + prob * (int64_t)(m * n * N);
-      for (int e = g; e < m * n * N; e += kQG) {
-        const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
-        gK[e] = GK[(t * m + aa) * QL::GW + j];
+      constexpr int CH = 8;
+      const int totK = m * n * N;
+      for (int base = 0; base < totK; base += CH * kQG) {
+        T v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+          const int e0 = base + q * kQG + g, e = e0 < totK ? e0 : totK - 1;
+          const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
+          v[q] = GK[(t * m + aa) * QL::GW + j];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+          const int e = base + q * kQG + g;
+          if (e < totK) gK[e] = v[q];
+        }
       }
       T* gk = a.k + prob * (int64_t)(m * N);
-      for (int e = g; e < m * N; e += kQG) {
-        const int aa = e / N, t = e - aa * N;
-        gk[e] = GK[(t * m + aa) * QL::GW + n];
+      const int totk = m * N;
+      for (int base = 0; base < totk; base += CH * kQG) {
+        T v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+          const int e0 = base + q * kQG + g, e = e0 < totk ? e0 : totk - 1;
+          const int aa = e / N, t = e - aa * N;
+          v[q] = GK[(t * m + aa) * QL::GW + n];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+          const int e = base + q * kQG + g;
+          if (e < totk) gk[e] = v[q];
+        }
       }
     }
     if (g == 0) {
@@ -693,6 +791,12 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
       if (a.status) a.status[prob] = status;
     }
   }
+#ifdef I2LQR_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP_END(7);  // slot 7: entry (loads + nominal rollout) + exit (stores), per launch
+  if (a.dbg && g == 0 && real)
+    for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = st_acc[q];
+#endif
 }
 
 }  // namespace i2lqr

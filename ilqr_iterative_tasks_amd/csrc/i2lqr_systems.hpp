@@ -171,6 +171,17 @@ template <class T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -
 // Reciprocal / square root for the 2x2 regularised inverse: hardware seed (v_rcp_f64 / v_rsq_f64)
 // + two Newton steps — <= ~2 ulp on normal-range operands, a third of the instructions of the
 // IEEE-exact division / sqrt expansions.  Zero, infinite and NaN operands behave like 1/x, sqrt(x).
+// The library is built with -ffp-contract=off so that one source expression rounds the same way
+// in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
+// the dot products of the Riccati step ask for the fused multiply-add explicitly.
+template <class T> __device__ __forceinline__ T t_fma(T a, T b, T c);
+template <> __device__ __forceinline__ double t_fma<double>(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+template <> __device__ __forceinline__ float t_fma<float>(float a, float b, float c) {
+  return __builtin_fmaf(a, b, c);
+}
+
 template <class T> __device__ __forceinline__ T t_rcp(T x);
 template <> __device__ __forceinline__ double t_rcp<double>(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -268,6 +279,70 @@ __device__ __forceinline__ void t_quu_inverse2(const T (&Quu)[4], T lamb, T (&in
     inv[1] = pd ? inv[1] : g1;
     inv[2] = pd ? inv[2] : g2;
     inv[3] = pd ? inv[3] : g3;
+  }
+}
+
+// Positive-definite form of the regularised solve, for callers that need (Quu + lamb I)^-1 applied
+// to a few vectors rather than the inverse itself: square-root-free LDL^T of the symmetrised Quu
+// (pivot test: *bad set, never cleared, if a pivot is not positive — the caller then repeats its
+// pass with the general form, t_quu_inverse_m<.., true>) and of Quu + lamb I (unit lower factor Lf,
+// reciprocal pivots ir).  Same factorisations as t_quu_inverse_m, without forming Lf^-1 and the
+// inverse (about a third of the instructions for m = 4); agrees with it to round-off.
+template <class T, int m>
+__device__ __forceinline__ void t_quu_factor_pd(const T (&Quu)[m * m], T lamb, T (&Lf)[m * m],
+                                                T (&ir)[m], bool* bad) {
+  T Sm[m * m];
+#pragma unroll
+  for (int i = 0; i < m; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Sm[i * m + j] = T(0.5) * (Quu[i * m + j] + Quu[j * m + i]);
+  T Lp[m * m], Wp[m * m], Wr[m * m];  // L and W = L diag(d), strictly lower parts
+  bool pd = true;
+#pragma unroll
+  for (int j = 0; j < m; j++) {
+    T dp = Sm[j * m + j], dr = Sm[j * m + j] + lamb;
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      dp = t_fma(-Wp[j * m + k], Lp[j * m + k], dp);
+      dr = t_fma(-Wr[j * m + k], Lf[j * m + k], dr);
+    }
+    pd = pd && (dp > T(0));
+    const T ipj = t_rcp(dp);
+    ir[j] = t_rcp(dr);
+#pragma unroll
+    for (int i = j + 1; i < m; i++) {
+      T vp = Sm[i * m + j], vr = Sm[i * m + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) {
+        vp = t_fma(-Wp[i * m + k], Lp[j * m + k], vp);
+        vr = t_fma(-Wr[i * m + k], Lf[j * m + k], vr);
+      }
+      Wp[i * m + j] = vp;
+      Wr[i * m + j] = vr;
+      Lp[i * m + j] = vp * ipj;
+      Lf[i * m + j] = vr * ir[j];
+    }
+  }
+  *bad = *bad || !pd;
+}
+// x = (Lf diag(1 / ir) Lf^T)^-1 b
+template <class T, int m>
+__device__ __forceinline__ void t_quu_solve(const T (&Lf)[m * m], const T (&ir)[m], const T (&b)[m],
+                                            T (&x)[m]) {
+  T y[m];
+#pragma unroll
+  for (int i = 0; i < m; i++) {
+    T acc = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) acc = t_fma(-Lf[i * m + k], y[k], acc);
+    y[i] = acc;
+  }
+#pragma unroll
+  for (int i = m - 1; i >= 0; i--) {
+    T acc = y[i] * ir[i];
+#pragma unroll
+    for (int k = i + 1; k < m; k++) acc = t_fma(-Lf[k * m + i], x[k], acc);
+    x[i] = acc;
   }
 }
 
@@ -412,17 +487,6 @@ __device__ __forceinline__ void t_quu_inverse_m(const T (&Quu)[m * m], T lamb, T
 #pragma unroll
     for (int e = 0; e < m * m; e++) inv[e] = pd ? inv[e] : ginv[e];
   }
-}
-
-// The library is built with -ffp-contract=off so that one source expression rounds the same way
-// in every kernel it is inlined into (the bit-exact replay properties of tests/ rely on it);
-// the dot products of the Riccati step ask for the fused multiply-add explicitly.
-template <class T> __device__ __forceinline__ T t_fma(T a, T b, T c);
-template <> __device__ __forceinline__ double t_fma<double>(double a, double b, double c) {
-  return __builtin_fma(a, b, c);
-}
-template <> __device__ __forceinline__ float t_fma<float>(float a, float b, float c) {
-  return __builtin_fmaf(a, b, c);
 }
 
 // ---------------------------------------------------------------------------------------------

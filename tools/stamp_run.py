@@ -13,7 +13,7 @@ from ilqr_iterative_tasks_amd import _abi, workloads
 _abi.LIB_PATH = ROOT / "tools" / "_diag" / "libi2lqr_stamps.so"
 from ilqr_iterative_tasks_amd import BatchedILQR
 
-B = 1024
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
 iters = 10 if wl == "config2" else 4
 cfg = workloads.config_for(wl, sys.argv[1] if len(sys.argv) > 1 else "f64")
@@ -37,7 +37,8 @@ solver.iterate(buf, iters)
 torch.cuda.synchronize()
 d = dbg.double().mean(0).cpu().numpy() / iters
 names = (["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
-         if lanes == 64 else ["record phase", "backward", "forward", "accept + adopt", "-", "-", "-", "-"]
+         if lanes == 64 else ["record phase", "bwd P1 + T1 exchange", "forward", "accept + adopt", "bwd P2 (H column)",
+          "bwd record fetch, Quu, inverse, gain column", "bwd gain exchange + value update", "rollout at entry + stores at exit (per launch / iters)"]
          if lanes == 16 else
          ["prep", "bwd P1 + T1 exchange", "bwd P2 (H column)", "bwd Quu + inverse",
           "bwd gains + exchange", "bwd value update", "forward", "-"])
