@@ -297,9 +297,9 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     ms = e0.elapsed_time(e1) / reps
     it = sets[1]["iters"].double()
     executed = float(it.sum())
-    kernel = solver.iterate_kernel(B)
+    kernel = solver.solve_kernel(B)
     if kernel == "k_lane_iterate" and not single_launch:
-        kernel = "k_lane_iterate chunks + k_lane_compact + k_iterate tail"
+        kernel = "k_lane_iterate chunks + k_lane_compact + k_group_spec tail"
     solver.close()
     return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
             "iterations_mean": executed / B, "iterations_max": int(it.max()), "kernel": kernel}

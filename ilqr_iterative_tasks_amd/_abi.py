@@ -144,6 +144,7 @@ EXPORTS = {
     "i2lqr_set_compaction": (C.c_int, [_P, C.c_int64]),
     "i2lqr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "i2lqr_iterate_kernel": (C.c_char_p, [_P, C.c_int64]),
+    "i2lqr_solve_kernel": (C.c_char_p, [_P, C.c_int64]),
     "i2lqr_rollout": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "i2lqr_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "i2lqr_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -73,6 +73,7 @@ template <class T, class Sys> struct Launch {
   }
   static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
   static constexpr int64_t kAutoGroupBatch = 1024;
+  static constexpr int64_t kAutoSpecBatch = 2048;
   static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
@@ -147,8 +148,12 @@ template <class T, class Sys> struct Launch {
       if (h->opt_spec == 1 && !can_spec)
         return fail(I2LQR_ERR_UNSUPPORTED, "\"speculate\" = 1 needs the eight-lane kernel and a "
                     "horizon whose speculative buffers fit the 160 KiB of LDS");
+      // Automatic for solves to termination (early_exit) of at most kAutoSpecBatch problems: the
+      // launch lasts as long as its slowest problem, and the slowest problems alternate accepts and
+      // rejects — 1.20 -> 0.77 ms at 1024 problems, 0.78 -> 0.68 ms at 2048, even at 4096.
       const bool spec = can_spec && h->opt_group != 64 &&
-                        h->opt_spec == 1;
+                        (h->opt_spec == 1 ||
+                         (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch));
       if (spec) {
         HIP_TRY(group_spec_iterate<T>(h->cfg, a, s));
         return I2LQR_OK;
@@ -419,14 +424,22 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (wave_tail > 0 && done >= 4) {
         using WL = Launch<T, Sys>;
         const size_t lds_f = WL::fstep_lds_bytes(N);
-        if (WL::kHasFstep && lds_f <= 64 * 1024) {
-          IterArgs<T> t;
-          t.B = B; t.n_iters = max_iter; t.early_exit = 1;
-          t.X = w.X; t.U = w.U; t.x_term = w.x_term; t.lamb = w.lamb; t.obs = w.obs;
-          t.cost = w.cost; t.K = w.K; t.k = w.k; t.iters = w.iters; t.status = w.status;
-          t.dbg = nullptr;
-          t.count = cv.count + cur; t.count_max = wave_tail; t.max_total = max_iter;
-          t.set_stride = B;
+        IterArgs<T> t;
+        t.B = B; t.n_iters = max_iter; t.early_exit = 1;
+        t.X = w.X; t.U = w.U; t.x_term = w.x_term; t.lamb = w.lamb; t.obs = w.obs;
+        t.cost = w.cost; t.K = w.K; t.k = w.k; t.iters = w.iters; t.status = w.status;
+        t.dbg = nullptr;
+        t.count = cv.count + cur; t.count_max = wave_tail; t.max_total = max_iter;
+        t.set_stride = B;
+        // The survivors are the problems with long accept / reject chains (stragglers alternate
+        // accept, reject, accept, ...): the speculative eight-lane kernel runs the iteration after
+        // a reject beside the current one and needs about half the rounds; bit-identical.
+        bool spec_tail = false;
+        if constexpr (m == 2 && n + m <= 8)
+          spec_tail = h->opt_spec != 0 && c.flags == 0 && group_spec_tail_supported(h->cfg);
+        if (spec_tail) {
+          if constexpr (m == 2 && n + m <= 8) HIP_TRY(group_spec_tail<T>(h->cfg, t, s));
+        } else if (WL::kHasFstep && lds_f <= 64 * 1024) {
           if constexpr (WL::kHasFstep) {
             if (c.flags)
               hipLaunchKernelGGL((k_iterate<T, Sys, 64, true, true, true>), dim3(wave_tail),
@@ -929,12 +942,13 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   return I2LQR_OK;
 }
 
-const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) {
+static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit) {
   if (!h) return "";
   if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return "k_lane_iterate";
   const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
   const bool can = m2 && group_supported(h->cfg);
-  if (can && group_spec_supported(h->cfg) && h->opt_group != 64 && h->opt_spec == 1)
+  if (can && group_spec_supported(h->cfg) && h->opt_group != 64 &&
+      (h->opt_spec == 1 || (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= 2048)))
     return "k_group_spec";
   if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
   if ((h->opt_group == 16 || h->opt_group < 0) && quad_supported(h->cfg) && h->ws &&
@@ -942,6 +956,9 @@ const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) {
     return "k_quad_iterate";
   return "k_iterate";
 }
+
+const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) { return kernel_name(h, B, false); }
+const char* i2lqr_solve_kernel(const i2lqr_handle* h, int64_t B) { return kernel_name(h, B, true); }
 
 int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes) {
   if (!h) return fail(I2LQR_ERR_INVALID, "null handle");

@@ -20,6 +20,13 @@ template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterA
 bool group_spec_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group_spec_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                                  hipStream_t stream);
+// The same kernel on the first *a.count (<= a.count_max) columns of a batch-minor work set: the tail
+// of the chunked solves of the one-problem-per-lane layouts (IterArgs::count / set_stride /
+// max_total).  Supported for the plants of the eight-lane kernel with Q = R = 0, whatever the
+// handle's layout is.
+bool group_spec_tail_supported(const i2lqr_config& cfg);
+template <class T> hipError_t group_spec_tail(const i2lqr_config& cfg, const IterArgs<T>& a,
+                                              hipStream_t stream);
 
 // Sixteen lanes per problem (i2lqr_quad.hpp; the n + m = 16 plant quad12, Q = R = 0): needs a
 // caller-provided HBM workspace of quad_workspace_bytes() for B problems.

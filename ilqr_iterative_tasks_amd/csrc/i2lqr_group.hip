@@ -46,28 +46,41 @@ template <class T, class Sys> size_t spec_lds_bytes(int N) {
   return (size_t)GSpecLayout<Sys, kSpecV>(N).group_words() * sizeof(T);
 }
 
-template <class T, class Sys>
+// SETIO: a.count_max problems at most (k_group_spec<.., true>, the tail of the chunked solves)
+template <class T, class Sys, bool SETIO>
 hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
   const size_t lds = spec_lds_bytes<T, Sys>(cfg.N);
   if (lds > 64 * 1024) {
     static thread_local int raised_for = 0;
     if (raised_for < (int)lds) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, kSpecV>,
+      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, kSpecV, SETIO>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       raised_for = (int)lds;
     }
   }
-  const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
-  hipLaunchKernelGGL((k_group_spec<T, Sys, kSpecV>), dim3(grid), dim3(64 * kSpecV), lds, s, c, a);
+  const int64_t problems = SETIO ? (int64_t)a.count_max : a.B;
+  const unsigned grid = (unsigned)((problems + kGroupsPerWave - 1) / kGroupsPerWave);
+  hipLaunchKernelGGL((k_group_spec<T, Sys, kSpecV, SETIO>), dim3(grid), dim3(64 * kSpecV), lds, s,
+                     c, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
+namespace {
+bool spec_lds_fits(const i2lqr_config& cfg);
+}
 bool group_spec_supported(const i2lqr_config& cfg) {
-  if (!group_supported(cfg)) return false;
+  return group_supported(cfg) && spec_lds_fits(cfg);
+}
+bool group_spec_tail_supported(const i2lqr_config& cfg) {
+  if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
+  return !has_stage_weights(cfg) && spec_lds_fits(cfg);
+}
+namespace {
+bool spec_lds_fits(const i2lqr_config& cfg) {
   const size_t lds = cfg.dtype == I2LQR_F64
       ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>>(cfg.N)
                                              : spec_lds_bytes<double, Bicycle6<double>>(cfg.N))
@@ -75,16 +88,31 @@ bool group_spec_supported(const i2lqr_config& cfg) {
                                              : spec_lds_bytes<float, Bicycle6<float>>(cfg.N));
   return lds <= 160 * 1024;
 }
+}  // namespace
 
 template <> hipError_t group_spec_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
                                                   hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec<double, Bicycle4<double>>(cfg, a, s);
-  return launch_spec<double, Bicycle6<double>>(cfg, a, s);
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
+    return launch_spec<double, Bicycle4<double>, false>(cfg, a, s);
+  return launch_spec<double, Bicycle6<double>, false>(cfg, a, s);
 }
 template <> hipError_t group_spec_iterate<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
                                                  hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec<float, Bicycle4<float>>(cfg, a, s);
-  return launch_spec<float, Bicycle6<float>>(cfg, a, s);
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
+    return launch_spec<float, Bicycle4<float>, false>(cfg, a, s);
+  return launch_spec<float, Bicycle6<float>, false>(cfg, a, s);
+}
+template <> hipError_t group_spec_tail<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                               hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
+    return launch_spec<double, Bicycle4<double>, true>(cfg, a, s);
+  return launch_spec<double, Bicycle6<double>, true>(cfg, a, s);
+}
+template <> hipError_t group_spec_tail<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                              hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
+    return launch_spec<float, Bicycle4<float>, true>(cfg, a, s);
+  return launch_spec<float, Bicycle6<float>, true>(cfg, a, s);
 }
 
 bool group_supported(const i2lqr_config& cfg) {

@@ -88,15 +88,24 @@ template <class Sys> struct GroupPattern {
 //   TR0, TR1  sin / cos values the plant step evaluated at x_t (t = 0..N), one array per trajectory
 //             buffer: the rollouts compute them anyway, prep() reads them back instead of
 //             evaluating sincos a second time
-//   T1c       exchange buffer for the T1 columns, [8 columns][W rows]
-// Per wavefront (after the eight problem slices): Qt[n][n].
+// Per wavefront (after the eight problem slices):
+//   T1c       exchange buffers for the T1 columns, kT1Stride words per problem, [row pair][column][2]
+//             words: the eight columns of a row pair are eight consecutive 16-byte slots, so the
+//             eight lanes of a problem store their columns without a bank conflict (column-major
+//             put them on two slots: 4-way) and lanes that fetch different columns of one row pair
+//             do not collide.  The stride (640 bytes) alternates the problems between the two
+//             halves of the 256-byte bank row and the columns of problems 2, 3, 6, 7 are rotated by
+//             one slot (t1_word): with that, none of the 16-lane groups a ds_read_b128 is served in
+//             has two lanes on one slot for this kernel's read patterns.
+//   Qt[n][n]
 template <class Sys> struct GLayout {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
   static constexpr int KW = (n + 1 + 1) & ~1;  // gain row [K[a][0..n-1], k[a]] padded to 16 bytes (fp64)
   static constexpr int R_JV = 0, R_ZERO = NV, R_ONE = NV + 1, R_LU = NV + 2, R_LUU = NV + 2 + m,
                        R_OB = NV + 2 + 2 * m, RW = (NV + 2 + 2 * m + 5 + 1) & ~1;
   int N;
-  int XU0, XU1, Kk, R, TR0, TR1, T1c, total;
+  static constexpr int kT1Stride = 80;
+  int XU0, XU1, Kk, R, TR0, TR1, total;
   __host__ __device__ explicit GLayout(int N_) : N(N_) {
     int o = 0;
     XU0 = o; o += W * (N + 1); o = (o + 3) & ~3;
@@ -105,14 +114,15 @@ template <class Sys> struct GLayout {
     R = o; o += RW * (N + 1);
     TR0 = o; o += NT * (N + 1); o = (o + 3) & ~3;
     TR1 = o; o += NT * (N + 1); o = (o + 3) & ~3;
-    T1c = o; o += kGroup * W; o = (o + 3) & ~3;
     // keep consecutive problem slices on different LDS banks for group-uniform 16-byte reads:
     // slice stride = 4 * odd words
     o = (o + 3) & ~3;
     if (((o / 4) & 1) == 0) o += 4;
     total = o;
   }
-  __host__ __device__ int wave_words() const { return kGroupsPerWave * total + n * n; }
+  __host__ __device__ int t1_base() const { return kGroupsPerWave * total; }
+  __host__ __device__ int qt_base() const { return t1_base() + kGroupsPerWave * kT1Stride; }
+  __host__ __device__ int wave_words() const { return qt_base() + n * n; }
 };
 
 template <class T, class Sys> struct GroupWorker {
@@ -128,8 +138,10 @@ template <class T, class Sys> struct GroupWorker {
   const T* const Qt; // the wavefront's copy of Q_terminal
   const int g;       // lane inside the group = column index
   const int N;
-  int oR, oKk, oT1c;  // where the records, the gains and the exchange buffer sit in the slice
-                      // (the layout's by default; the speculative kernel gives each wavefront its own)
+  int oR, oKk;       // where the records and the gains sit in the slice (the layout's by default;
+                     // the speculative kernel gives each wavefront its own)
+  T* T1c;            // this problem's exchange buffer
+  int rho;           // its column rotation (see GLayout)
 
   // per-lane column description (constant over the kernel)
   int off_c0, off_c1;        // record offsets of F[0][g], F[1][g]
@@ -143,12 +155,22 @@ template <class T, class Sys> struct GroupWorker {
 
   __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
       : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N).total,
-                    smem + kGroupsPerWave * GLayout<Sys>(c_.N).total, lane % kGroup) {}
+                    smem + GLayout<Sys>(c_.N).qt_base(), lane % kGroup) {
+    const int p = lane / kGroup;
+    T1c = smem + L.t1_base() + p * GL::kT1Stride;
+    rho = (p >> 1) & 1;
+  }
+  // word of (column, row) in the problem's exchange buffer
+  __device__ __forceinline__ int t1_word(int col, int row) const {
+    return (row >> 1) * (2 * kGroup) + ((col + rho) & (kGroup - 1)) * 2 + (row & 1);
+  }
 
   // slice: this problem's LDS slice; qt: Q_terminal in LDS
   __device__ GroupWorker(const Cfg& c_, T* slice, const T* qt, int g_)
       : c(c_), L(c_.N), S(slice), Qt(qt), g(g_), N(c_.N) {
-    oR = L.R; oKk = L.Kk; oT1c = L.T1c;
+    oR = L.R; oKk = L.Kk;
+    T1c = nullptr;  // set by the caller (with rho) before the first pass
+    rho = 0;
     off_c0 = GL::R_ZERO; off_c1 = GL::R_ZERO; off_l0 = GL::R_ZERO; off_l1 = GL::R_ZERO;
 #pragma unroll
     for (int a = 0; a < m; a++) off_lu[a] = GL::R_ZERO;
@@ -348,7 +370,6 @@ template <class T, class Sys> struct GroupWorker {
       va[0] += Rn[off_l0];
       va[1] += Rn[off_l1];
     }
-    T* const T1c = S + oT1c;
     const int gcol = g < GL::KW ? g : GL::KW - 1;  // lanes past the gain row write its padding word
     // The record of a step (uniform and per-lane words) is loaded one step ahead, behind the gain
     // exchange of the previous step: its LDS latency hides under that step's value update.
@@ -382,7 +403,7 @@ template <class T, class Sys> struct GroupWorker {
         t1[a] = acc;
       });
 #pragma unroll
-      for (int a = 0; a < W; a++) T1c[g * W + a] = t1[a];
+      for (int a = 0; a < W; a++) T1c[t1_word(g, a)] = t1[a];
       wave_sync();
       STAMP_END(1);
       // P2: column g of H = L + T1[:, :n] F (lanes < n), g = l + T1[:, n] (lane n)
@@ -391,9 +412,9 @@ template <class T, class Sys> struct GroupWorker {
         T s0[W], s1[W], sr[W];
 #pragma unroll
         for (int a = 0; a < W; a++) {
-          s0[a] = T1c[0 * W + a];
-          s1[a] = T1c[1 * W + a];
-          sr[a] = T1c[rsrc * W + a];
+          s0[a] = T1c[t1_word(0, a)];
+          s1[a] = T1c[t1_word(1, a)];
+          sr[a] = T1c[t1_word(rsrc, a)];
         }
 #pragma unroll
         for (int a = 0; a < W; a++) {
@@ -419,7 +440,7 @@ template <class T, class Sys> struct GroupWorker {
           bool first = true;
           static_for_i<0, n>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            if constexpr (Sys::pat(i, n + b) != 0) f_acc<i, n + b>(acc, first, T1c[i * W + n + a], jv);
+            if constexpr (Sys::pat(i, n + b) != 0) f_acc<i, n + b>(acc, first, T1c[t1_word(i, n + a)], jv);
           });
           Quu[a * m + b] = (a == b ? luu[a] : T(0)) + acc;
         });
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
       const int aa = e / N, t = e - aa * N;
       S[L.XU0 + t * W + n + aa] = gU[e];
     }
-    for (int e = lane; e < n * n; e += 64) smem[kGroupsPerWave * L.total + e] = c.Qt[e];
+    for (int e = lane; e < n * n; e += 64) smem[L.qt_base() + e] = c.Qt[e];
   }
   T xT[n], ob[6];
 #pragma unroll
@@ -714,7 +735,7 @@ template <class Sys, int V> struct GSpecLayout {
     var0 = o;
     Kk_in_var = 0;
     T1c_in_var = (m * GL::KW * N + 3) & ~3;
-    var_words = (T1c_in_var + kGroup * W + 3) & ~3;
+    var_words = (T1c_in_var + kGroup * 2 * ((W + 1) / 2) + 3) & ~3;  // [row pair][column][2]
     o += V * var_words;
     if (((o / 4) & 1) == 0) o += 4;
     total = o;
@@ -725,7 +746,11 @@ template <class Sys, int V> struct GSpecLayout {
   __host__ __device__ int group_words() const { return kGroupsPerWave * total + n * n + (V + 1) * kGroupsPerWave; }
 };
 
-template <class T, class Sys, int V>
+// SETIO: the problems are the first *a.count columns of a batch-minor, time-major work set (the
+// tail of the chunked solve of the one-problem-per-lane layouts, see IterArgs and k_iterate): the
+// launch does nothing unless *count <= count_max, the iteration counters continue from iters[] and
+// stop at max_total.
+template <class T, class Sys, int V, bool SETIO = false>
 __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, Sys::m> c,
                                                        const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
@@ -736,8 +761,14 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = lane / kGroup, g = lane % kGroup;
   const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + p;
-  const bool real = prob0 < a.B;
-  const int64_t prob = real ? prob0 : a.B - 1;
+  int64_t live = a.B;
+  if constexpr (SETIO) {
+    live = *a.count;
+    if (live > a.count_max || (int64_t)blockIdx.x * kGroupsPerWave >= live) return;  // block-uniform
+  }
+  const int64_t Bs = SETIO ? a.set_stride : 0;
+  const bool real = prob0 < live;
+  const int64_t prob = real ? prob0 : live - 1;
   const SL SLay(c.N);
   const int N = c.N;
   T* const S = smem + p * SLay.total;
@@ -746,25 +777,36 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   GroupWorker<T, Sys> w(c, S, QtL, g);
   w.oR = SLay.R;
   w.oKk = SLay.var0 + v * SLay.var_words + SLay.Kk_in_var;
-  w.oT1c = SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;
+  w.T1c = S + SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;
 
   // entry (wavefront 0): x0, U into buffer 0, Q_terminal; nominal rollout
   if (v == 0) {
-    const T* gX = a.X + prob * (int64_t)(n * (N + 1));
-    if (g < n) S[SLay.xu_off(0) + g] = gX[g * (N + 1)];
-    const T* gU = a.U + prob * (int64_t)(m * N);
-    for (int e = g; e < m * N; e += kGroup) {
-      const int aa = e / N, t = e - aa * N;
-      S[SLay.xu_off(0) + t * W + n + aa] = gU[e];
+    if constexpr (SETIO) {  // work-set rows: x_t[i] is row t n + i of X, u_t[a] row t m + a of U
+      if (g < n) S[SLay.xu_off(0) + g] = a.X[g * Bs + prob];
+      for (int e = g; e < m * N; e += kGroup) {
+        const int t = e / m, aa = e - t * m;
+        S[SLay.xu_off(0) + t * W + n + aa] = a.U[e * Bs + prob];
+      }
+    } else {
+      const T* gX = a.X + prob * (int64_t)(n * (N + 1));
+      if (g < n) S[SLay.xu_off(0) + g] = gX[g * (N + 1)];
+      const T* gU = a.U + prob * (int64_t)(m * N);
+      for (int e = g; e < m * N; e += kGroup) {
+        const int aa = e / N, t = e - aa * N;
+        S[SLay.xu_off(0) + t * W + n + aa] = gU[e];
+      }
     }
     for (int e = lane; e < n * n; e += 64) QtL[e] = c.Qt[e];
   }
   T xT[n], ob[6];
 #pragma unroll
-  for (int i = 0; i < n; i++) xT[i] = a.x_term[prob * n + i];
+  for (int i = 0; i < n; i++) xT[i] = SETIO ? a.x_term[i * Bs + prob] : a.x_term[prob * n + i];
 #pragma unroll
-  for (int q = 0; q < 6; q++) ob[q] = a.obs ? a.obs[prob * 6 + q] : T(q == 5 ? -1 : 1);
+  for (int q = 0; q < 6; q++)
+    ob[q] = a.obs ? (SETIO ? a.obs[q * Bs + prob] : a.obs[prob * 6 + q]) : T(q == 5 ? -1 : 1);
   T lamb = a.lamb[prob];
+  const int it0 = SETIO ? a.iters[prob] : 0;              // iterations of the earlier chunks
+  const int it_cap = SETIO ? a.max_total - it0 : a.n_iters;
   const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
   __syncthreads();
   if (v == 0) {
@@ -780,7 +822,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   for (int k = 0; k < V; k++) cb[k] = k + 1;
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/, gsel = 0;
   T cost_ret = cost;
-  bool fresh = true, active = a.n_iters > 0;
+  bool fresh = true, active = it_cap > 0;
   while (__any(active)) {
     if (__any(fresh)) {
       w.prep(SLay.xu_off(nb), SLay.tr_off(nb), ob, ob_pa, ob_pb, v * kGroup + g, V * kGroup);
@@ -829,7 +871,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
             if (status == 0) status = 3;
           }
         }
-        if (it >= a.n_iters) { active = false; chain = false; }
+        if (it >= it_cap) { active = false; chain = false; }
       }
     }
     __syncthreads();  // every wavefront has read the costs before the next round overwrites them
@@ -837,7 +879,33 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   if (!t_isfinite(cost_ret)) status = 4;
 
   // exit (wavefront 0): X, U from the nominal buffer, the gains of the last executed iteration
-  if (real && v == 0) {
+  if (real && v == 0 && SETIO) {
+    const int XUo = SLay.xu_off(nb);
+    for (int e = g; e < n * (N + 1); e += kGroup) {
+      const int t = e / n, i = e - t * n;
+      a.X[e * Bs + prob] = S[XUo + t * W + i];
+    }
+    for (int e = g; e < m * N; e += kGroup) {
+      const int t = e / m, aa = e - t * m;
+      a.U[e * Bs + prob] = S[XUo + t * W + n + aa];
+    }
+    if (a.K) {  // K rows (t m + a) n + j, k rows t m + a
+      const int oK = SLay.var0 + gsel * SLay.var_words + SLay.Kk_in_var;
+      for (int e = g; e < m * N * (n + 1); e += kGroup) {
+        const int r = e / (n + 1), j = e - r * (n + 1);
+        const T val = S[oK + r * GL::KW + j];
+        if (j < n) a.K[((int64_t)r * n + j) * Bs + prob] = val;
+        else a.k[(int64_t)r * Bs + prob] = val;
+      }
+    }
+    if (g == 0) {
+      a.lamb[prob] = lamb;
+      a.cost[prob] = cost_ret;
+      if (a.iters) a.iters[prob] = it0 + it;
+      if (a.status) a.status[prob] = status;
+    }
+  }
+  if (real && v == 0 && !SETIO) {
     const int XUo = SLay.xu_off(nb);
     T* gX = a.X + prob * (int64_t)(n * (N + 1));
     for (int e = g; e < n * (N + 1); e += kGroup) {

@@ -149,13 +149,17 @@ class BatchedILQR:
     def set_option(self, name: str, value: int) -> None:
         """Scheduling options (i2lqr_set_option in include/i2lqr.h); -1 restores the automatic
         choice.  Lane layouts: "defer_states", "reroll_nominal", "lds_gain_steps", "wave_tail";
-        problem-major layout: "group_lanes" (8 / 64), "per_step_jacobians".  All but "wave_tail" leave the
-        results bit-identical."""
+        problem-major layout: "group_lanes" (8 / 16 / 64), "speculate", "per_step_jacobians".  All
+        but "wave_tail" and "group_lanes" leave the results bit-identical."""
         self._check(self.lib.i2lqr_set_option(self._handle, name.encode(), int(value)))
 
     def iterate_kernel(self, B: int) -> str:
-        """Name of the kernel iterate() / solve() launch for B problems (rocprofv3 traces)."""
+        """Name of the kernel iterate() launches for B problems (rocprofv3 traces)."""
         return self.lib.i2lqr_iterate_kernel(self._handle, int(B)).decode()
+
+    def solve_kernel(self, B: int) -> str:
+        """Name of the (dominant) kernel solve() launches for B problems."""
+        return self.lib.i2lqr_solve_kernel(self._handle, int(B)).decode()
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=self.dtype if dtype is None else dtype,

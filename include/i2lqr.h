@@ -206,10 +206,15 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     in order and everything behind the first accept is discarded.  Same
  *                     iterations, same order, same arithmetic: bit-identical results; a run of r
  *                     rejects and one accept costs one round instead of r + 1.  Uses SIMDs a small
- *                     batch leaves idle, but the eight problems of a wavefront advance in
- *                     lockstep rounds: on the benchmark workload it measures slower than the
- *                     plain kernel (0.275 vs 0.215 ms per 10 iterations at 1024 problems).
- *                     Opt-in; automatic: 0.
+ *                     batch leaves idle.  A launch lasts as long as its slowest problem, and the
+ *                     slowest problems of a solve to termination alternate accepts and rejects:
+ *                     i2lqr_solve of 1024 problems 1.20 -> 0.77 ms.  With a FIXED iteration count
+ *                     nothing is gained as soon as one problem of the batch never rejects (0.275
+ *                     vs 0.215 ms per 10 iterations at 1024 problems).  Automatic: on for
+ *                     early-exit calls (i2lqr_solve, i2lqr_iterate with early_exit) of at most
+ *                     2048 problems where built, and for the <= "wave_tail" survivors of the
+ *                     chunked solves of the lane layouts; off for fixed iteration counts.
+ *                     0: never; 1: always (I2LQR_ERR_UNSUPPORTED where not built).
  *   "per_step_jacobians"  ("group_lanes" 64)  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
  *                     30-52) are written to LDS by the parallel per-step phase, so the serial
  *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.
@@ -218,10 +223,14 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  */
 int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 
-/* Name of the kernel i2lqr_iterate / i2lqr_solve launch for a batch of B problems with the handle's
- * current options ("k_iterate", "k_group_iterate", "k_lane_iterate"): what to look for in a
- * rocprofv3 kernel trace.  Host only; "" for a NULL handle. */
+/* Name of the kernel i2lqr_iterate (fixed iteration count) launches for a batch of B problems
+ * with the handle's current options ("k_iterate", "k_group_iterate", "k_group_spec",
+ * "k_quad_iterate", "k_lane_iterate"): what to look for in a rocprofv3 kernel trace.  Host only;
+ * "" for a NULL handle. */
 const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B);
+/* The same for i2lqr_solve / early-exit calls (the dominant kernel; the chunked solves of the lane
+ * layouts also launch k_lane_compact and a tail kernel). */
+const char* i2lqr_solve_kernel(const i2lqr_handle* h, int64_t B);
 
 /*
  * Nominal rollout + cost — replaces control/iterative_ilqr.py:32-48.
