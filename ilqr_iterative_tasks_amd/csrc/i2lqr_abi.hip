@@ -302,8 +302,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // of wavefronts per CU (one per SIMD, four per CU) resident in the 160 KiB: 36 KiB each, i.e.
     // 5 steps in fp64 and 10 in fp32 at n=6, m=2.
     const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-    a.lds_steps = (36 * 1024) / per_step;
-    if (a.lds_steps > N) a.lds_steps = N;
+    a.lds_steps = (36 * 1024 - kK0Bytes) / per_step;  // steps 1..lds_steps; k_0 sits behind them
+    if (a.lds_steps > N - 1) a.lds_steps = N - 1;
     a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
     a.defer = 1;  // the forward pass stores no states; accepted steps re-roll them (see i2lqr_lane.hpp)
     // ... and merge the accepted candidate inputs into the one input buffer.  fp64 (HBM-bound):
@@ -345,6 +345,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   }
   // LDS of the state checkpointing: the states of one segment of kSeg steps for 64 lanes
   static constexpr int kSegBytes = (kSeg + 1) * n * 64 * (int)sizeof(T);
+  // k_0 of 64 lanes: step 0 keeps only its feed-forward term in LDS (LaneWorker::lds_k0)
+  static constexpr int kK0Bytes = 64 * m * (int)sizeof(T);
   // State checkpointing (i2lqr_lane.hpp): fp64 with deferred, merged states and the re-rolling
   // forward pass, Q = R = 0; automatic from 262144 problems (where the kernel sits on the HBM
   // roof).  Its segment buffer takes the place of LDS-resident gain steps.  Must be called again
@@ -359,14 +361,15 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= 262144);
     if (a.ckpt) {
       const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-      int steps = (36 * 1024 - kSegBytes) / per_step;
+      int steps = (37 * 1024 - kSegBytes - kK0Bytes) / per_step;
       if (steps < 0) steps = 0;
       if (a.lds_steps > steps) a.lds_steps = steps;
     }
   }
   template <bool TL>
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
-    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + (a.ckpt ? kSegBytes : 0);
+    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
+                       (a.ckpt ? kSegBytes : 0);
     if (c.flags)
       hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
     else

@@ -101,11 +101,15 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   const int N;
   const int64_t Bs_;    // row stride of the batch-minor layout (the tiled one is 64 at compile time)
   const unsigned lane;  // this lane's column inside the wavefront's re-based rows
-  // Gains of the first `lds_steps` horizon steps stay in LDS: the backward pass produces them
-  // last and the forward pass consumes them first, so they never need to travel through HBM
-  // (flushed once at kernel exit for the caller).  Word (t, q) of lane l sits at
-  // lds[(t * m (n+1) + q) * 64 + l]: consecutive lanes on consecutive words, conflict-free.
-  T* lds = nullptr;
+  // Gains of the first horizon steps stay in LDS: the backward pass produces them last and the
+  // forward pass consumes them first, so they never need to travel through HBM (flushed once at
+  // kernel exit for the caller).  Step 0 is special: x_0 is given, so the candidate starts ON the
+  // nominal and K_0 (x_0 - x_0) = 0 whatever K_0 is — the forward pass needs k_0 only (m words
+  // instead of m (n + 1)); K_0 is written to HBM by the backward passes that can be the launch's
+  // last (k0_out) and never read back.  Steps 1..lds_steps keep [K | k]: word (t, q) of lane l
+  // sits at lds[((t - 1) m (n+1) + q) * 64 + l], k_0[a] behind them: consecutive lanes on
+  // consecutive words, conflict-free.
+  T* lds = nullptr;  // null (the one-pass kernels): every gain goes through HBM
   int lds_steps = 0;
 #ifdef I2LQR_STAMPS
   mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
@@ -124,12 +128,17 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   static __device__ __forceinline__ int rx(int i, int t) { return t * n + i; }
   static __device__ __forceinline__ int ru(int a, int t) { return t * m + a; }
   static __device__ __forceinline__ int rK(int a, int j, int t) { return (t * m + a) * n + j; }
-  __device__ __forceinline__ T& lds_gain(int t, int q) const {
-    return lds[(t * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
+  __device__ __forceinline__ T& lds_gain(int t, int q) const {  // 1 <= t <= lds_steps
+    return lds[((t - 1) * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
   }
-  // write the LDS-resident gains of this lane to HBM (kernel exit)
+  __device__ __forceinline__ T& lds_k0(int a) const {
+    return lds[(lds_steps * (m * (n + 1)) + a) * 64 + (threadIdx.x & 63)];
+  }
+  // write the LDS-resident gains of this lane to HBM (kernel exit; K_0 is there already)
   __device__ __forceinline__ void flush_gains(T* gK, T* gk) const {
-    for (int t = 0; t < lds_steps && t < N; t++) {
+#pragma unroll
+    for (int a = 0; a < m; a++) at(gk, ru(a, 0)) = lds_k0(a);
+    for (int t = 1; t <= lds_steps && t < N; t++) {
 #pragma unroll
       for (int a = 0; a < m; a++) {
 #pragma unroll
@@ -408,7 +417,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // CK: checkpointed states (kSeg above); seg = (kSeg + 1) n 64 words of LDS for this wavefront.
   template <bool FASTBAR = false, bool CK = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
-                                           const T (&ob)[6], T lamb, T* gK, T* gk,
+                                           const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
                                            T* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
@@ -608,7 +617,16 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], G[bb][j], acc);
           Kk[a][j] = -acc;
         }
-      if (t < lds_steps) {
+      if (t == 0 && lds) {
+#pragma unroll
+        for (int a = 0; a < m; a++) lds_k0(a) = Kk[a][n];
+        if (k0_out) {
+#pragma unroll
+          for (int a = 0; a < m; a++)
+#pragma unroll
+            for (int j = 0; j < n; j++) at(gK, rK(a, j, 0)) = Kk[a][j];
+        }
+      } else if (t >= 1 && t <= lds_steps) {
 #pragma unroll
         for (int a = 0; a < m; a++)
 #pragma unroll
@@ -712,7 +730,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
 #pragma unroll
       for (int a = 0; a < m; a++) ul[a] = at(U, ru(a, t));
-      if (t < lds_steps) {
+      if (t == 0 && lds) {  // x_0 is common to the nominal and the candidate: K_0 multiplies zeros
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+#pragma unroll
+          for (int j = 0; j < n; j++) kl[a][j] = T(0);
+          kl[a][n] = lds_k0(a);
+        }
+      } else if (t >= 1 && t <= lds_steps) {
 #pragma unroll
         for (int a = 0; a < m; a++)
 #pragma unroll
@@ -849,13 +874,15 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
-  T* const seg = reinterpret_cast<T*>(lane_smem) + (size_t)a.lds_steps * 64 * m * (n + 1);
+  T* const seg = reinterpret_cast<T*>(lane_smem) + (size_t)a.lds_steps * 64 * m * (n + 1) + 64 * m;
   while (it < a.n_iters && it0 + it < a.max_total) {
+    // K_0 goes to HBM from the passes that can be this launch's last one for the problem
+    const bool k0_out = a.early_exit || it + 1 >= a.n_iters || it0 + it + 1 >= a.max_total;
     if constexpr (kCanCkpt) {
-      if (ckpt) w.template backward<true, true>(X, Uc, xT, ob, lamb, gK, gk, seg);
-      else w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
+      if (ckpt) w.template backward<true, true>(X, Uc, xT, ob, lamb, gK, gk, k0_out, seg);
+      else w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk, k0_out);
     } else {
-      w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk);
+      w.template backward<true>(X, Uc, xT, ob, lamb, gK, gk, k0_out);
     }
 #ifdef I2LQR_STAMPS
     {
@@ -1071,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_lane_backward(const DevCfg<T, Sys::n, Sy
 #pragma unroll
   for (int q = 0; q < 6; q++) ob[q] = gob ? gob[(int64_t)q * v.Bs + v.bl] : T(q == 5 ? -1 : 1);
   w.backward(v.rebase(X, n * (N + 1)), v.rebase(U, m * N), xT, ob, lamb[b],
-             v.rebase(K, m * n * N), v.rebase(k, m * N));
+             v.rebase(K, m * n * N), v.rebase(k, m * N), true);  // no LDS: every gain to HBM
 }
 
 template <class T, class Sys, bool HASQR, bool TILED>

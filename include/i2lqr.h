@@ -179,12 +179,15 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     replaces two LDS-resident gain steps.  Automatic: 1 from 262144 problems.
  *   "reroll_nominal"  1: the forward pass re-rolls the nominal states it needs for the feedback
  *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
- *   "lds_gain_steps"  upper bound on the horizon steps whose gains stay in LDS between the
- *                     backward and the forward pass (automatic: what fits next to four
- *                     wavefronts per CU).
+ *   "lds_gain_steps"  upper bound on the horizon steps 1, 2, ... whose gains stay in LDS between
+ *                     the backward and the forward pass (automatic: what fits next to four
+ *                     wavefronts per CU: 5 in fp64, 10 in fp32 at n = 6, m = 2).  Step 0 always
+ *                     stays: the forward pass needs only its k_0 (x_0 is common to the nominal
+ *                     and the candidate trajectory, K_0 multiplies zeros).
  *   "wave_tail"       chunked solve (i2lqr_set_compaction) only: once a compaction leaves at most
- *                     this many running problems (<= 8192), they are finished by the one-problem-
- *                     per-wavefront kernel, whose iteration latency is ~2.8x lower.  Same
+ *                     this many running problems (<= 8192), they are finished by the speculative
+ *                     eight-lane kernel ("speculate"; the one-problem-per-wavefront kernel where
+ *                     that is not built), whose iteration latency is ~2.8x lower.  Same
  *                     algorithm, different summation order: results agree with the single launch
  *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
  *                     settle an accept / reject tie the other way and stop at a different
