@@ -47,6 +47,15 @@ echo "$WORKLOADS" | while read name wl dt b lay it ln; do
     > "$RAW/${name}_SQINS.log" 2>&1
   echo "collected $name"
 done
+# solves to termination (kernel traces only): the speculative eight-lane kernel at 1024 problems,
+# lane chunks + compaction + speculative tail at 65536
+for spec in "1024 wave" "65536 tiled"; do
+  set -- $spec
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/solve_B$1_kstats" -- \
+    python3 $ROOT/tools/pmc_target.py --workload config2 --dtype f64 --batch $1 --layout $2 --launches 10 --solve \
+    > "$RAW/solve_B$1_kstats.log" 2>&1
+  find "$RAW/solve_B$1_kstats" -name "*kernel_stats.csv" -exec cp {} "$NEW/${TAG}_kstats_solve_f64_B$1.csv" \;
+done
 cd "$ROOT"
 python3 tools/summarise_profiles.py "$RAW" "$NEW" "$TAG" > "$NEW/summarise.log" 2>&1
 cp "$NEW/pmc_traffic.json" "$ROOT/profiles/pmc_traffic.json"   # bench.py reads it from profiles/

@@ -18,6 +18,8 @@ ap.add_argument("--layout", default="wave")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--options", default="", help="i2lqr_set_option settings: 'name=value name=value'")
+ap.add_argument("--solve", action="store_true", help="i2lqr_solve (to termination) instead of "
+                "a fixed iteration count")
 args = ap.parse_args()
 cfg = workloads.config_for(args.workload, args.dtype)
 cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[args.layout]
@@ -36,6 +38,9 @@ for _ in range(args.launches):
     bufs.append(buf)
 torch.cuda.synchronize()
 for buf in bufs:
-    solver.iterate(buf, args.iters)
+    if args.solve:
+        solver.solve(buf)
+    else:
+        solver.iterate(buf, args.iters)
 torch.cuda.synchronize()
 print("done", args)

@@ -54,8 +54,8 @@ out = {"_meta": {"lib_sha256": hashlib.sha256(LIB.read_bytes()).hexdigest(),
 full = {"_meta": out["_meta"]}
 for d in sorted(glob.glob(f"{raw}/*_kstats")):
     name = Path(d).name[: -len("_kstats")]
-    if name == "bench":
-        continue
+    if name == "bench" or name.startswith("solve"):
+        continue  # kernel traces only
     wl, dt, bb = name.split("_")
     B = int(bb[1:])
     iters = 4 if wl == "config5" else 10
