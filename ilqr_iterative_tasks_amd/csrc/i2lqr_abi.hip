@@ -73,7 +73,7 @@ template <class T, class Sys> struct Launch {
   }
   static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
   static constexpr int64_t kAutoGroupBatch = 1024;
-  static constexpr int64_t kAutoSpecBatch = 2048;
+  static constexpr int64_t kAutoSpecBatch = 8192;
   static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
@@ -150,7 +150,8 @@ template <class T, class Sys> struct Launch {
                     "horizon whose speculative buffers fit the 160 KiB of LDS");
       // Automatic for solves to termination (early_exit) of at most kAutoSpecBatch problems: the
       // launch lasts as long as its slowest problem, and the slowest problems alternate accepts and
-      // rejects — 1.20 -> 0.77 ms at 1024 problems, 0.78 -> 0.68 ms at 2048, even at 4096.
+      // rejects — i2lqr_solve 0.60 -> 0.44 ms at 16 problems, 1.21 -> 0.71 ms at 1024, 0.78 -> 0.51
+      // at 2048, 1.03 -> 0.85 at 4096, 1.23 -> 1.17 at 8192.
       const bool spec = can_spec && h->opt_group != 64 &&
                         (h->opt_spec == 1 ||
                          (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch));
@@ -951,7 +952,7 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
   const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
   const bool can = m2 && group_supported(h->cfg);
   if (can && group_spec_supported(h->cfg) && h->opt_group != 64 &&
-      (h->opt_spec == 1 || (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= 2048)))
+      (h->opt_spec == 1 || (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= 8192)))
     return "k_group_spec";
   if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
   if ((h->opt_group == 16 || h->opt_group < 0) && quad_supported(h->cfg) && h->ws &&

@@ -40,21 +40,26 @@ hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) 
   return hipGetLastError();
 }
 
-constexpr int kSpecV = 3;  // wavefronts per group of eight problems in the speculative kernel
+// Wavefronts per group of eight problems in the speculative kernel.  Three skip two rejects per
+// round but share one CU's LDS three ways; the stragglers that decide a solve's duration alternate
+// accept / reject, which two wavefronts cover: measured (i2lqr_solve, ms) 16 problems 0.43 (V = 3)
+// / 0.46 (V = 2), 256: 0.25 / 0.26, 1024: 0.77 / 0.72, 2048: 0.70 / 0.50, tail of 65536: 2.41 /
+// 2.34.  Three up to kSpecWideBatch problems where they fit, two above and in the tail.
+constexpr int kSpecWideBatch = 512;
 
-template <class T, class Sys> size_t spec_lds_bytes(int N) {
-  return (size_t)GSpecLayout<Sys, kSpecV>(N).group_words() * sizeof(T);
+template <class T, class Sys, int V> size_t spec_lds_bytes(int N) {
+  return (size_t)GSpecLayout<Sys, V>(N).group_words() * sizeof(T);
 }
 
 // SETIO: a.count_max problems at most (k_group_spec<.., true>, the tail of the chunked solves)
-template <class T, class Sys, bool SETIO>
-hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+template <class T, class Sys, int V, bool SETIO>
+hipError_t launch_spec_v(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
-  const size_t lds = spec_lds_bytes<T, Sys>(cfg.N);
+  const size_t lds = spec_lds_bytes<T, Sys, V>(cfg.N);
   if (lds > 64 * 1024) {
     static thread_local int raised_for = 0;
     if (raised_for < (int)lds) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, kSpecV, SETIO>,
+      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, V, SETIO>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       raised_for = (int)lds;
@@ -62,16 +67,28 @@ hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_
   }
   const int64_t problems = SETIO ? (int64_t)a.count_max : a.B;
   const unsigned grid = (unsigned)((problems + kGroupsPerWave - 1) / kGroupsPerWave);
-  hipLaunchKernelGGL((k_group_spec<T, Sys, kSpecV, SETIO>), dim3(grid), dim3(64 * kSpecV), lds, s,
-                     c, a);
+  hipLaunchKernelGGL((k_group_spec<T, Sys, V, SETIO>), dim3(grid), dim3(64 * V), lds, s, c, a);
   return hipGetLastError();
+}
+template <class T, class Sys, bool SETIO>
+hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  const bool wide = !SETIO && a.B <= kSpecWideBatch &&
+                    spec_lds_bytes<T, Sys, 3>(cfg.N) <= 160 * 1024;
+  if (wide) return launch_spec_v<T, Sys, 3, SETIO>(cfg, a, s);
+  return launch_spec_v<T, Sys, 2, SETIO>(cfg, a, s);
+}
+
+bool spec_lds_fits(const i2lqr_config& cfg) {  // the two-wavefront form
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>, 2>(cfg.N)
+                                             : spec_lds_bytes<double, Bicycle6<double>, 2>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>, 2>(cfg.N)
+                                             : spec_lds_bytes<float, Bicycle6<float>, 2>(cfg.N));
+  return lds <= 160 * 1024;
 }
 
 }  // namespace
 
-namespace {
-bool spec_lds_fits(const i2lqr_config& cfg);
-}
 bool group_spec_supported(const i2lqr_config& cfg) {
   return group_supported(cfg) && spec_lds_fits(cfg);
 }
@@ -79,16 +96,6 @@ bool group_spec_tail_supported(const i2lqr_config& cfg) {
   if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
   return !has_stage_weights(cfg) && spec_lds_fits(cfg);
 }
-namespace {
-bool spec_lds_fits(const i2lqr_config& cfg) {
-  const size_t lds = cfg.dtype == I2LQR_F64
-      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>>(cfg.N)
-                                             : spec_lds_bytes<double, Bicycle6<double>>(cfg.N))
-      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>>(cfg.N)
-                                             : spec_lds_bytes<float, Bicycle6<float>>(cfg.N));
-  return lds <= 160 * 1024;
-}
-}  // namespace
 
 template <> hipError_t group_spec_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
                                                   hipStream_t s) {

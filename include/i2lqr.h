@@ -203,7 +203,8 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     The two agree to round-off (1e-10 on one backward pass), not bit for bit:
  *                     K^T Quu K is associated differently.
  *   "speculate"       ("group_lanes" 8 / automatic) 1: the speculative form of the eight-lane
- *                     kernel — three wavefronts per eight problems, wavefront v runs the iteration
+ *                     kernel — V wavefronts per eight problems (three up to 512 problems, two
+ *                     above and in the tail of the chunked solves), wavefront v runs the iteration
  *                     that follows v rejects (same nominal trajectory, lamb * 10^v:
  *                     control/iterative_ilqr.py:81-82); after each round the outcomes are resolved
  *                     in order and everything behind the first accept is discarded.  Same
@@ -211,11 +212,11 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     rejects and one accept costs one round instead of r + 1.  Uses SIMDs a small
  *                     batch leaves idle.  A launch lasts as long as its slowest problem, and the
  *                     slowest problems of a solve to termination alternate accepts and rejects:
- *                     i2lqr_solve of 1024 problems 1.20 -> 0.77 ms.  With a FIXED iteration count
+ *                     i2lqr_solve of 1024 problems 1.21 -> 0.71 ms.  With a FIXED iteration count
  *                     nothing is gained as soon as one problem of the batch never rejects (0.275
  *                     vs 0.215 ms per 10 iterations at 1024 problems).  Automatic: on for
  *                     early-exit calls (i2lqr_solve, i2lqr_iterate with early_exit) of at most
- *                     2048 problems where built, and for the <= "wave_tail" survivors of the
+ *                     8192 problems where built, and for the <= "wave_tail" survivors of the
  *                     chunked solves of the lane layouts; off for fixed iteration counts.
  *                     0: never; 1: always (I2LQR_ERR_UNSUPPORTED where not built).
  *   "per_step_jacobians"  ("group_lanes" 64)  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:
