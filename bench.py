@@ -160,7 +160,8 @@ def make_step_buffers(solver, host, n_sets, torch):
     return sets
 
 
-def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True):
+def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True,
+            event_stride=1):
     """Time `steps` steps; returns dict(seconds, kernel_ms, iterations, ...)."""
     import torch.distributed as dist
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
@@ -207,7 +208,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
 
     def step(i_set, i_timed=None):
         buf, cost_it = sets[i_set], cost_its[i_set]
-        bracket = i_timed is not None and i_timed % EVENT_STRIDE == 0
+        bracket = i_timed is not None and i_timed % event_stride == 0
         if bracket:
             ev0[i_timed].record()
         solver.iterate(buf, args.iters)
@@ -253,7 +254,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         dist.all_gather(allt, t)
         rank_seconds = [float(x.item()) for x in allt]
         seconds = max(rank_seconds)
-    timed = range(0, steps, EVENT_STRIDE)
+    timed = range(0, steps, event_stride)
     kern_ms = sum(ev0[i].elapsed_time(ev1[i]) for i in timed) / len(timed)
     # every problem executes exactly `iters` iterations (no early exit): check on the last set
     assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
@@ -493,7 +494,8 @@ def run_rank(args) -> int:
     dtype = "f64" if cfg.dtype == 0 else "f32"
     pmc = PmcFile()
 
-    res = run_gpu(args, cfg, B, rank, world, torch, dist_mod, args.steps, args.warmup)
+    res = run_gpu(args, cfg, B, rank, world, torch, dist_mod, args.steps, args.warmup,
+                  event_stride=EVENT_STRIDE)
     value = res["iterations"] / res["seconds"]
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
