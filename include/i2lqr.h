@@ -140,10 +140,10 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
- * problems the solve runs in chunks of 4, 4, 4, 4, 8, 8, 16, ... iterations and packs the
+ * problems the solve runs in chunks of 8, 4, 4, 8, 8, 16, ... iterations and packs the
  * still-running problems into dense work sets between chunks (no host synchronisation); once few
- * problems are left ("wave_tail" option below) they are finished by the one-problem-per-wavefront
- * kernel.
+ * problems are left ("wave_tail" option below) they are finished by the speculative eight-lane
+ * kernel (the one-problem-per-wavefront kernel where that is not built).
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
  * large solve is bound by the slowest problem's iteration latency.
  *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
@@ -191,7 +191,8 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     algorithm, different summation order: results agree with the single launch
  *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
  *                     settle an accept / reject tie the other way and stop at a different
- *                     iteration).  0: off; automatic: 2048.
+ *                     iteration).  0: off; automatic: 8192 with the speculative kernel, 2048 with
+ *                     the one-problem-per-wavefront kernel.
  * Problem-major layout, i2lqr_iterate / i2lqr_solve:
  *   "group_lanes"     lanes of a wavefront that work on one problem: 64 (one problem per
  *                     wavefront, each lane one element of the Riccati step's products), 8 (eight
