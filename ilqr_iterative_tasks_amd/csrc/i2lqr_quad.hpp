@@ -249,12 +249,15 @@ template <class T, class Sys> struct QuadWorker {
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = S[L.XU + i];
     T* XC = Wp + XCo;
+    // the three angles on three lanes, as in the forward pass (same values as Sys::trig)
+    auto bc = [](auto lane_, T v) { return row_bcast<decltype(lane_)::value>(v); };
+    bool unused = false;
     for (int t = 0; t < N; t++) {
 #pragma unroll
       for (int a = 0; a < m; a++) u[a] = clip(S[L.XU + t * W + n + a], -c.u_max[a], c.u_max[a]);
 #pragma unroll
       for (int a = 0; a < m; a++) S[L.XU + t * W + n + a] = u[a];
-      Sys::trig(x, tr);
+      Sys::template trig_row<true>(x, tr, &unused, g, bc);
       if (g == 0) {
 #pragma unroll
         for (int q = 0; q < NT; q++) XC[t * QL::XCW + n + q] = tr[q];
@@ -265,7 +268,7 @@ template <class T, class Sys> struct QuadWorker {
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
     }
-    Sys::trig(x, tr);
+    Sys::template trig_row<true>(x, tr, &unused, g, bc);
     if (g == 0) {
 #pragma unroll
       for (int q = 0; q < NT; q++) XC[N * QL::XCW + n + q] = tr[q];
