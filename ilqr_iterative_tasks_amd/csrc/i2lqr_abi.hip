@@ -57,7 +57,7 @@ struct i2lqr_handle {
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
-  int opt_spec;   // eight-lane kernel: speculative form (three wavefronts per eight problems); -1 = automatic
+  int opt_spec;   // eight-lane kernel: speculative form (2-3 wavefronts per eight problems); -1 = automatic
 };
 
 namespace {
@@ -138,12 +138,12 @@ template <class T, class Sys> struct Launch {
       if (h->opt_group == 8 && !can)
         return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 "
                     "and a horizon whose eight problem slices fit the 160 KiB of LDS");
-      // Speculative form (k_group_spec; opt-in): three wavefronts per eight problems run the
-      // iterations that follow 0, 1, 2 rejects at once; bit-identical results.  Measured SLOWER
-      // than the plain kernels on the benchmark workload (0.275 vs 0.215 ms per 10 iterations at
-      // 1024 problems): the eight problems of a wavefront advance in lockstep rounds, so a round
-      // saves time only if ALL eight have a reject to skip, and three wavefronts per CU contend
-      // for LDS.  Kept as an option for workloads dominated by long reject chains.
+      // Speculative form (k_group_spec): two or three wavefronts per eight problems run the
+      // iterations that follow 0, 1, (2) rejects at once; bit-identical results.  With a FIXED
+      // iteration count it measures slower than the plain kernel (0.275 vs 0.215 ms per 10
+      // iterations at 1024 problems: the launch lasts until the one problem that never rejects is
+      // done, and the wavefronts of a workgroup contend for the CU's LDS), so it stays opt-in
+      // there.
       const bool can_spec = can && group_spec_supported(h->cfg);
       if (h->opt_spec == 1 && !can_spec)
         return fail(I2LQR_ERR_UNSUPPORTED, "\"speculate\" = 1 needs the eight-lane kernel and a "
@@ -493,7 +493,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static int iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
                      const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
                      int32_t* iters, int32_t* status, hipStream_t s) {
-    // automatic: chunked solve with the wave-kernel tail from 4096 problems and more than 16
+    // automatic: chunked solve with the speculative tail from 4096 problems and more than 16
     // iterations allowed (measured 1.2-1.9x on the bench workload from 4096 to 262144 problems;
     // the chunks alone cost ~9 % when nothing terminates early)
     const int64_t cmin = h->compact_min_batch < 0 ? (h->cfg.max_iter > 16 ? kAutoCompactBatch : 0)

@@ -700,7 +700,8 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
 }
 
 // ---------------------------------------------------------------------------------------------
-// Speculative form for small batches (<= 2048 problems: at most one workgroup per CU).
+// Speculative form: solves to termination of small batches (one workgroup of V wavefronts per
+// eight problems and per CU) and the tail of the chunked solves (SETIO).
 //
 // An iLQR iteration ends in accept (new nominal, lamb / 10) or reject (same nominal, lamb * 10):
 // control/iterative_ilqr.py:74-84.  After a reject the next iteration runs the backward and forward
@@ -713,8 +714,9 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
 // iterations a problem executes, their order and their arithmetic are exactly those of the
 // sequential kernel — results are bit-identical — but a run of r rejects followed by one accept costs one
 // round instead of r + 1.  Rejects are frequent (the lamb schedule probes until a step is
-// accepted, and converged problems reject until lamb overflows): ~1.8 iterations per round at
-// V = 3 on the benchmark workload.
+// accepted, converged problems reject until lamb overflows, and the stragglers that decide how
+// long a solve lasts alternate accept / reject): ~1.8 iterations per round at V = 3 on the
+// benchmark workload, 1.7 at V = 2.
 //
 // LDS per problem: V + 1 trajectory buffers (nominal + one candidate per wavefront; a per-problem
 // table says which is which, an accepted candidate becomes the nominal by swapping two table

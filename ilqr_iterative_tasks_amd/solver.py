@@ -138,8 +138,9 @@ class BatchedILQR:
         """Threshold of the chunked, compacting form of solve() on the lane layouts
         (i2lqr_set_compaction in include/i2lqr.h): min_batch > 0 explicit, 0 never (single launch),
         < 0 automatic — the handle's default: chunked from 4096 problems when max_iter > 16, with
-        the last <= 2048 survivors finished by the one-problem-per-wavefront kernel ("wave_tail").
-        The chunks alone are bit-identical to the single launch; with the wave tail the outputs
+        the last <= 8192 survivors finished by the speculative eight-lane kernel ("wave_tail"; the
+        one-problem-per-wavefront kernel from 2048 survivors where that is not built).
+        The chunks alone are bit-identical to the single launch; with the tail the outputs
         agree to 1e-8 (fp64), not bit for bit: for bit-reproducibility against the single launch
         call set_compaction(0) or set_option("wave_tail", 0).  The chunked form always runs with
         in-place candidate states and stored nominal states ("defer_states" / "reroll_nominal"
