@@ -359,6 +359,12 @@ def issue_roofline(pmc, key, kernel_ms, waves):
     out = {"bound": "issue", "unit": "G wavefront-instructions/s", "peak": peak,
            "simds_occupied": simds, "achieved": None, "frac": None,
            "wave_instructions_per_launch": insts}
+    launched = pmc.get(key, "waves_per_launch")
+    if launched and launched > waves:
+        # k_group_iterate up to 2048 problems: two helper wavefronts per workgroup take a share of
+        # the per-step records and sleep at a barrier otherwise; the roofline is that of the SIMDs
+        # that carry the serial recursion (their instructions are in the count)
+        out["helper_wavefronts"] = int(launched - waves)
     if insts:
         out["achieved"] = insts / (kernel_ms * 1e-3) / 1e9
         out["frac"] = out["achieved"] / peak

@@ -22,22 +22,32 @@ bool has_stage_weights(const i2lqr_config& cfg) {
   return false;
 }
 
-template <class T, class Sys>
-hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+template <class T, class Sys, int H>
+hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
   const size_t lds = group_lds_bytes<T, Sys>(cfg.N);
   if (lds > 64 * 1024) {
     static thread_local int raised_for = 0;  // the attribute is per kernel: raise it once per size
     if (raised_for < (int)lds) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_group_iterate<T, Sys>,
+      hipError_t e = hipFuncSetAttribute((const void*)k_group_iterate<T, Sys, H>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       raised_for = (int)lds;
     }
   }
   const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
-  hipLaunchKernelGGL((k_group_iterate<T, Sys>), dim3(grid), dim3(64), lds, s, c, a);
+  hipLaunchKernelGGL((k_group_iterate<T, Sys, H>), dim3(grid), dim3(64 * H), lds, s, c, a);
   return hipGetLastError();
+}
+// Two helper wavefronts for the record phase (k_group_iterate<.., 3>) while every workgroup has
+// a CU to itself (<= 256 workgroups = 2048 problems): 0.2216 -> 0.2107 ms per 10 iterations at
+// 1024 problems (two / four wavefronts: 0.2122 / 0.2102).  With two workgroups per CU the extra
+// wavefronts crowd the main ones off their SIMDs: 0.25 -> 0.40 ms at 4096 problems.
+template <class T, class Sys>
+hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  constexpr int64_t kCUs = 256;
+  if ((a.B + kGroupsPerWave - 1) / kGroupsPerWave <= kCUs) return launch_h<T, Sys, 3>(cfg, a, s);
+  return launch_h<T, Sys, 1>(cfg, a, s);
 }
 
 // Wavefronts per group of eight problems in the speculative kernel.  Three skip two rejects per

@@ -122,7 +122,10 @@ template <class Sys> struct GLayout {
   }
   __host__ __device__ int t1_base() const { return kGroupsPerWave * total; }
   __host__ __device__ int qt_base() const { return t1_base() + kGroupsPerWave * kT1Stride; }
-  __host__ __device__ int wave_words() const { return qt_base() + n * n; }
+  // control words of the helper wavefronts (k_group_iterate<.., H > 1>): int[8] nominal buffer of
+  // each problem, int flags
+  __host__ __device__ int ctl_base() const { return (qt_base() + n * n + 3) & ~3; }
+  __host__ __device__ int wave_words() const { return ctl_base() + 16; }
 };
 
 template <class T, class Sys> struct GroupWorker {
@@ -556,15 +559,20 @@ template <class T, class Sys> struct GroupWorker {
   }
 };
 
-// Grid: ceil(B / 8) workgroups of one wavefront; dynamic LDS = GLayout::wave_words() * sizeof(T).
-template <class T, class Sys>
-__global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sys::m> c,
-                                                      const IterArgs<T> a) {
+// Grid: ceil(B / 8) workgroups of H wavefronts; dynamic LDS = GLayout::wave_words() * sizeof(T).
+// H > 1: wavefronts 1..H-1 are helpers for the one phase of an iteration that is parallel over the
+// horizon — the per-step records (prep): 21 records of eight problems are three rounds for one
+// wavefront and one round for three.  They sleep at a workgroup barrier the rest of the time (a
+// batch of 1024 problems leaves seven of eight SIMDs idle anyway).  Same values whoever computes
+// a record: bit-identical to H = 1.
+template <class T, class Sys, int H = 1>
+__global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n, Sys::m> c,
+                                                          const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
   using GL = GLayout<Sys>;
   extern __shared__ __align__(16) unsigned char gsmem_raw[];
   T* smem = reinterpret_cast<T*>(gsmem_raw);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, hv = threadIdx.x >> 6;
   const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + lane / kGroup;
   // groups past the end of the batch work on a copy of the last problem and store nothing, so
   // that every lane of the wavefront runs the same control flow
@@ -596,6 +604,23 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
 
   int cur = 0;
   const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+  int* const ctl = reinterpret_cast<int*>(smem + L.ctl_base());
+  if constexpr (H > 1) {
+    if (hv > 0) {  // helper: its share of the records whenever the main wavefront asks for them
+      for (;;) {
+        __syncthreads();  // B1: the control words of this iteration are written
+        const int flags = ctl[8];
+        if (!(flags & 1)) break;
+        if (flags & 2) {
+          const int pc = ctl[lane / kGroup];
+          w.prep(pc ? L.XU1 : L.XU0, pc ? L.TR1 : L.TR0, ob, ob_pa, ob_pb, hv * kGroup + g,
+                 H * kGroup);
+        }
+        __syncthreads();  // B2: the records are complete
+      }
+      return;
+    }
+  }
   T cost = w.rollout(L.XU0, L.TR0, xT);
   int it = 0, status = a.early_exit ? 2 /*MAX_ITER*/ : 0 /*RUNNING*/;
   T cost_ret = cost;
@@ -614,7 +639,16 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
       STAMP_END(0);
     }
 #else
-    if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
+    if constexpr (H > 1) {
+      const bool do_prep = __any(fresh);
+      if (g == 0) ctl[lane / kGroup] = cur;
+      if (lane == 0) ctl[8] = 1 | (do_prep ? 2 : 0);
+      __syncthreads();  // B1
+      if (do_prep) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, H * kGroup);
+      __syncthreads();  // B2
+    } else {
+      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
+    }
 #endif
     // optimistic, branch-free passes first; the general forms only if a lane asked for them
     if (__builtin_expect(__any(w.template backward<false>(XUo, xT, lamb, active)), 0))
@@ -658,6 +692,10 @@ __global__ __launch_bounds__(64) void k_group_iterate(const DevCfg<T, Sys::n, Sy
     } else {
       fresh = false;
     }
+  }
+  if constexpr (H > 1) {
+    if (lane == 0) ctl[8] = 0;  // release the helpers
+    __syncthreads();            // B1 of an iteration that does not happen
   }
   if (!t_isfinite(cost_ret)) status = 4;
 
