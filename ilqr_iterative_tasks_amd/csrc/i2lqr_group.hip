@@ -46,7 +46,9 @@ hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s
 template <class T, class Sys>
 hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   constexpr int64_t kCUs = 256;
+#ifndef I2LQR_STAMPS  // (the diagnostic build stamps the phases of the lone wavefront)
   if ((a.B + kGroupsPerWave - 1) / kGroupsPerWave <= kCUs) return launch_h<T, Sys, 3>(cfg, a, s);
+#endif
   return launch_h<T, Sys, 1>(cfg, a, s);
 }
 
