@@ -21,6 +21,8 @@
 #include "i2lqr_select.hpp"
 #include "i2lqr_wave.hpp"
 
+#include "i2lqr_lane12.h"
+
 using namespace i2lqr;
 
 namespace {
@@ -253,7 +255,7 @@ template <class T, class Sys> struct Launch {
   }
 };
 
-// Batch-minor layout: one problem per lane (i2lqr_lane.hpp); m == 2 systems.
+// Batch-minor / batch-tiled layouts: one problem per lane (i2lqr_lane.hpp).
 template <class T, class Sys, bool TILED> struct LaneLaunch {
   static constexpr int kAutoWaveTail = 2048;
   static constexpr int kAutoSpecTail = 8192;
@@ -274,7 +276,17 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     h->lds_bytes = 0;
     return I2LQR_OK;
   }
+  // stage weights Q, R != 0: built for the plants without the row-block form (the bicycles)
+  static constexpr bool kStageWeights = Sys::NBLK == 0;
   static int need_ws(i2lqr_handle* h, int64_t B) {
+    if constexpr (!kStageWeights) {
+      bool hasqr = false;
+      for (int i = 0; i < I2LQR_MAX_N * I2LQR_MAX_N && !hasqr; i++) hasqr = h->cfg.Q[i] != 0.0;
+      for (int i = 0; i < I2LQR_MAX_M * I2LQR_MAX_M && !hasqr; i++) hasqr = h->cfg.R[i] != 0.0;
+      if (hasqr)
+        return fail(I2LQR_ERR_UNSUPPORTED, "the one-problem-per-lane kernels of this plant are built "
+                    "for Q = R = 0 (use the problem-major layout for stage weights)");
+    }
     if (TILED && (B & 63))
       return fail(I2LQR_ERR_INVALID, "the batch-tiled layout needs a batch that is a multiple of "
                   "64 (got %lld)", (long long)B);
@@ -372,9 +384,14 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
     const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
                        (a.ckpt ? kSegBytes : 0);
-    if (c.flags)
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
-    else
+    bool launched = false;
+    if constexpr (kStageWeights) {
+      if (c.flags) {
+        hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
+        launched = true;
+      }
+    }
+    if (!launched)
       hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), lds, s, c,
                          a);
   }
@@ -524,10 +541,15 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
     LaneArgs<T> a;
     carve(h, B, a);
-    if (c.flags)
-      hipLaunchKernelGGL((k_lane_rollout<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
+    bool launched = false;
+    if constexpr (kStageWeights) {
+      if (c.flags) {
+        hipLaunchKernelGGL((k_lane_rollout<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (T*)X, (T*)U, (const T*)x_term, (T*)cost);
-    else
+        launched = true;
+      }
+    }
+    if (!launched)
       hipLaunchKernelGGL((k_lane_rollout<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (T*)X, (T*)U, (const T*)x_term, (T*)cost);
     HIP_TRY(hipGetLastError());
@@ -539,11 +561,16 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
     LaneArgs<T> a;
     carve(h, B, a);
-    if (c.flags)
-      hipLaunchKernelGGL((k_lane_backward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
+    bool launched = false;
+    if constexpr (kStageWeights) {
+      if (c.flags) {
+        hipLaunchKernelGGL((k_lane_backward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
                          (const T*)obs, (T*)K, (T*)k);
-    else
+        launched = true;
+      }
+    }
+    if (!launched)
       hipLaunchKernelGGL((k_lane_backward<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)lamb,
                          (const T*)obs, (T*)K, (T*)k);
@@ -557,11 +584,16 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
     LaneArgs<T> a;
     carve(h, B, a);
-    if (c.flags)
-      hipLaunchKernelGGL((k_lane_forward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
+    bool launched = false;
+    if constexpr (kStageWeights) {
+      if (c.flags) {
+        hipLaunchKernelGGL((k_lane_forward<T, Sys, true, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
                          (T*)Xn, (T*)Un, (T*)cost_new);
-    else
+        launched = true;
+      }
+    }
+    if (!launched)
       hipLaunchKernelGGL((k_lane_forward<T, Sys, false, TILED>), dim3(grid(B)), dim3(64), 0, s, c, B,
                          (const T*)X, (const T*)U, (const T*)x_term, (const T*)K, (const T*)k,
                          (T*)Xn, (T*)Un, (T*)cost_new);
@@ -580,6 +612,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           return LaneLaunch<double, Bicycle4<double>, false>::CALL;                           \
         if (sid_ == I2LQR_SYS_BICYCLE6)                                                       \
           return LaneLaunch<double, Bicycle6<double>, false>::CALL;                           \
+        if (sid_ == I2LQR_SYS_QUAD12)                                                         \
+          return LaneLaunch<double, Quad12<double>, false>::CALL;                             \
       } else {                                                                                \
         if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, false>::CALL; \
         if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, false>::CALL; \
@@ -593,6 +627,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           return LaneLaunch<double, Bicycle4<double>, true>::CALL;                            \
         if (sid_ == I2LQR_SYS_BICYCLE6)                                                       \
           return LaneLaunch<double, Bicycle6<double>, true>::CALL;                            \
+        if (sid_ == I2LQR_SYS_QUAD12)                                                         \
+          return LaneLaunch<double, Quad12<double>, true>::CALL;                              \
       } else {                                                                                \
         if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, true>::CALL; \
         if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, true>::CALL; \
@@ -922,6 +958,10 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
                             : LaneLaunch<double, Bicycle6<double>, false>::ws_bytes(N, B);
       return tiled ? LaneLaunch<float, Bicycle6<float>, true>::ws_bytes(N, B)
                    : LaneLaunch<float, Bicycle6<float>, false>::ws_bytes(N, B);
+    case I2LQR_SYS_QUAD12:
+      if (f64) return tiled ? LaneLaunch<double, Quad12<double>, true>::ws_bytes(N, B)
+                            : LaneLaunch<double, Quad12<double>, false>::ws_bytes(N, B);
+      return 0;
     default: return 0;
   }
 }

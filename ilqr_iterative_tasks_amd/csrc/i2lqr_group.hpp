@@ -583,8 +583,11 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   const GL& L = w.L;
   T* S = w.S;
 
-  // entry: x0, U, x_term, lamb, obs (HBM, problem-major records) -> LDS / registers
-  {
+  // entry: x0, U, x_term, lamb, obs (HBM, problem-major records) -> LDS / registers.  Only the
+  // main wavefront stores: rollout() clips the inputs IN these LDS words right away, and a late
+  // helper store of the caller's raw value would undo the clip (inputs outside [-u_max, u_max] are
+  // legal: the reference clips them, control/iterative_ilqr.py:33-41).
+  if (H == 1 || hv == 0) {
     const T* gX = a.X + prob * (int64_t)(n * (N + 1));
     if (g < n) S[L.XU0 + g] = gX[g * (N + 1)];
     const T* gU = a.U + prob * (int64_t)(m * N);

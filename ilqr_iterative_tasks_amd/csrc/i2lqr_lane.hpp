@@ -95,10 +95,12 @@ template <bool TILED> struct LaneView {
 #define I2LQR_F32_WAVES 1
 #endif
 template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
-  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG, NV = Sys::NVAR;
+  static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG, NV = Sys::NVAR,
+                       NC = Sys::NCONST;
   using Cfg = DevCfg<T, n, m>;
   const Cfg& c;
   const int N;
+  T pc[NC > 0 ? NC : 1];  // plant-constant entries of F (pattern codes >= 100); wave-uniform
   const int64_t Bs_;    // row stride of the batch-minor layout (the tiled one is 64 at compile time)
   const unsigned lane;  // this lane's column inside the wavefront's re-based rows
   // Gains of the first horizon steps stay in LDS: the backward pass produces them last and the
@@ -116,7 +118,19 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #endif
 
   __device__ LaneWorker(const Cfg& c_, int64_t Bs, unsigned lane_)
-      : c(c_), N(c_.N), Bs_(Bs), lane(lane_) {}
+      : c(c_), N(c_.N), Bs_(Bs), lane(lane_) {
+#pragma unroll
+    for (int q = 0; q < NC; q++) pc[q] = uniform(Sys::plant_const(c, q));
+  }
+  // a value every lane computes identically, moved to scalar registers (a v_fma_f64 takes one
+  // scalar operand: the constant costs no vector registers in the unrolled Riccati step)
+  static __device__ __forceinline__ double uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  }
+  static __device__ __forceinline__ float uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+  }
   // Element (row, this lane) of a re-based (wave-uniform) array.  Rows are TIME-major:
   //   X: t n + i    U, k: t m + a    K: (t m + a) n + j
   // so the words of one horizon step are adjacent rows: one scalar base per step, immediate
@@ -183,6 +197,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     constexpr int code = Sys::pat(i, a);
     if constexpr (code == 1) return T(1);
     else if constexpr (code == 2) return c.dt;
+    else if constexpr (code >= 100) return pc[code - 100];
     else return jv[code - 3];
   }
   // acc += F[i][a] * v  (skipped at compile time for structural zeros; exact for ones)
@@ -398,10 +413,16 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   }
 
   // regularised inverse of Q_uu (m == 2 closed form, control/iterative_ilqr.py:118-123)
+  // m > 2: LDL^T inverse of Quu + lamb I where Quu is positive definite, clamped eigenvalues behind
+  // a wave-uniform unlikely branch otherwise (t_quu_inverse_m)
   __device__ __forceinline__ void quu_inverse(const T (&Quu)[m * m], T lamb,
                                               T (&inv)[m * m]) const {
-    static_assert(m == 2, "lane kernels are built for m == 2 systems");
-    t_quu_inverse2(Quu, lamb, inv);
+    if constexpr (m == 2) {
+      t_quu_inverse2(Quu, lamb, inv);
+    } else {
+      bool unused = false;
+      t_quu_inverse_m<T, m, true>(Quu, lamb, inv, &unused);
+    }
   }
 
   // -- backward pass: control/iterative_ilqr.py:88-130 ----------------------------------------
@@ -420,6 +441,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
                                            const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
                                            T* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
+    if constexpr (Sys::NBLK > 0) {
+      static_assert(!CK, "the row-block form has no checkpointed variant");
+      backward_blocked<FASTBAR>(X, U, xT, ob, lamb, gK, gk, k0_out);
+      return;
+    }
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     const unsigned l64 = threadIdx.x & 63;
     // state k of the current segment (k = 0: the checkpoint), component i: conflict-free LDS words
@@ -698,6 +724,314 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     }
   }
 
+  // -- backward pass, row-block form (plants with Sys::NBLK > 0: quad12) ------------------------
+  // Same recursion (control/iterative_ilqr.py:88-130), organised for a plant whose unrolled step
+  // does not fit a lane's registers otherwise (n = 12: [Vxx | Vx] and [Qxx | Qx] are 90 doubles
+  // EACH, next to 52 of [Qux | Qu] and 37 Jacobian entries; a lane has 256).  With
+  // A = M_0 M_1 .. M_{NBLK-1}, M_k = I + (rows of block k of E = A - I) (see Quad12::blk) and
+  // Kc = -Quu_reg^-1 B^T Vxx (the gains before the state Jacobian is applied):
+  //   G    = B^T [Vxx | Vx]                                      m x (n+1)
+  //   Quu  = l_uu + G[:, :n] B,   Qu = l_u + G[:, n]
+  //   [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu]                     in place over G
+  //   [W | w]  = [Vxx | Vx] - Kc^T (Quu [Kc | k])                in place over V
+  //   K    = Kc A = Kc M_0 M_1 ...                               in place, block after block
+  //   Vxx' = l_xx + A^T W A = .. M_1^T (M_0^T W M_0) M_1 ..      in place, upper triangle
+  //   Vx'  = l_x + A^T w    = .. M_1^T (M_0^T w)                 in place
+  // which is the reference's Qux = B^T Vxx A, K = -Quu_reg^-1 Qux, Vxx' = Qxx - K^T Quu K with the
+  // products associated differently (K^T Quu K = A^T (Kc^T Quu Kc) A): agreement with the other
+  // kernel families and the oracle is to round-off, not bit for bit.  Nothing of size n x n lives
+  // next to V, and the gains are stored and dead before the state blocks are applied.
+  static constexpr bool e_nz(int i, int j) {
+    return i == j ? Sys::pat(i, j) != 1 : Sys::pat(i, j) != 0;
+  }
+  static constexpr bool blocks_valid() {  // E[i][j] != 0 only where blk(j) <= blk(i)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++)
+        if (e_nz(i, j) && Sys::blk(j) > Sys::blk(i)) return false;
+    return true;
+  }
+  // does some row of block b reach column cc?
+  static constexpr bool in_s(int b, int cc) {
+    for (int r = 0; r < n; r++)
+      if (Sys::blk(r) == b && e_nz(r, cc)) return true;
+    return false;
+  }
+  // acc += E[i][j] * v
+  template <int i, int j> __device__ __forceinline__ void e_acc(T& acc, T v, const T (&jv)[NV]) const {
+    if constexpr (!e_nz(i, j)) {
+      return;
+    } else if constexpr (i == j) {  // a varying diagonal entry of A: E = A - 1
+      static_assert(Sys::pat(i, j) >= 3 && Sys::pat(i, j) < 100, "diagonal of A: one or varying");
+      acc = t_fma(jv[Sys::pat(i, j) - 3] - T(1), v, acc);
+    } else if constexpr (Sys::pat(i, j) == 1) {
+      acc = acc + v;
+    } else {
+      acc = t_fma(f_entry<i, j>(jv), v, acc);
+    }
+  }
+  // G[:, :n] <- G[:, :n] M_b
+  template <int b>
+  __device__ __forceinline__ void block_gains(T (&G)[m][n + 1], const T (&jv)[NV]) const {
+#pragma unroll
+    for (int a = 0; a < m; a++) {
+      T go[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) go[i] = G[a][i];
+      static_for<0, n>([&](auto c_) {
+        constexpr int cc = decltype(c_)::value;
+        if constexpr (in_s(b, cc)) {
+          T acc = go[cc];
+          static_for<0, n>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            if constexpr (Sys::blk(r) == b) e_acc<r, cc>(acc, go[r], jv);
+          });
+          G[a][cc] = acc;
+        }
+      });
+    }
+  }
+  // V <- M_b^T V M_b (upper triangle), vx <- M_b^T vx.  With rho_r = row r of E and
+  // z_r = V[r][:] + sum_r' (V[r][r'] / 2) rho_r' over the rows r, r' of the block:
+  //   M_b^T V M_b = V + sum_r (rho_r z_r^T + z_r rho_r^T)
+  // — a symmetric rank-2 update per row; the only temporaries are the z_r.
+  template <int b>
+  __device__ __forceinline__ void block_value(T (&V)[n][n], T (&vx)[n], const T (&jv)[NV]) const {
+    T z[n][n];  // rows of the block only
+    static_for<0, n>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      if constexpr (Sys::blk(r) == b) {
+        static_for<0, n>([&](auto c_) {
+          constexpr int cc = decltype(c_)::value;
+          T acc = r <= cc ? V[r][cc] : V[cc][r];
+          if constexpr (in_s(b, cc)) {
+            static_for<0, n>([&](auto q_) {
+              constexpr int q = decltype(q_)::value;
+              if constexpr (Sys::blk(q) == b && e_nz(q, cc))
+                e_acc<q, cc>(acc, T(0.5) * (r <= q ? V[r][q] : V[q][r]), jv);
+            });
+          }
+          z[r][cc] = acc;
+        });
+      }
+    });
+    T vo[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) vo[i] = vx[i];
+    static_for<0, n>([&](auto x_) {
+      constexpr int x = decltype(x_)::value;
+      static_for<x, n>([&](auto c_) {
+        constexpr int cc = decltype(c_)::value;
+        if constexpr (in_s(b, x) || in_s(b, cc)) {
+          T acc = V[x][cc];
+          static_for<0, n>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            if constexpr (Sys::blk(r) == b) {
+              e_acc<r, x>(acc, z[r][cc], jv);
+              e_acc<r, cc>(acc, z[r][x], jv);
+            }
+          });
+          V[x][cc] = acc;
+        }
+      });
+      if constexpr (in_s(b, x)) {
+        T acc = vo[x];
+        static_for<0, n>([&](auto r_) {
+          constexpr int r = decltype(r_)::value;
+          if constexpr (Sys::blk(r) == b) e_acc<r, x>(acc, vo[r], jv);
+        });
+        vx[x] = acc;
+      }
+    });
+  }
+
+  template <bool FASTBAR>
+  __device__ __forceinline__ void backward_blocked(const T* X, const T* U, const T (&xT)[n],
+                                                   const T (&ob)[6], T lamb, T* gK, T* gk,
+                                                   bool k0_out) const {
+    static_assert(blocks_valid(), "Sys::blk does not factor A = I + E into row blocks");
+    const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+    T V[n][n], vx[n];  // Vxx (upper triangle live), Vx
+    {
+      // get_cost_final(): control/ilqr_helper.py:106-150
+      T xN[n], o[5];
+#pragma unroll
+      for (int i = 0; i < n; i++) xN[i] = at(X, rx(i, N));
+      obstacle(ob, ob_pa, ob_pb, xN[0], xN[1], N, o);
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T acc = T(0);
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+          V[i][r] = T(2) * c.Qt[i * n + r];
+          acc += T(2) * c.Qt[i * n + r] * (xN[r] - xT[r]);
+        }
+        vx[i] = acc;
+      }
+      V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
+      vx[0] += o[0]; vx[1] += o[1];
+    }
+    T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t: loaded one step ahead (see backward())
+#pragma unroll
+    for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
+#pragma unroll
+    for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
+#pragma unroll
+    for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
+    for (int t = N - 1; t >= 0; t--) {
+      T jv[NV], o[5], tr[NT];
+      Sys::trig(xe, tr);
+      Sys::jac_var(c, xe, u, tr, jv);
+      obstacle(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
+      T lu[m], luu[m];  // input barrier: control/ilqr_helper.py:83-103 (see backward())
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T e_hi, e_lo;
+        if (FASTBAR && sizeof(T) == 8 && c.fast_barrier) {
+          e_hi = t_exp_bounded(c.ctrl_q2 * (u[a] - c.u_max[a]));
+          e_lo = c.ctrl_c[a] * t_rcp(e_hi);
+        } else {
+          e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
+          e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
+        }
+        T l = T(0);
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) l += T(2) * c.R[a * m + bb] * u[bb];
+        }
+        lu[a] = l + (c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo);
+        luu[a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
+                 c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+      }
+      T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
+#pragma unroll
+      for (int a = 0; a < n; a++) {
+        T l = T(0);
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int r = 0; r < n; r++) l += T(2) * c.Q[a * n + r] * (xp[r] - c.xtarget[r]);
+        }
+        lxq[a] = l;
+      }
+#pragma unroll
+      for (int i = 0; i < n; i++) xe[i] = xp[i];
+      if (t >= 1) {
+#pragma unroll
+        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - 1));
+#pragma unroll
+        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - 1));
+      }
+      // G = B^T [Vxx | Vx]
+      T G[m][n + 1];
+      static_for<0, m>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+#pragma unroll
+        for (int j = 0; j <= n; j++) {
+          T acc = T(0);
+          bool first = true;
+          static_for<0, n>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            const T vij = j == n ? vx[i] : (i <= j ? V[i][j] : V[j][i]);
+            f_acc<i, n + a>(acc, first, vij, jv);
+          });
+          G[a][j] = acc;
+        }
+      });
+      // Quu = l_uu + G[:, :n] B (upper triangle, mirrored); Qu = l_u + G[:, n]
+      T Quu[m * m];
+      static_for<0, m>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        static_for<a, m>([&](auto b_) {
+          constexpr int bb = decltype(b_)::value;
+          T acc = T(0);
+          bool first = true;
+          static_for<0, n>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            f_acc<i, n + bb>(acc, first, G[a][i], jv);
+          });
+          T l = T(0);
+          if constexpr (HASQR) l = T(2) * c.R[a * m + bb];
+          if constexpr (a == bb) l += luu[a];
+          Quu[a * m + bb] = l + acc;
+          Quu[bb * m + a] = l + acc;
+        });
+        G[a][n] = lu[a] + G[a][n];
+      });
+      // [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu], in place: control/iterative_ilqr.py:118-126
+      T Qinv[m * m];
+      quu_inverse(Quu, lamb, Qinv);
+#pragma unroll
+      for (int j = 0; j <= n; j++) {
+        T gc[m];
+#pragma unroll
+        for (int bb = 0; bb < m; bb++) gc[bb] = G[bb][j];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+          T acc = T(0);
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], gc[bb], acc);
+          G[a][j] = -acc;
+        }
+      }
+      // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu:
+      // control/iterative_ilqr.py:128-129 before the state Jacobian is applied
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T ktq[m];
+#pragma unroll
+        for (int bb = 0; bb < m; bb++) {
+          T acc = T(0);
+#pragma unroll
+          for (int a = 0; a < m; a++) acc = t_fma(G[a][i], Quu[a * m + bb], acc);
+          ktq[bb] = acc;
+        }
+#pragma unroll
+        for (int j = i; j <= n; j++) {
+          T acc = T(0);
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) acc = t_fma(ktq[bb], G[bb][j], acc);
+          if (j == n) vx[i] = vx[i] - acc;
+          else V[i][j] = V[i][j] - acc;
+        }
+      }
+      // K = Kc A, then the gains leave the registers
+      static_for<0, Sys::NBLK>([&](auto b_) { block_gains<decltype(b_)::value>(G, jv); });
+      if (t == 0 && lds) {
+#pragma unroll
+        for (int a = 0; a < m; a++) lds_k0(a) = G[a][n];
+        if (k0_out) {
+#pragma unroll
+          for (int a = 0; a < m; a++)
+#pragma unroll
+            for (int j = 0; j < n; j++) at(gK, rK(a, j, 0)) = G[a][j];
+        }
+      } else if (t >= 1 && t <= lds_steps) {
+#pragma unroll
+        for (int a = 0; a < m; a++)
+#pragma unroll
+          for (int j = 0; j <= n; j++) lds_gain(t, a * (n + 1) + j) = G[a][j];
+      } else {
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+#pragma unroll
+          for (int j = 0; j < n; j++) at(gK, rK(a, j, t)) = G[a][j];
+          at(gk, ru(a, t)) = G[a][n];
+        }
+      }
+      // [Vxx' | Vx'] = [l_xx | l_x] + A^T [W A | w], block after block
+      static_for<0, Sys::NBLK>([&](auto b_) { block_value<decltype(b_)::value>(V, vx, jv); });
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int j = i; j < n; j++) V[i][j] = T(2) * c.Q[i * n + j] + V[i][j];
+        }
+        vx[i] = lxq[i] + vx[i];
+      }
+      V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
+      vx[0] += o[0]; vx[1] += o[1];
+    }
+  }
+
   // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
   // REROLL: the nominal states x_t that the feedback law needs are re-rolled from the nominal
   // inputs next to the candidate (bit-identical to the stored X: same code, same inputs) instead
@@ -868,7 +1202,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
   // checkpointed states (fp64 only; host: deferred + merged + re-rolling forward pass, Q = R = 0)
-  constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR;
+  constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR && Sys::NBLK == 0;
   const bool ckpt = kCanCkpt && a.ckpt;
   T cost = w.rollout(X, Uc, xT, ckpt);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks

@@ -1,0 +1,35 @@
+// The one-problem-per-lane kernels of quad12 (n = 12, m = 4) are compiled in a translation unit
+// of their own (i2lqr_lane12.hip: the unrolled Riccati step is ~4000 instructions per horizon
+// step); i2lqr_abi.hip launches them through these declarations.
+#pragma once
+#include "i2lqr_lane.hpp"
+
+namespace i2lqr {
+
+#define I2LQR_LANE12_KERNELS(DECL)                                                               \
+  DECL void k_lane_iterate<double, Quad12<double>, false, false>(const DevCfg<double, 12, 4>,     \
+                                                                 const LaneArgs<double>);         \
+  DECL void k_lane_iterate<double, Quad12<double>, false, true>(const DevCfg<double, 12, 4>,      \
+                                                                const LaneArgs<double>);          \
+  DECL void k_lane_rollout<double, Quad12<double>, false, false>(                                 \
+      const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
+  DECL void k_lane_rollout<double, Quad12<double>, false, true>(                                  \
+      const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
+  DECL void k_lane_backward<double, Quad12<double>, false, false>(                                \
+      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
+      const double*, const double*, double*, double*);                                            \
+  DECL void k_lane_backward<double, Quad12<double>, false, true>(                                 \
+      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
+      const double*, const double*, double*, double*);                                            \
+  DECL void k_lane_forward<double, Quad12<double>, false, false>(                                 \
+      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
+      const double*, const double*, double*, double*, double*);                                   \
+  DECL void k_lane_forward<double, Quad12<double>, false, true>(                                  \
+      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
+      const double*, const double*, double*, double*, double*);
+
+#ifndef I2LQR_LANE12_DEFINE
+I2LQR_LANE12_KERNELS(extern template __global__)
+#endif
+
+}  // namespace i2lqr

@@ -347,8 +347,10 @@ template <class T, class Sys> struct QuadWorker {
 
   // -- backward pass: control/iterative_ilqr.py:88-130.  Leaves the gains in the HBM workspace.
   //    GENERAL: see GroupWorker::backward.
+  //    commit: the problem is still running — a problem that has terminated keeps computing beside
+  //    its wavefront neighbours but must not overwrite the gains of its last executed iteration.
   template <bool GENERAL>
-  __device__ __forceinline__ bool backward(const T (&xT)[n], T lamb) const {
+  __device__ __forceinline__ bool backward(const T (&xT)[n], T lamb, bool commit) const {
     bool bad = false;
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150
     T va[n];
@@ -491,7 +493,7 @@ template <class T, class Sys> struct QuadWorker {
 #pragma unroll
       for (int a = 0; a < m; a++) {
         EX[a * QL::GW + g] = kc[a];
-        Gt[a * QL::GW + g] = kc[a];
+        if (commit) Gt[a * QL::GW + g] = kc[a];
       }
       wave_sync();
       // value update with the UNregularised Quu: Va'[:, g] = [H | g][:n, g] - K^T (Quu [K|k][:, g])
@@ -690,8 +692,8 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
 #ifdef I2LQR_STAMPS
     STAMP_END(0);
 #endif
-    if (__builtin_expect(__any(w.template backward<false>(xT, lamb)), 0))
-      w.template backward<true>(xT, lamb);
+    if (__builtin_expect(__any(w.template backward<false>(xT, lamb, active)), 0))
+      w.template backward<true>(xT, lamb, active);
 #ifdef I2LQR_STAMPS
     STAMP_BEGIN();
 #endif

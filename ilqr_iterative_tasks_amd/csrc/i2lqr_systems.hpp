@@ -494,6 +494,9 @@ __device__ __forceinline__ void t_quu_inverse_m(const T (&Quu)[m * m], T lamb, T
 // ---------------------------------------------------------------------------------------------
 template <class T> struct Bicycle4 {
   static constexpr int n = 4, m = 2, NTRIG = 2, NVAR = 6;
+  static constexpr int NCONST = 0, NBLK = 0;  // no plant-constant entries in F, no row-block form
+  static constexpr int blk(int) { return 0; }
+  template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 0;
 
   // {cos(theta), sin(theta)}
@@ -567,6 +570,9 @@ template <class T> struct Bicycle4 {
 // ---------------------------------------------------------------------------------------------
 template <class T> struct Bicycle6 {
   static constexpr int n = 6, m = 2, NTRIG = 2, NVAR = 6;
+  static constexpr int NCONST = 0, NBLK = 0;  // no plant-constant entries in F, no row-block form
+  static constexpr int blk(int) { return 0; }
+  template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 1;
 
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
@@ -784,6 +790,19 @@ template <class T> struct Quad12 {
     if (i == 10) return a == 2 ? 102 : (a == 0 ? 103 : 0);
     if (i == 11) return (a & 1) == 0 ? 104 : 105;
     return 0;
+  }
+  // Row-block factorisation of A = I + E (one-problem-per-lane kernel, LaneWorker::backward_blocked).
+  // With the state rows grouped into the blocks
+  //     {p, q, r} = 0   {phi, theta} = 1   {psi} = 2   {vx}, {vy}, {vz} = 3, 4, 5   {x}, {y}, {z} = 6, 7, 8
+  // every non-zero E[i][j] has blk(j) <= blk(i) (rates feed angles, angles feed velocities,
+  // velocities feed positions; the cycles p-q-r and phi-theta stay inside one block), hence
+  //     A = M_0 M_1 ... M_8,   M_k = I + (the rows of block k of E)
+  // exactly (all cross products vanish), and A^T V A, K A, A^T v become nine IN-PLACE updates that
+  // touch only the columns a block's rows reach — no n x n intermediate next to V.  Checked at
+  // compile time where it is used.
+  static constexpr int NBLK = 9;
+  static constexpr int blk(int i) {
+    return i >= 9 ? 0 : (i == 3 || i == 4) ? 1 : i == 5 ? 2 : i >= 6 ? i - 3 : i + 6;
   }
   // {dt arm / Ix, -, dt arm / Iy, -, dt ctau / Iz, -}: the constant entries of B (jac_const)
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg& c, int q) {
