@@ -384,16 +384,16 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
     const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
                        (a.ckpt ? kSegBytes : 0);
-    bool launched = false;
-    if constexpr (kStageWeights) {
-      if (c.flags) {
-        hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c, a);
-        launched = true;
-      }
+    if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
+      hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+    } else {
+      if (c.flags)
+        hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c,
+                           a);
+      else
+        hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), lds, s, c,
+                           a);
     }
-    if (!launched)
-      hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), lds, s, c,
-                         a);
   }
 
   // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per

@@ -43,6 +43,26 @@ template <class T, int n, int m> inline DevCfg<T, n, m> make_dev_cfg(const i2lqr
       hasR |= h.R[a * I2LQR_MAX_M + b] != 0.0;
     }
   for (int q = 0; q < 8; q++) d.sys_par[q] = (T)h.sys_par[q];
+  d.ctrl_q12 = d.ctrl_q1 * d.ctrl_q2;
+  d.ctrl_q122 = d.ctrl_q1 * (d.ctrl_q2 * d.ctrl_q2);
+  d.obs_q12 = d.obs_q1 * d.obs_q2;
+  d.obs_q122 = d.obs_q1 * (d.obs_q2 * d.obs_q2);
+  if (h.system_id == I2LQR_SYS_QUAD12) {  // Quad12::step_tr / jac_var / plant_const read these
+    const T mass = d.sys_par[0], g = d.sys_par[1], arm = d.sys_par[2];
+    const T Ix = d.sys_par[3], Iy = d.sys_par[4], Iz = d.sys_par[5], ct = d.sys_par[6];
+    d.pd[0] = T(1) / mass;
+    d.pd[1] = arm / Ix;
+    d.pd[2] = arm / Iy;
+    d.pd[3] = ct / Iz;
+    d.pd[4] = (Iy - Iz) / Ix;
+    d.pd[5] = (Iz - Ix) / Iy;
+    d.pd[6] = (Ix - Iy) / Iz;
+    d.pd[7] = mass * g;
+    for (int q = 0; q < 6; q++) {
+      const T v = q < 2 ? d.dt * arm / Ix : (q < 4 ? d.dt * arm / Iy : d.dt * ct / Iz);
+      d.pd[8 + q] = (q & 1) ? -v : v;
+    }
+  }
   d.flags = (hasQ ? FLAG_HAS_Q : 0) | (hasR ? FLAG_HAS_R : 0);
   return d;
 }

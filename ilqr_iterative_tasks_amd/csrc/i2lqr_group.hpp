@@ -307,9 +307,9 @@ template <class T, class Sys> struct GroupWorker {
             e_hi = t_exp(c.ctrl_q2 * (u[a] - c.u_max[a]));
             e_lo = t_exp(c.ctrl_q2 * (-c.u_max[a] - u[a]));
           }
-          Rs[GL::R_LU + a] = c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo;
-          Rs[GL::R_LUU + a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
-                              c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+          Rs[GL::R_LU + a] = c.ctrl_q12 * e_hi - c.ctrl_q12 * e_lo;
+          Rs[GL::R_LUU + a] = c.ctrl_q122 * e_hi +
+                              c.ctrl_q122 * e_lo;
         }
       }
       T* R = S + oR + t * GL::RW;
@@ -323,7 +323,7 @@ template <class T, class Sys> struct GroupWorker {
       const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
       const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
       const T e = t_exp(c.obs_q2 * h);
-      const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+      const T c1 = c.obs_q12 * e, c2 = c.obs_q122 * e;
       R[GL::R_OB + 0] = has_ob ? c1 * hd0 : T(0);
       R[GL::R_OB + 1] = has_ob ? c1 * hd1 : T(0);
       R[GL::R_OB + 2] = has_ob ? c2 * (hd0 * hd0) : T(0);

@@ -32,6 +32,14 @@ template <int Begin, int End, class F> __device__ __forceinline__ void static_fo
   }
 }
 
+// Scheduling fence between the phases of the unrolled row-block Riccati step: the phases are
+// thousands of independent multiply-adds, and a scheduler free to interleave them across phase
+// boundaries stretches every live range (registers are the scarce resource at one wavefront per
+// SIMD with 90 doubles of value function resident).
+#ifndef I2LQR_PHASE_FENCE
+#define I2LQR_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 template <class T> struct LaneArgs {
   int64_t B;                 // row stride (capacity) of every array; also the batch unless `count`
   int n_iters, early_exit;
@@ -122,6 +130,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
     for (int q = 0; q < NC; q++) pc[q] = uniform(Sys::plant_const(c, q));
   }
+  // hides a value's origin from the optimiser (no instruction)
+  static __device__ __forceinline__ void opaque(double& v) { asm volatile("" : "+v"(v)); }
+  static __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
   // a value every lane computes identically, moved to scalar registers (a v_fma_f64 takes one
   // scalar operand: the constant costs no vector registers in the unrolled Riccati step)
   static __device__ __forceinline__ double uniform(double v) {
@@ -138,6 +149,28 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   __device__ __forceinline__ int64_t stride() const { return TILED ? (int64_t)64 : Bs_; }
   template <class P> __device__ __forceinline__ P& at(P* p, int row) const {
     return (p + (int64_t)row * stride())[lane];
+  }
+  // Row groups (kernels of the row-block plants): CNT consecutive rows starting at `row0` are
+  // addressed as ONE scalar base per group of eight rows (formed per use: two scalar adds, hidden
+  // from the optimiser so that it is not split into per-row loop invariants — 52 gain rows per
+  // step otherwise become 52 hoisted address registers, spilled to scratch and reloaded one by
+  // one) + the lane's offset + an immediate row offset (global_* immediates reach 4 KiB: eight
+  // 512-byte rows of the tiled layout).  f(integral_constant<row index>, word reference).
+  template <class P> __device__ __forceinline__ P* rows(P* p, int row) const {
+    P* q = p + (int64_t)row * stride();
+    asm volatile("" : "+s"(q));
+    return q;
+  }
+  template <int CNT, class P, class F>
+  __device__ __forceinline__ void for_rows(P* p, int row0, F&& f) const {
+    static_for<0, (CNT + 7) / 8>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      P* q = rows(p, row0 + 8 * g);
+      static_for<0, (CNT - 8 * g < 8 ? CNT - 8 * g : 8)>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        f(std::integral_constant<int, 8 * g + r>{}, (q + (int64_t)r * stride())[lane]);
+      });
+    });
   }
   static __device__ __forceinline__ int rx(int i, int t) { return t * n + i; }
   static __device__ __forceinline__ int ru(int a, int t) { return t * m + a; }
@@ -403,12 +436,36 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
       const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
       const T e = t_exp(c.obs_q2 * h);
-      const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+      const T c1 = c.obs_q12 * e, c2 = c.obs_q122 * e;
       o[0] = c1 * hd0;
       o[1] = c1 * hd1;
       o[2] = c2 * (hd0 * hd0);
       o[3] = c2 * (hd0 * hd1);
       o[4] = c2 * (hd1 * hd1);
+    }
+  }
+
+  // GENERAL = false: the same terms without a branch — computed for every lane (a lane without an
+  // obstacle carries finite placeholders) and selected
+  template <bool GENERAL>
+  __device__ __forceinline__ void obstacle_sel(const T (&ob)[6], T pa, T pb, T px, T py, int t,
+                                               T (&o)[5]) const {
+    if constexpr (GENERAL) {
+      obstacle(ob, pa, pb, px, py, t, o);
+    } else {
+      const bool has = ob[5] >= T(0);
+      const int opt = has ? (int)ob[5] : 0;
+      const T dy = opt == 1 ? py - (ob[1] + T(t) * ob[4]) : py - ob[1];
+      const T dz = opt == 2 ? px - (ob[0] - T(t) * ob[4]) : px - ob[0];
+      const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
+      const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
+      const T e = t_exp(c.obs_q2 * h);
+      const T c1 = c.obs_q12 * e, c2 = c.obs_q122 * e;
+      o[0] = has ? c1 * hd0 : T(0);
+      o[1] = has ? c1 * hd1 : T(0);
+      o[2] = has ? c2 * (hd0 * hd0) : T(0);
+      o[3] = has ? c2 * (hd0 * hd1) : T(0);
+      o[4] = has ? c2 * (hd1 * hd1) : T(0);
     }
   }
 
@@ -443,7 +500,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
-      backward_blocked<FASTBAR>(X, U, xT, ob, lamb, gK, gk, k0_out);
+      backward_blocked<FASTBAR, true>(X, U, xT, ob, lamb, gK, gk);
       return;
     }
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
@@ -546,9 +603,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
           for (int bb = 0; bb < m; bb++) l += T(2) * c.R[a * m + bb] * u[bb];
         }
-        lu[a] = l + (c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo);
-        luu[a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
-                 c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+        lu[a] = l + (c.ctrl_q12 * e_hi - c.ctrl_q12 * e_lo);
+        luu[a] = c.ctrl_q122 * e_hi +
+                 c.ctrl_q122 * e_lo;
       }
       T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
 #pragma unroll
@@ -844,19 +901,25 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     });
   }
 
-  template <bool FASTBAR>
-  __device__ __forceinline__ void backward_blocked(const T* X, const T* U, const T (&xT)[n],
-                                                   const T (&ob)[6], T lamb, T* gK, T* gk,
-                                                   bool k0_out) const {
+  // Every gain goes to HBM (no LDS-resident steps: one step of this plant's gains is 26 KB).
+  // GENERAL = false: the hot form — no branch inside the horizon loop (short sin / cos kernels,
+  // the positive-definite Quu inverse, the one-exp input barrier, the obstacle term computed for
+  // every lane and selected); returns true if some lane needed a general form (argument of a
+  // sin / cos out of range, Quu not positive definite), in which case the caller repeats the pass
+  // with GENERAL = true (same protocol as the other kernel families: the general forms' cold code
+  // — library sincos, Jacobi sweeps — stays out of the loop the register allocator has to fit).
+  template <bool FASTBAR, bool GENERAL = true>
+  __device__ __forceinline__ bool backward_blocked(const T* X, const T* U, const T (&xT)[n],
+                                                   const T (&ob)[6], T lamb, T* gK, T* gk) const {
+    bool bad = false;
     static_assert(blocks_valid(), "Sys::blk does not factor A = I + E into row blocks");
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     T V[n][n], vx[n];  // Vxx (upper triangle live), Vx
     {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
-#pragma unroll
-      for (int i = 0; i < n; i++) xN[i] = at(X, rx(i, N));
-      obstacle(ob, ob_pa, ob_pb, xN[0], xN[1], N, o);
+      for_rows<n>(X, rx(0, N), [&](auto i_, const T& w) { xN[decltype(i_)::value] = w; });
+      obstacle_sel<GENERAL>(ob, ob_pa, ob_pb, xN[0], xN[1], N, o);
 #pragma unroll
       for (int i = 0; i < n; i++) {
         T acc = T(0);
@@ -870,23 +933,33 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
       vx[0] += o[0]; vx[1] += o[1];
     }
-    T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t: loaded one step ahead (see backward())
-#pragma unroll
-    for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
-#pragma unroll
-    for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, N - 1));
-#pragma unroll
-    for (int a = 0; a < m; a++) u[a] = at(U, ru(a, N - 1));
+    // Register budget of the step (a lane has 256 doubles, 90 of them hold [Vxx | Vx]): the inputs
+    // of step t-1 are loaded late in step t (before the state blocks, ~7000 cycles ahead of their
+    // first use) instead of at its top, and only what the step's first phases need stays live
+    // through them: of x_t the position (obstacle term; all of it with stage weights), of the
+    // Jacobian the B entries — the 25 varying A entries are formed again from the kept sin / cos
+    // values, rates and thrust right before the phases that use them.
+    constexpr int NP = HASQR ? n : 2;
+    T xe[n], xp[NP], u[m];  // x_{t+1}, (leading entries of) x_t, u_t
+    for_rows<n>(X, rx(0, N), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
+    for_rows<NP>(X, rx(0, N - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
+    for_rows<m>(U, ru(0, N - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
     for (int t = N - 1; t >= 0; t--) {
       T jv[NV], o[5], tr[NT];
-      Sys::trig(xe, tr);
-      Sys::jac_var(c, xe, u, tr, jv);
-      obstacle(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
+      Sys::template trig_g<GENERAL>(xe, tr, &bad);
+      {
+        T jb[NV];
+        Sys::jac_var(c, xe, u, tr, jb);
+#pragma unroll
+        for (int q = 0; q < NV; q++) jv[q] = jb[q];  // only the B entries are used before `refresh`
+      }
+
+      obstacle_sel<GENERAL>(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
       T lu[m], luu[m];  // input barrier: control/ilqr_helper.py:83-103 (see backward())
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T e_hi, e_lo;
-        if (FASTBAR && sizeof(T) == 8 && c.fast_barrier) {
+        if (!GENERAL || (FASTBAR && sizeof(T) == 8 && c.fast_barrier)) {
           e_hi = t_exp_bounded(c.ctrl_q2 * (u[a] - c.u_max[a]));
           e_lo = c.ctrl_c[a] * t_rcp(e_hi);
         } else {
@@ -898,9 +971,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
           for (int bb = 0; bb < m; bb++) l += T(2) * c.R[a * m + bb] * u[bb];
         }
-        lu[a] = l + (c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo);
-        luu[a] = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
-                 c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+        lu[a] = l + (c.ctrl_q12 * e_hi - c.ctrl_q12 * e_lo);
+        luu[a] = c.ctrl_q122 * e_hi +
+                 c.ctrl_q122 * e_lo;
       }
       T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
 #pragma unroll
@@ -912,15 +985,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
         lxq[a] = l;
       }
-#pragma unroll
-      for (int i = 0; i < n; i++) xe[i] = xp[i];
-      if (t >= 1) {
-#pragma unroll
-        for (int i = 0; i < n; i++) xp[i] = at(X, rx(i, t - 1));
-#pragma unroll
-        for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - 1));
-      }
       // G = B^T [Vxx | Vx]
+      I2LQR_PHASE_FENCE();
       T G[m][n + 1];
       static_for<0, m>([&](auto a_) {
         constexpr int a = decltype(a_)::value;
@@ -957,8 +1023,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         G[a][n] = lu[a] + G[a][n];
       });
       // [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu], in place: control/iterative_ilqr.py:118-126
+      I2LQR_PHASE_FENCE();
       T Qinv[m * m];
-      quu_inverse(Quu, lamb, Qinv);
+      if constexpr (GENERAL) quu_inverse(Quu, lamb, Qinv);
+      else t_quu_inverse_m<T, m, false>(Quu, lamb, Qinv, &bad);
 #pragma unroll
       for (int j = 0; j <= n; j++) {
         T gc[m];
@@ -974,6 +1042,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
       // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu:
       // control/iterative_ilqr.py:128-129 before the state Jacobian is applied
+      I2LQR_PHASE_FENCE();
 #pragma unroll
       for (int i = 0; i < n; i++) {
         T ktq[m];
@@ -994,31 +1063,42 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
       }
       // K = Kc A, then the gains leave the registers
+      I2LQR_PHASE_FENCE();
+      {  // the A entries of the Jacobian, formed again (hidden from value numbering: the compiler
+         // would otherwise keep the first evaluation's 25 doubles live through the phases above)
+        T xr[n], ur[m], trr[NT];
+#pragma unroll
+        for (int i = 0; i < n; i++) xr[i] = xe[i];
+#pragma unroll
+        for (int a = 0; a < m; a++) ur[a] = u[a];
+#pragma unroll
+        for (int q = 0; q < NT; q++) trr[q] = tr[q];
+#pragma unroll
+        for (int i = 0; i < n; i++) opaque(xr[i]);
+#pragma unroll
+        for (int a = 0; a < m; a++) opaque(ur[a]);
+#pragma unroll
+        for (int q = 0; q < NT; q++) opaque(trr[q]);
+        Sys::jac_var(c, xr, ur, trr, jv);
+      }
       static_for<0, Sys::NBLK>([&](auto b_) { block_gains<decltype(b_)::value>(G, jv); });
-      if (t == 0 && lds) {
-#pragma unroll
-        for (int a = 0; a < m; a++) lds_k0(a) = G[a][n];
-        if (k0_out) {
-#pragma unroll
-          for (int a = 0; a < m; a++)
-#pragma unroll
-            for (int j = 0; j < n; j++) at(gK, rK(a, j, 0)) = G[a][j];
-        }
-      } else if (t >= 1 && t <= lds_steps) {
-#pragma unroll
-        for (int a = 0; a < m; a++)
-#pragma unroll
-          for (int j = 0; j <= n; j++) lds_gain(t, a * (n + 1) + j) = G[a][j];
-      } else {
-#pragma unroll
-        for (int a = 0; a < m; a++) {
-#pragma unroll
-          for (int j = 0; j < n; j++) at(gK, rK(a, j, t)) = G[a][j];
-          at(gk, ru(a, t)) = G[a][n];
-        }
+      for_rows<m * n>(gK, rK(0, 0, t), [&](auto e_, T& w) {
+        constexpr int e = decltype(e_)::value;
+        w = G[e / n][e % n];
+      });
+      for_rows<m>(gk, ru(0, t), [&](auto a_, T& w) { w = G[decltype(a_)::value][n]; });
+      // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1}
+      I2LQR_PHASE_FENCE();
+      if (t >= 1) {
+        for_rows<n>(X, rx(0, t), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
+        for_rows<NP>(X, rx(0, t - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
+        for_rows<m>(U, ru(0, t - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
       }
       // [Vxx' | Vx'] = [l_xx | l_x] + A^T [W A | w], block after block
-      static_for<0, Sys::NBLK>([&](auto b_) { block_value<decltype(b_)::value>(V, vx, jv); });
+      static_for<0, Sys::NBLK>([&](auto b_) {
+        I2LQR_PHASE_FENCE();
+        block_value<decltype(b_)::value>(V, vx, jv);
+      });
 #pragma unroll
       for (int i = 0; i < n; i++) {
         if constexpr (HASQR) {
@@ -1030,6 +1110,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
       vx[0] += o[0]; vx[1] += o[1];
     }
+    return bad;
   }
 
   // -- forward pass: control/iterative_ilqr.py:133-160 ----------------------------------------
@@ -1138,6 +1219,86 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     }
     cost = cost + terminal_cost(x, xT);
     return cost;
+  }
+
+  // -- forward pass of the row-block plants: control/iterative_ilqr.py:133-160 ------------------
+  // The deferred form of forward(): the feedback law reads the nominal states, the candidate
+  // inputs go to Un, no candidate state is stored (an accepted step re-rolls them:
+  // restore_rows()).  Same arithmetic, word for word, as forward<false, false>; the step's 68
+  // words are loaded one step ahead through row groups.  x_0 is common to the nominal and the
+  // candidate: K_0 multiplies zeros and is not read.
+  template <bool GENERAL>
+  __device__ __forceinline__ T forward_rows(const T* X, const T* U, const T* gK, const T* gk, T* Un,
+                                            const T (&xT)[n], bool* bad) const {
+    T x[n], u[m], xn[n], tr[NT];
+    T xl[n], ul[m], kl[m][n + 1];
+    for_rows<n>(X, rx(0, 0), [&](auto i_, const T& w) { x[decltype(i_)::value] = w; });
+#pragma unroll
+    for (int i = 0; i < n; i++) xl[i] = x[i];
+    for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
+    for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
+#pragma unroll
+    for (int a = 0; a < m; a++)
+#pragma unroll
+      for (int j = 0; j < n; j++) kl[a][j] = T(0);
+    T cost = T(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < n; j++) acc = t_fma(kl[a][j], x[j] - xl[j], acc);
+        u[a] = clip(ul[a] + kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
+      }
+      if (t + 1 < N) {
+        for_rows<n>(X, rx(0, t + 1), [&](auto i_, const T& w) { xl[decltype(i_)::value] = w; });
+        for_rows<m>(U, ru(0, t + 1), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
+        for_rows<m * n>(gK, rK(0, 0, t + 1), [&](auto e_, const T& w) {
+          constexpr int e = decltype(e_)::value;
+          kl[e / n][e % n] = w;
+        });
+        for_rows<m>(gk, ru(0, t + 1), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
+      }
+      for_rows<m>(Un, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
+      Sys::template trig_g<GENERAL>(x, tr, bad);
+      Sys::step_tr(c, x, u, tr, xn);
+      cost = cost + stage_cost(x, xT, u);
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    cost = cost + terminal_cost(x, xT);
+    return cost;
+  }
+
+  // Re-roll X[:, 1..N] from the inputs (restore_states_paired through row groups).  MERGE: the
+  // lanes that accepted take their inputs from the candidate buffer Un, every lane writes its
+  // current inputs back to U (one buffer with full rows for the whole wavefront).
+  // Running it twice gives the same result (the repeat with GENERAL = true relies on it).
+  template <bool MERGE, bool GENERAL>
+  __device__ __forceinline__ bool restore_rows(T* X, T* U, const T* Un = nullptr,
+                                               bool acc = false) const {
+    bool bad = false;
+    T x[n], xn[n], tr[NT], u[m], ul[m], uc[m];
+    for_rows<n>(X, rx(0, 0), [&](auto i_, const T& w) { x[decltype(i_)::value] = w; });
+    auto load_u = [&](const int t) __attribute__((always_inline)) {
+      for_rows<m>(U, ru(0, t), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
+      if constexpr (MERGE)
+        for_rows<m>(Un, ru(0, t), [&](auto a_, const T& w) { uc[decltype(a_)::value] = w; });
+    };
+    load_u(0);
+    for (int t = 0; t < N; t++) {
+#pragma unroll
+      for (int a = 0; a < m; a++) u[a] = (MERGE && acc) ? uc[a] : ul[a];
+      if (t + 1 < N) load_u(t + 1);
+      if constexpr (MERGE)
+        for_rows<m>(U, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
+      Sys::template trig_g<GENERAL>(x, tr, &bad);
+      Sys::step_tr(c, x, u, tr, xn);
+      for_rows<n>(X, rx(0, t + 1), [&](auto i_, T& w) { w = xn[decltype(i_)::value]; });
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    }
+    return bad;
   }
 
   // stage cost of a stored trajectory measured to xtarget (only needed when Q != 0, where the
@@ -1307,6 +1468,88 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     if (ckpt) w.restore_states(X, Uc);  // the caller's X in full: one re-roll per launch
   }
   w.flush_gains(gK, gk);
+  if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
+    for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
+  }
+  a.lamb[b] = lamb;
+  a.cost[b] = cost_ret;
+  if (a.iters) a.iters[b] = it0 + it;
+  if (a.status) a.status[b] = status;
+}
+
+// The fused kernel of the row-block plants (quad12): k_lane_iterate's deferred, merged form — the
+// forward pass stores no states, accepted candidates are merged into the one input buffer while
+// the states are re-rolled — with every access through row groups and no LDS (see LaneWorker::
+// for_rows, backward_blocked).  Same arguments and results as k_lane_iterate (chunked solves
+// included); the defer / reroll / merge / lds / ckpt options do not apply.  Q = R = 0.
+template <class T, class Sys, bool TILED>
+__global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys::n, Sys::m> c,
+                                                             const LaneArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m;
+  static_assert(Sys::NBLK > 0, "built for the plants with a row-block form");
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t live = a.count ? (int64_t)*a.count : a.B;
+  if (b >= live) return;
+  if (a.resume && a.status[b] != 0) return;
+  const int N = c.N;
+  const LaneView<TILED> v(a.B);
+  LaneWorker<T, Sys, false, TILED> w(c, v.Bs, v.bl);
+  const T* gxt = v.rebase(a.x_term, n);
+  const T* gob = v.rebase(a.obs, 6);
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = gob ? gob[(int64_t)q * v.Bs + v.bl] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[b];
+  T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
+  T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
+  T* const X = v.rebase(a.X, n * (N + 1));
+  T* const U0 = v.rebase(a.U, m * N);
+  T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
+  T cost = w.rollout(X, Uc, xT);
+  const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
+  int it = 0, status = a.early_exit ? 2 : 0;
+  T cost_ret = cost;
+  const bool general = !(sizeof(T) == 8 && c.fast_barrier);  // configurations outside the hot form
+  while (it < a.n_iters && it0 + it < a.max_total) {
+    // hot, branch-free passes first; the general forms only if a lane asked for them
+    if (__builtin_expect(__any(general || w.template backward_blocked<true, false>(X, Uc, xT, ob, lamb, gK, gk)), 0))
+      w.template backward_blocked<true, true>(X, Uc, xT, ob, lamb, gK, gk);
+    bool big = false;
+    T cost_new = w.template forward_rows<false>(X, Uc, gK, gk, Un, xT, &big);
+    if (__builtin_expect(__any(big), 0))
+      cost_new = w.template forward_rows<true>(X, Uc, gK, gk, Un, xT, &big);
+    it++;
+    const bool accepted = cost_new < cost;
+    if (__all(accepted)) {  // the two input buffers change roles for the whole wavefront
+      T* tp = Uc; Uc = Un; Un = tp;
+      if (__builtin_expect(__any(w.template restore_rows<false, false>(X, Uc)), 0))
+        w.template restore_rows<false, true>(X, Uc);
+    } else if (__any(accepted)) {
+      if (__builtin_expect(__any(w.template restore_rows<true, false>(X, Uc, Un, accepted)), 0))
+        w.template restore_rows<true, true>(X, Uc, Un, accepted);
+    }
+    if (accepted) {  // control/iterative_ilqr.py:74-80
+      lamb /= c.lamb_factor;
+      const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
+      cost_ret = cost_new;
+      cost = cost_new;
+      if (conv) {
+        if (a.early_exit) { status = 1; break; }
+        if (status == 0) status = 1;
+      }
+    } else {  // control/iterative_ilqr.py:81-84
+      lamb *= c.lamb_factor;
+      cost_ret = cost;
+      if (lamb > c.max_lamb) {
+        if (a.early_exit) { status = 3; break; }
+        if (status == 0) status = 3;
+      }
+    }
+  }
+  if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
+  if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
   if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
     for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
   }

@@ -7,10 +7,10 @@
 namespace i2lqr {
 
 #define I2LQR_LANE12_KERNELS(DECL)                                                               \
-  DECL void k_lane_iterate<double, Quad12<double>, false, false>(const DevCfg<double, 12, 4>,     \
-                                                                 const LaneArgs<double>);         \
-  DECL void k_lane_iterate<double, Quad12<double>, false, true>(const DevCfg<double, 12, 4>,      \
-                                                                const LaneArgs<double>);          \
+  DECL void k_lane_iterate_rows<double, Quad12<double>, false>(const DevCfg<double, 12, 4>,       \
+                                                               const LaneArgs<double>);           \
+  DECL void k_lane_iterate_rows<double, Quad12<double>, true>(const DevCfg<double, 12, 4>,        \
+                                                              const LaneArgs<double>);            \
   DECL void k_lane_rollout<double, Quad12<double>, false, false>(                                 \
       const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
   DECL void k_lane_rollout<double, Quad12<double>, false, true>(                                  \

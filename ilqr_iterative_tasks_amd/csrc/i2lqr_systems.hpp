@@ -692,13 +692,13 @@ template <class T> struct Quad12 {
     // the two divisions by cos(theta) share one reciprocal: an IEEE fp64 division is a dozen
     // instructions on this hardware, six of them per step were a fifth of the rollout.  (A few ulp
     // from the textbook form; every kernel and every rollout uses this one function.)
-    const T mass = c.sys_par[0], g = c.sys_par[1], arm = c.sys_par[2];
-    const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5], ct = c.sys_par[6];
-    const T inv_mass = T(1) / mass, arm_ix = arm / Ix, arm_iy = arm / Iy, ct_iz = ct / Iz;
+    // (the quotients are formed once on the host, DevCfg::pd: the same IEEE divisions)
+    const T g = c.sys_par[1];
+    const T inv_mass = c.pd[0], arm_ix = c.pd[1], arm_iy = c.pd[2], ct_iz = c.pd[3];
     const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
     const T icth = t_rcp(cth);
     const T tth = sth * icth;
-    const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
+    const T Tt = c.pd[7] + (u[0] + u[1] + u[2] + u[3]);
     const T Tm = Tt * inv_mass;
     const T p = x[9], q = x[10], r = x[11], dt = c.dt;
     T f[n];
@@ -711,9 +711,9 @@ template <class T> struct Quad12 {
     f[6] = Tm * (cph * sth * cps + sph * sps);
     f[7] = Tm * (cph * sth * sps - sph * cps);
     f[8] = Tm * (cph * cth) - g;
-    f[9] = ((Iy - Iz) / Ix) * q * r + arm_ix * (u[1] - u[3]);
-    f[10] = ((Iz - Ix) / Iy) * p * r + arm_iy * (u[2] - u[0]);
-    f[11] = ((Ix - Iy) / Iz) * p * q + ct_iz * (u[0] - u[1] + u[2] - u[3]);
+    f[9] = c.pd[4] * q * r + arm_ix * (u[1] - u[3]);
+    f[10] = c.pd[5] * p * r + arm_iy * (u[2] - u[0]);
+    f[11] = c.pd[6] * p * q + ct_iz * (u[0] - u[1] + u[2] - u[3]);
 #pragma unroll
     for (int i = 0; i < n; i++) xn[i] = x[i] + dt * f[i];
   }
@@ -727,13 +727,11 @@ template <class T> struct Quad12 {
   template <class Cfg>
   static __device__ __forceinline__ void jac_var(const Cfg& c, const T (&xe)[n], const T (&u)[m],
                                                  const T (&tr)[NTRIG], T (&v)[NVAR]) {
-    const T mass = c.sys_par[0], g = c.sys_par[1];
-    const T Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
-    const T inv_mass = T(1) / mass;
+    const T inv_mass = c.pd[0];
     const T sph = tr[0], cph = tr[1], sth = tr[2], cth = tr[3], sps = tr[4], cps = tr[5];
     const T icth = t_rcp(cth);  // one reciprocal for every division by cos(theta) (see step_tr)
     const T tth = sth * icth, sec2 = icth * icth;
-    const T Tt = mass * g + (u[0] + u[1] + u[2] + u[3]);
+    const T Tt = c.pd[7] + (u[0] + u[1] + u[2] + u[3]);
     const T Tm = Tt * inv_mass, dt = c.dt;
     const T p = xe[9], q = xe[10], r = xe[11];
     // A = I + dt * dF/dx
@@ -756,12 +754,12 @@ template <class T> struct Quad12 {
     v[16] = dt * (Tm * (cph * sth * cps + sph * sps));    // [7][5]
     v[17] = dt * (Tm * (-sph * cth));                     // [8][3]
     v[18] = dt * (Tm * (-cph * sth));                     // [8][4]
-    v[19] = dt * (((Iy - Iz) / Ix) * r);                  // [9][10]
-    v[20] = dt * (((Iy - Iz) / Ix) * q);                  // [9][11]
-    v[21] = dt * (((Iz - Ix) / Iy) * r);                  // [10][9]
-    v[22] = dt * (((Iz - Ix) / Iy) * p);                  // [10][11]
-    v[23] = dt * (((Ix - Iy) / Iz) * q);                  // [11][9]
-    v[24] = dt * (((Ix - Iy) / Iz) * p);                  // [11][10]
+    v[19] = dt * (c.pd[4] * r);                  // [9][10]
+    v[20] = dt * (c.pd[4] * q);                  // [9][11]
+    v[21] = dt * (c.pd[5] * r);                  // [10][9]
+    v[22] = dt * (c.pd[5] * p);                  // [10][11]
+    v[23] = dt * (c.pd[6] * q);                  // [11][9]
+    v[24] = dt * (c.pd[6] * p);                  // [11][10]
     // B rows 6..8: dt * a{x,y,z} for each of the 4 inputs
     const T ax = dt * ((cph * sth * cps + sph * sps) * inv_mass);
     const T ay = dt * ((cph * sth * sps - sph * cps) * inv_mass);
@@ -806,10 +804,7 @@ template <class T> struct Quad12 {
   }
   // {dt arm / Ix, -, dt arm / Iy, -, dt ctau / Iz, -}: the constant entries of B (jac_const)
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg& c, int q) {
-    const T dt = c.dt, arm = c.sys_par[2], Ix = c.sys_par[3], Iy = c.sys_par[4], Iz = c.sys_par[5];
-    const T ct = c.sys_par[6];
-    const T v = q < 2 ? dt * arm / Ix : (q < 4 ? dt * arm / Iy : dt * ct / Iz);
-    return (q & 1) ? -v : v;
+    return c.pd[8 + q];
   }
   static constexpr int var_idx_c(int v) {
     constexpr int W = n + m;

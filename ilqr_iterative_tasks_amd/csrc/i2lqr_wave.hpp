@@ -40,6 +40,13 @@ template <class T, int n, int m> struct DevCfg {
   T xtarget[n];
   T Q[n * n], Qt[n * n], R[m * m];
   T sys_par[8];
+  // Products / quotients of the constants above that every lane would otherwise form itself and
+  // keep in vector registers across the horizon loops (host-computed in T, same roundings):
+  // q1 q2 and q1 q2^2 of the two barrier families, and the plant's derived constants
+  // (Quad12: {1/mass, arm/Ix, arm/Iy, ctau/Iz, (Iy-Iz)/Ix, (Iz-Ix)/Iy, (Ix-Iy)/Iz, mass g,
+  // plant_const(0..5)}).
+  T ctrl_q12, ctrl_q122, obs_q12, obs_q122;
+  T pd[16];
 };
 
 template <class T> struct IterArgs {
@@ -337,9 +344,9 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
 #pragma unroll
             for (int b = 0; b < m; b++) lu += T(2) * c.R[a * m + b] * u[b];
           }
-          lu += c.ctrl_q1 * c.ctrl_q2 * e_hi - c.ctrl_q1 * c.ctrl_q2 * e_lo;
-          const T luu = c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_hi +
-                        c.ctrl_q1 * (c.ctrl_q2 * c.ctrl_q2) * e_lo;
+          lu += c.ctrl_q12 * e_hi - c.ctrl_q12 * e_lo;
+          const T luu = c.ctrl_q122 * e_hi +
+                        c.ctrl_q122 * e_lo;
           S[L.lu + t * m + a] = lu;
           S[L.luu + t * m + a] = luu;
         }
@@ -356,7 +363,7 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
         const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
         const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
         const T e = t_exp(c.obs_q2 * h);
-        const T c1 = c.obs_q1 * c.obs_q2 * e, c2 = c.obs_q1 * (c.obs_q2 * c.obs_q2) * e;
+        const T c1 = c.obs_q12 * e, c2 = c.obs_q122 * e;
         o0 = c1 * hd0;
         o1 = c1 * hd1;
         o2 = c2 * (hd0 * hd0);
