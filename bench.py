@@ -117,6 +117,7 @@ def spawn_ranks(args) -> int:
 EVENT_STRIDE = 8
 LANE_THRESHOLD = 10240
 LANE_THRESHOLD_SOLVE = 16384
+QUAD_LANE_THRESHOLD = 8192
 LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
 LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",  # eight from 1024 problems
                "lane": "batch-minor (one problem per lane)",
@@ -130,7 +131,11 @@ def pick_layout(args, B, solve=False, cfg=None):
     if args.layout != "auto":
         return args.layout
     if cfg is not None and cfg.system_id == 2:
-        return "wave"  # quad12 (m = 4) is built for the problem-major kernels
+        # quad12: one problem per lane (k_lane_iterate_rows) from 8192 problems, the sixteen-lane
+        # kernel of the problem-major layout below (tools/ab_bench.py --workload config5)
+        if B < QUAD_LANE_THRESHOLD or cfg.dtype != 0:
+            return "wave"
+        return "lane" if B % 64 else "tiled"
     if B < (LANE_THRESHOLD_SOLVE if solve else LANE_THRESHOLD):
         return "wave"
     return "lane" if B % 64 else "tiled"

@@ -64,6 +64,70 @@ struct i2lqr_handle {
 
 namespace {
 
+// Which fused kernel a problem-major call runs on: ONE function, used by the launchers and by
+// i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
+enum FusedKernel { K_WAVE, K_GROUP, K_SPEC, K_QUAD, K_INVALID };
+constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
+constexpr int64_t kAutoSpecBatch = 8192;   // speculative form for solves up to here (automatic)
+
+// *why: the message of K_INVALID (a forced option the configuration cannot honour)
+FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, const char** why) {
+  static const char* none = "";
+  if (!why) why = &none;
+  const bool m2 = h->cfg.m == 2 && h->cfg.n + h->cfg.m <= 8;
+  const bool q16 = h->cfg.n + h->cfg.m == 16;
+  if (m2) {
+    // Eight lanes per problem, eight problems per wavefront (i2lqr_group.hpp).  Automatic where it
+    // is built (the bicycles, Q = R = 0) from 1024 problems: below that every problem gets a SIMD
+    // of its own either way and the one-problem-per-wavefront kernel's iteration is ~8 % shorter
+    // (tools/group_ab.py: 0.195 vs 0.212 ms per 10 iterations at 64-256 problems, 0.219 vs 0.213
+    // at 1024, 0.63 vs 0.25 at 4096).
+    const bool can = group_supported(h->cfg);
+    if (h->opt_group == 8 && !can) {
+      *why = "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 and a horizon whose eight "
+             "problem slices fit the 160 KiB of LDS";
+      return K_INVALID;
+    }
+    // Speculative form (k_group_spec): two or three wavefronts per eight problems run the
+    // iterations that follow 0, 1, (2) rejects at once; bit-identical results.  With a FIXED
+    // iteration count it measures slower than the plain kernel (0.275 vs 0.215 ms per 10
+    // iterations at 1024 problems), so it stays opt-in there.  Automatic for solves to
+    // termination (early_exit) of at most kAutoSpecBatch problems: the launch lasts as long as
+    // its slowest problem, and the slowest problems alternate accepts and rejects — i2lqr_solve
+    // 0.60 -> 0.44 ms at 16 problems, 1.21 -> 0.71 ms at 1024, 1.23 -> 1.17 at 8192.
+    const bool can_spec = can && group_spec_supported(h->cfg);
+    if (h->opt_spec == 1 && !can_spec) {
+      *why = "\"speculate\" = 1 needs the eight-lane kernel and a horizon whose speculative "
+             "buffers fit the 160 KiB of LDS";
+      return K_INVALID;
+    }
+    if (can_spec && h->opt_group != 64 &&
+        (h->opt_spec == 1 ||
+         (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
+      return K_SPEC;
+    if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) return K_GROUP;
+  } else if (h->opt_group == 8) {
+    *why = "\"group_lanes\" = 8 is built for the m = 2 plants only";
+    return K_INVALID;
+  }
+  if (q16) {
+    // Sixteen lanes per problem, four problems per wavefront (i2lqr_quad.hpp): needs the caller's
+    // workspace (i2lqr_workspace_bytes); automatic whenever it is registered.
+    const bool can = quad_supported(h->cfg);
+    const bool have_ws = h->ws && h->ws_bytes >= quad_workspace_bytes(h->cfg, B);
+    if (h->opt_group == 16 && !(can && have_ws)) {
+      *why = "\"group_lanes\" = 16 needs Q = R = 0 and a registered workspace of "
+             "i2lqr_workspace_bytes() for this batch";
+      return K_INVALID;
+    }
+    if ((h->opt_group == 16 || h->opt_group < 0) && can && have_ws) return K_QUAD;
+  } else if (h->opt_group == 16) {
+    *why = "\"group_lanes\" = 16 is built for the n + m = 16 plant only";
+    return K_INVALID;
+  }
+  return K_WAVE;
+}
+
 // One launcher per (dtype, system); LANES fixed at 64 = one problem per wavefront.
 template <class T, class Sys> struct Launch {
   static constexpr int n = Sys::n, m = Sys::m, LANES = 64;
@@ -74,8 +138,6 @@ template <class T, class Sys> struct Launch {
     return (size_t)Layout<Sys>(N, true).total * sizeof(T) * (64 / LANES);
   }
   static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
-  static constexpr int64_t kAutoGroupBatch = 1024;
-  static constexpr int64_t kAutoSpecBatch = 8192;
   static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
@@ -130,59 +192,30 @@ template <class T, class Sys> struct Launch {
 #ifdef I2LQR_STAMPS
     a.dbg = (unsigned long long*)h->ws;  // diagnostic build: caller registers [B][8] u64 here
 #endif
-    // Eight lanes per problem, eight problems per wavefront (i2lqr_group.hpp).  Automatic where it
-    // is built (the bicycles, Q = R = 0) from 1024 problems: below that every problem gets a SIMD
-    // of its own either way and the one-problem-per-wavefront kernel's iteration is ~8 % shorter
-    // (tools/group_ab.py: 0.195 vs 0.212 ms per 10 iterations at 64-256 problems, 0.219 vs 0.213
-    // at 1024, 0.63 vs 0.25 at 4096).
-    if constexpr (m == 2 && n + m <= 8) {
-      const bool can = group_supported(h->cfg);
-      if (h->opt_group == 8 && !can)
-        return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 "
-                    "and a horizon whose eight problem slices fit the 160 KiB of LDS");
-      // Speculative form (k_group_spec): two or three wavefronts per eight problems run the
-      // iterations that follow 0, 1, (2) rejects at once; bit-identical results.  With a FIXED
-      // iteration count it measures slower than the plain kernel (0.275 vs 0.215 ms per 10
-      // iterations at 1024 problems: the launch lasts until the one problem that never rejects is
-      // done, and the wavefronts of a workgroup contend for the CU's LDS), so it stays opt-in
-      // there.
-      const bool can_spec = can && group_spec_supported(h->cfg);
-      if (h->opt_spec == 1 && !can_spec)
-        return fail(I2LQR_ERR_UNSUPPORTED, "\"speculate\" = 1 needs the eight-lane kernel and a "
-                    "horizon whose speculative buffers fit the 160 KiB of LDS");
-      // Automatic for solves to termination (early_exit) of at most kAutoSpecBatch problems: the
-      // launch lasts as long as its slowest problem, and the slowest problems alternate accepts and
-      // rejects — i2lqr_solve 0.60 -> 0.44 ms at 16 problems, 1.21 -> 0.71 ms at 1024, 0.78 -> 0.51
-      // at 2048, 1.03 -> 0.85 at 4096, 1.23 -> 1.17 at 8192.
-      const bool spec = can_spec && h->opt_group != 64 &&
-                        (h->opt_spec == 1 ||
-                         (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch));
-      if (spec) {
-        HIP_TRY(group_spec_iterate<T>(h->cfg, a, s));
-        return I2LQR_OK;
-      }
-      if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
-        HIP_TRY(group_iterate<T>(h->cfg, a, s));
-        return I2LQR_OK;
-      }
-    } else if (h->opt_group == 8) {
-      return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 8 is built for the m = 2 plants only");
-    }
-    // Sixteen lanes per problem, four problems per wavefront (i2lqr_quad.hpp): the n + m = 16 plant.
-    // Needs the caller's workspace (i2lqr_workspace_bytes); automatic whenever it is registered.
-    if constexpr (n + m == 16) {
-      const bool can = quad_supported(h->cfg);
-      const bool have_ws = h->ws && h->ws_bytes >= quad_workspace_bytes(h->cfg, B);
-      if (h->opt_group == 16 && !(can && have_ws))
-        return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 16 needs Q = R = 0 and a registered "
-                    "workspace of i2lqr_workspace_bytes() (%lld B for this batch)",
-                    (long long)quad_workspace_bytes(h->cfg, B));
-      if ((h->opt_group == 16 || h->opt_group < 0) && can && have_ws) {
-        HIP_TRY(quad_iterate<T>(h->cfg, a, h->ws, s));
-        return I2LQR_OK;
-      }
-    } else if (h->opt_group == 16) {
-      return fail(I2LQR_ERR_UNSUPPORTED, "\"group_lanes\" = 16 is built for the n + m = 16 plant only");
+    const char* why = "";
+    switch (select_fused(h, B, early_exit != 0, &why)) {
+      case K_INVALID:
+        return fail(I2LQR_ERR_UNSUPPORTED, "%s", why);
+      case K_SPEC:
+        if constexpr (m == 2 && n + m <= 8) {
+          HIP_TRY(group_spec_iterate<T>(h->cfg, a, s));
+          return I2LQR_OK;
+        }
+        break;
+      case K_GROUP:
+        if constexpr (m == 2 && n + m <= 8) {
+          HIP_TRY(group_iterate<T>(h->cfg, a, s));
+          return I2LQR_OK;
+        }
+        break;
+      case K_QUAD:
+        if constexpr (n + m == 16) {
+          HIP_TRY(quad_iterate<T>(h->cfg, a, h->ws, s));
+          return I2LQR_OK;
+        }
+        break;
+      case K_WAVE:
+        break;
     }
     // Per-step F matrices (prep() writes them in parallel over t; the serial recursion then has no
     // Jacobian refresh) double the LDS slice: taken when every wavefront of the launch still fits
@@ -997,17 +1030,15 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
 
 static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit) {
   if (!h) return "";
-  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return "k_lane_iterate";
-  const bool m2 = h->cfg.system_id != I2LQR_SYS_QUAD12;
-  const bool can = m2 && group_supported(h->cfg);
-  if (can && group_spec_supported(h->cfg) && h->opt_group != 64 &&
-      (h->opt_spec == 1 || (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= 8192)))
-    return "k_group_spec";
-  if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= 1024)) return "k_group_iterate";
-  if ((h->opt_group == 16 || h->opt_group < 0) && quad_supported(h->cfg) && h->ws &&
-      h->ws_bytes >= quad_workspace_bytes(h->cfg, B))
-    return "k_quad_iterate";
-  return "k_iterate";
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return h->cfg.system_id == I2LQR_SYS_QUAD12 ? "k_lane_iterate_rows" : "k_lane_iterate";
+  switch (select_fused(h, B, early_exit, nullptr)) {
+    case K_SPEC: return "k_group_spec";
+    case K_GROUP: return "k_group_iterate";
+    case K_QUAD: return "k_quad_iterate";
+    case K_WAVE: return "k_iterate";
+    default: return "unsupported";  // the launch returns I2LQR_ERR_UNSUPPORTED
+  }
 }
 
 const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B) { return kernel_name(h, B, false); }

@@ -22,19 +22,30 @@ bool has_stage_weights(const i2lqr_config& cfg) {
   return false;
 }
 
+// Launches with more than 64 KiB of dynamic LDS need the kernel's attribute raised — per kernel
+// AND per device (a second GPU used from the same thread has its own copy of the attribute):
+// once per (kernel, device, size).
+template <auto Kernel> hipError_t raise_lds_limit(size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  constexpr int kMaxDev = 64;
+  static thread_local int raised_for[kMaxDev] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDev || raised_for[dev] < (int)lds) {
+    e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < kMaxDev) raised_for[dev] = (int)lds;
+  }
+  return hipSuccess;
+}
+
 template <class T, class Sys, int H>
 hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
   const size_t lds = group_lds_bytes<T, Sys>(cfg.N);
-  if (lds > 64 * 1024) {
-    static thread_local int raised_for = 0;  // the attribute is per kernel: raise it once per size
-    if (raised_for < (int)lds) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_group_iterate<T, Sys, H>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      raised_for = (int)lds;
-    }
-  }
+  if (hipError_t e = raise_lds_limit<k_group_iterate<T, Sys, H>>(lds); e != hipSuccess) return e;
   const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
   hipLaunchKernelGGL((k_group_iterate<T, Sys, H>), dim3(grid), dim3(64 * H), lds, s, c, a);
   return hipGetLastError();
@@ -68,15 +79,8 @@ template <class T, class Sys, int V, bool SETIO>
 hipError_t launch_spec_v(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
   const size_t lds = spec_lds_bytes<T, Sys, V>(cfg.N);
-  if (lds > 64 * 1024) {
-    static thread_local int raised_for = 0;
-    if (raised_for < (int)lds) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_group_spec<T, Sys, V, SETIO>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      raised_for = (int)lds;
-    }
-  }
+  if (hipError_t e = raise_lds_limit<k_group_spec<T, Sys, V, SETIO>>(lds); e != hipSuccess)
+    return e;
   const int64_t problems = SETIO ? (int64_t)a.count_max : a.B;
   const unsigned grid = (unsigned)((problems + kGroupsPerWave - 1) / kGroupsPerWave);
   hipLaunchKernelGGL((k_group_spec<T, Sys, V, SETIO>), dim3(grid), dim3(64 * V), lds, s, c, a);

@@ -39,6 +39,9 @@ template <int Begin, int End, class F> __device__ __forceinline__ void static_fo
 #ifndef I2LQR_PHASE_FENCE
 #define I2LQR_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef I2LQR_LOADS_FIRST
+#define I2LQR_LOADS_FIRST 0
+#endif
 
 template <class T> struct LaneArgs {
   int64_t B;                 // row stride (capacity) of every array; also the batch unless `count`
@@ -500,7 +503,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
-      backward_blocked<FASTBAR, true>(X, U, xT, ob, lamb, gK, gk);
+      __shared__ T lds_gains[kGainWords];
+      backward_blocked<FASTBAR, true>(X, U, xT, ob, lamb, gK, gk, lds_gains);
       return;
     }
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
@@ -787,17 +791,18 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // EACH, next to 52 of [Qux | Qu] and 37 Jacobian entries; a lane has 256).  With
   // A = M_0 M_1 .. M_{NBLK-1}, M_k = I + (rows of block k of E = A - I) (see Quad12::blk) and
   // Kc = -Quu_reg^-1 B^T Vxx (the gains before the state Jacobian is applied):
-  //   G    = B^T [Vxx | Vx]                                      m x (n+1)
+  //   G    = B^T [Vxx | Vx]                                      m x (n+1), column by column
   //   Quu  = l_uu + G[:, :n] B,   Qu = l_u + G[:, n]
-  //   [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu]                     in place over G
-  //   [W | w]  = [Vxx | Vx] - Kc^T (Quu [Kc | k])                in place over V
-  //   K    = Kc A = Kc M_0 M_1 ...                               in place, block after block
+  //   [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu]                     columns -> LDS
+  //   [W | w]  = [Vxx | Vx] - Kc^T (Quu [Kc | k])                in place over V, row by row of Quu Kc
+  //   K    = Kc A = Kc M_0 M_1 ...                               row by row from LDS, to HBM
   //   Vxx' = l_xx + A^T W A = .. M_1^T (M_0^T W M_0) M_1 ..      in place, upper triangle
   //   Vx'  = l_x + A^T w    = .. M_1^T (M_0^T w)                 in place
   // which is the reference's Qux = B^T Vxx A, K = -Quu_reg^-1 Qux, Vxx' = Qxx - K^T Quu K with the
   // products associated differently (K^T Quu K = A^T (Kc^T Quu Kc) A): agreement with the other
   // kernel families and the oracle is to round-off, not bit for bit.  Nothing of size n x n lives
   // next to V, and the gains are stored and dead before the state blocks are applied.
+  static constexpr int kGainWords = m * (n + 1) * 64;  // LDS words per wavefront (backward_blocked)
   static constexpr bool e_nz(int i, int j) {
     return i == j ? Sys::pat(i, j) != 1 : Sys::pat(i, j) != 0;
   }
@@ -826,26 +831,29 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       acc = t_fma(f_entry<i, j>(jv), v, acc);
     }
   }
-  // G[:, :n] <- G[:, :n] M_b
+  // is row i of B = F[:, n:] structurally non-zero?
+  static constexpr bool b_row(int i) {
+    for (int a = 0; a < m; a++)
+      if (Sys::pat(i, n + a) != 0) return true;
+    return false;
+  }
+  // g <- g M_b (one row of the gains)
   template <int b>
-  __device__ __forceinline__ void block_gains(T (&G)[m][n + 1], const T (&jv)[NV]) const {
+  __device__ __forceinline__ void block_gain_row(T (&g)[n], const T (&jv)[NV]) const {
+    T go[n];
 #pragma unroll
-    for (int a = 0; a < m; a++) {
-      T go[n];
-#pragma unroll
-      for (int i = 0; i < n; i++) go[i] = G[a][i];
-      static_for<0, n>([&](auto c_) {
-        constexpr int cc = decltype(c_)::value;
-        if constexpr (in_s(b, cc)) {
-          T acc = go[cc];
-          static_for<0, n>([&](auto r_) {
-            constexpr int r = decltype(r_)::value;
-            if constexpr (Sys::blk(r) == b) e_acc<r, cc>(acc, go[r], jv);
-          });
-          G[a][cc] = acc;
-        }
-      });
-    }
+    for (int i = 0; i < n; i++) go[i] = g[i];
+    static_for<0, n>([&](auto c_) {
+      constexpr int cc = decltype(c_)::value;
+      if constexpr (in_s(b, cc)) {
+        T acc = go[cc];
+        static_for<0, n>([&](auto r_) {
+          constexpr int r = decltype(r_)::value;
+          if constexpr (Sys::blk(r) == b) e_acc<r, cc>(acc, go[r], jv);
+        });
+        g[cc] = acc;
+      }
+    });
   }
   // V <- M_b^T V M_b (upper triangle), vx <- M_b^T vx.  With rho_r = row r of E and
   // z_r = V[r][:] + sum_r' (V[r][r'] / 2) rho_r' over the rows r, r' of the block:
@@ -910,8 +918,18 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // — library sincos, Jacobi sweeps — stays out of the loop the register allocator has to fit).
   template <bool FASTBAR, bool GENERAL = true>
   __device__ __forceinline__ bool backward_blocked(const T* X, const T* U, const T (&xT)[n],
-                                                   const T (&ob)[6], T lamb, T* gK, T* gk) const {
+                                                   const T (&ob)[6], T lamb, T* gK, T* gk,
+                                                   T* lds_gains) const {
     bool bad = false;
+    // the step's [Kc | k] in this wavefront's LDS slice (kGainWords words), typed as LDS (ds_*
+    // with immediate offsets).  Stores index with the lane, loads with a copy of it whose origin
+    // is hidden: the optimiser cannot prove that a load reads what a store wrote and forward the
+    // value — i.e. keep the 52 doubles in registers after all — but orders them as it must.
+    typedef __attribute__((address_space(3))) T lds_word;
+    lds_word* const kcs = (lds_word*)lds_gains;
+    const unsigned l64 = threadIdx.x & 63;
+    unsigned lrd = l64;
+    asm volatile("" : "+v"(lrd));
     static_assert(blocks_valid(), "Sys::blk does not factor A = I + E into row blocks");
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     T V[n][n], vx[n];  // Vxx (upper triangle live), Vx
@@ -944,9 +962,12 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     for_rows<n>(X, rx(0, N), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
     for_rows<NP>(X, rx(0, N - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
     for_rows<m>(U, ru(0, N - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
+    STAMP_BEGIN();
     for (int t = N - 1; t >= 0; t--) {
       T jv[NV], o[5], tr[NT];
-      Sys::template trig_g<GENERAL>(xe, tr, &bad);
+      STAMP_END(6);
+      if constexpr (GENERAL) Sys::trig(xe, tr);
+      else Sys::trig_s(xe, tr, &bad);
       {
         T jb[NV];
         Sys::jac_var(c, xe, u, tr, jb);
@@ -954,12 +975,40 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         for (int q = 0; q < NV; q++) jv[q] = jb[q];  // only the B entries are used before `refresh`
       }
 
-      obstacle_sel<GENERAL>(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
       T lu[m], luu[m];  // input barrier: control/ilqr_helper.py:83-103 (see backward())
+      T ehi[m];
+      if constexpr (!GENERAL && sizeof(T) == 8) {
+        // hot form: the obstacle term without a branch (obstacle_sel) and the step's m + 1
+        // exponentials evaluated together, their literals shared in scalar registers (t_exp_d)
+        const bool has = ob[5] >= T(0);
+        const int opt = has ? (int)ob[5] : 0;
+        const T dy = opt == 1 ? xp[1] - (ob[1] + T(t) * ob[4]) : xp[1] - ob[1];
+        const T dz = opt == 2 ? xp[0] - (ob[0] - T(t) * ob[4]) : xp[0] - ob[0];
+        const T h = T(1) + c.safety_margin - (dz * ob_pa * dz + dy * ob_pb * dy);
+        const T hd0 = T(-2) * ob_pa * dz, hd1 = T(-2) * ob_pb * dy;
+        T ea[m + 1], ee[m + 1];
+        ea[0] = c.obs_q2 * h;
+#pragma unroll
+        for (int a = 0; a < m; a++) ea[1 + a] = c.ctrl_q2 * (u[a] - c.u_max[a]);
+        t_exp_d<true, m + 1, m>(ea, ee);
+        const T c1 = c.obs_q12 * ee[0], c2 = c.obs_q122 * ee[0];
+        o[0] = has ? c1 * hd0 : T(0);
+        o[1] = has ? c1 * hd1 : T(0);
+        o[2] = has ? c2 * (hd0 * hd0) : T(0);
+        o[3] = has ? c2 * (hd0 * hd1) : T(0);
+        o[4] = has ? c2 * (hd1 * hd1) : T(0);
+#pragma unroll
+        for (int a = 0; a < m; a++) ehi[a] = ee[1 + a];
+      } else {
+        obstacle_sel<GENERAL>(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
+      }
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T e_hi, e_lo;
-        if (!GENERAL || (FASTBAR && sizeof(T) == 8 && c.fast_barrier)) {
+        if constexpr (!GENERAL && sizeof(T) == 8) {
+          e_hi = ehi[a];
+          e_lo = c.ctrl_c[a] * t_rcp(e_hi);
+        } else if (!GENERAL || (FASTBAR && sizeof(T) == 8 && c.fast_barrier)) {
           e_hi = t_exp_bounded(c.ctrl_q2 * (u[a] - c.u_max[a]));
           e_lo = c.ctrl_c[a] * t_rcp(e_hi);
         } else {
@@ -985,13 +1034,16 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
         lxq[a] = l;
       }
-      // G = B^T [Vxx | Vx]
+      // ---- gains.  [Kc | k] never lives in registers as a whole (52 doubles next to the 90 of
+      // [Vxx | Vx]): its columns go to this wavefront's LDS slice as they are formed and come back
+      // in the order the two consumers want them — word (a, j) of lane l at kcs[(a (n+1) + j) 64 + l],
+      // every lane reads only what it wrote (no barrier), consecutive lanes on consecutive words.
       I2LQR_PHASE_FENCE();
-      T G[m][n + 1];
-      static_for<0, m>([&](auto a_) {
-        constexpr int a = decltype(a_)::value;
-#pragma unroll
-        for (int j = 0; j <= n; j++) {
+      STAMP_END(0);
+      auto gcol = [&](auto j_, T (&g)[m]) __attribute__((always_inline)) {  // column j of B^T [Vxx | Vx]
+        constexpr int j = decltype(j_)::value;
+        static_for<0, m>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
           T acc = T(0);
           bool first = true;
           static_for<0, n>([&](auto i_) {
@@ -999,71 +1051,85 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
             const T vij = j == n ? vx[i] : (i <= j ? V[i][j] : V[j][i]);
             f_acc<i, n + a>(acc, first, vij, jv);
           });
-          G[a][j] = acc;
-        }
-      });
-      // Quu = l_uu + G[:, :n] B (upper triangle, mirrored); Qu = l_u + G[:, n]
-      T Quu[m * m];
-      static_for<0, m>([&](auto a_) {
-        constexpr int a = decltype(a_)::value;
-        static_for<a, m>([&](auto b_) {
-          constexpr int bb = decltype(b_)::value;
-          T acc = T(0);
-          bool first = true;
-          static_for<0, n>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            f_acc<i, n + bb>(acc, first, G[a][i], jv);
-          });
-          T l = T(0);
-          if constexpr (HASQR) l = T(2) * c.R[a * m + bb];
-          if constexpr (a == bb) l += luu[a];
-          Quu[a * m + bb] = l + acc;
-          Quu[bb * m + a] = l + acc;
+          g[a] = acc;
         });
-        G[a][n] = lu[a] + G[a][n];
-      });
-      // [Kc | k] = -Quu_reg^-1 [G[:, :n] | Qu], in place: control/iterative_ilqr.py:118-126
-      I2LQR_PHASE_FENCE();
+      };
+      // Quu = l_uu + (B^T Vxx) B, from the columns of B^T Vxx that the rows of B reach
+      T Quu[m * m];
+      {
+        T Gb[n][m];  // columns i of B^T Vxx with a non-zero row i of B
+        static_for<0, n>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          if constexpr (b_row(i)) gcol(i_, Gb[i]);
+        });
+        static_for<0, m>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          static_for<a, m>([&](auto b_) {
+            constexpr int bb = decltype(b_)::value;
+            T acc = T(0);
+            bool first = true;
+            static_for<0, n>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              if constexpr (b_row(i)) f_acc<i, n + bb>(acc, first, Gb[i][a], jv);
+            });
+            T l = T(0);
+            if constexpr (HASQR) l = T(2) * c.R[a * m + bb];
+            if constexpr (a == bb) l += luu[a];
+            Quu[a * m + bb] = l + acc;
+            Quu[bb * m + a] = l + acc;
+          });
+        });
+      }
+      // [Kc | k] = -Quu_reg^-1 [B^T Vxx | Qu], column by column: control/iterative_ilqr.py:118-126
       T Qinv[m * m];
       if constexpr (GENERAL) quu_inverse(Quu, lamb, Qinv);
       else t_quu_inverse_m<T, m, false>(Quu, lamb, Qinv, &bad);
+      static_for<0, n + 1>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        T g[m];
+        gcol(j_, g);
+        if constexpr (j == n) {
 #pragma unroll
-      for (int j = 0; j <= n; j++) {
-        T gc[m];
-#pragma unroll
-        for (int bb = 0; bb < m; bb++) gc[bb] = G[bb][j];
+          for (int a = 0; a < m; a++) g[a] = lu[a] + g[a];  // Qu = l_u + B^T Vx
+        }
 #pragma unroll
         for (int a = 0; a < m; a++) {
           T acc = T(0);
 #pragma unroll
-          for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], gc[bb], acc);
-          G[a][j] = -acc;
+          for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], g[bb], acc);
+          kcs[(a * (n + 1) + j) * 64 + l64] = -acc;
         }
-      }
-      // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu:
-      // control/iterative_ilqr.py:128-129 before the state Jacobian is applied
+      });
+      // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu
+      // (control/iterative_ilqr.py:128-129 before the state Jacobian is applied), one row b of
+      // Y = Quu Kc at a time: [W | w][i][j] -= Y[b][i] [Kc | k][b][j]
       I2LQR_PHASE_FENCE();
+      static_for<0, m>([&](auto b_) {
+        constexpr int bb = decltype(b_)::value;
+        T y[n], kb[n + 1];
+        asm volatile("" : "+v"(lrd));  // this pass reads its words again (no reuse across passes)
 #pragma unroll
-      for (int i = 0; i < n; i++) {
-        T ktq[m];
+        for (int i = 0; i < n; i++) y[i] = T(0);
+        static_for<0, m>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
 #pragma unroll
-        for (int bb = 0; bb < m; bb++) {
-          T acc = T(0);
+          for (int i = 0; i < n; i++) {
+            const T kai = kcs[(a * (n + 1) + i) * 64 + lrd];
+            if constexpr (a == bb) kb[i] = kai;
+            y[i] = t_fma(Quu[bb * m + a], kai, y[i]);
+          }
+        });
+        kb[n] = kcs[(bb * (n + 1) + n) * 64 + lrd];
 #pragma unroll
-          for (int a = 0; a < m; a++) acc = t_fma(G[a][i], Quu[a * m + bb], acc);
-          ktq[bb] = acc;
+        for (int i = 0; i < n; i++) {
+#pragma unroll
+          for (int j = i; j < n; j++) V[i][j] = t_fma(-y[i], kb[j], V[i][j]);
+          vx[i] = t_fma(-y[i], kb[n], vx[i]);
         }
-#pragma unroll
-        for (int j = i; j <= n; j++) {
-          T acc = T(0);
-#pragma unroll
-          for (int bb = 0; bb < m; bb++) acc = t_fma(ktq[bb], G[bb][j], acc);
-          if (j == n) vx[i] = vx[i] - acc;
-          else V[i][j] = V[i][j] - acc;
-        }
-      }
-      // K = Kc A, then the gains leave the registers
+      });
+      // K = Kc A row by row, then straight to HBM
       I2LQR_PHASE_FENCE();
+      STAMP_END(1);
       {  // the A entries of the Jacobian, formed again (hidden from value numbering: the compiler
          // would otherwise keep the first evaluation's 25 doubles live through the phases above)
         T xr[n], ur[m], trr[NT];
@@ -1081,19 +1147,29 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         for (int q = 0; q < NT; q++) opaque(trr[q]);
         Sys::jac_var(c, xr, ur, trr, jv);
       }
-      static_for<0, Sys::NBLK>([&](auto b_) { block_gains<decltype(b_)::value>(G, jv); });
-      for_rows<m * n>(gK, rK(0, 0, t), [&](auto e_, T& w) {
-        constexpr int e = decltype(e_)::value;
-        w = G[e / n][e % n];
-      });
-      for_rows<m>(gk, ru(0, t), [&](auto a_, T& w) { w = G[decltype(a_)::value][n]; });
-      // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1}
-      I2LQR_PHASE_FENCE();
-      if (t >= 1) {
-        for_rows<n>(X, rx(0, t), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
-        for_rows<NP>(X, rx(0, t - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
-        for_rows<m>(U, ru(0, t - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
+      // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1} — issued BEFORE
+      // the step's 52 gain stores: loads and stores share one in-order counter, so the wait for
+      // these loads at the top of the next step leaves the stores in flight instead of draining
+      // them.  (Step 0 loads the rows of step 1 again: no branch.)
+      {
+        const int tl = t >= 1 ? t : 1;
+        for_rows<n>(X, rx(0, tl), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
+        for_rows<NP>(X, rx(0, tl - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
+        for_rows<m>(U, ru(0, tl - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
       }
+      static_for<0, m>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        T g[n];
+        asm volatile("" : "+v"(lrd));
+#pragma unroll
+        for (int j = 0; j < n; j++) g[j] = kcs[(a * (n + 1) + j) * 64 + lrd];
+        static_for<0, Sys::NBLK>([&](auto b_) { block_gain_row<decltype(b_)::value>(g, jv); });
+        for_rows<n>(gK, rK(a, 0, t), [&](auto j_, T& w) { w = g[decltype(j_)::value]; });
+      });
+      for_rows<m>(gk, ru(0, t), [&](auto a_, T& w) {
+        w = kcs[(decltype(a_)::value * (n + 1) + n) * 64 + lrd];
+      });
+      STAMP_END(2);
       // [Vxx' | Vx'] = [l_xx | l_x] + A^T [W A | w], block after block
       static_for<0, Sys::NBLK>([&](auto b_) {
         I2LQR_PHASE_FENCE();
@@ -1109,6 +1185,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
       V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
       vx[0] += o[0]; vx[1] += o[1];
+      STAMP_END(3);
     }
     return bad;
   }
@@ -1222,19 +1299,20 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   }
 
   // -- forward pass of the row-block plants: control/iterative_ilqr.py:133-160 ------------------
-  // The deferred form of forward(): the feedback law reads the nominal states, the candidate
-  // inputs go to Un, no candidate state is stored (an accepted step re-rolls them:
-  // restore_rows()).  Same arithmetic, word for word, as forward<false, false>; the step's 68
-  // words are loaded one step ahead through row groups.  x_0 is common to the nominal and the
-  // candidate: K_0 multiplies zeros and is not read.
+  // The deferred, re-rolling form of forward(): the nominal states the feedback law needs are
+  // re-rolled from the nominal inputs next to the candidate (bit-identical to the stored X: same
+  // code, same inputs), the candidate inputs go to Un, no candidate state is stored (an accepted
+  // step re-rolls them: restore_rows()).  Same arithmetic, word for word, as forward<true, false>;
+  // the step's 56 words are loaded one step ahead through row groups.
   template <bool GENERAL>
   __device__ __forceinline__ T forward_rows(const T* X, const T* U, const T* gK, const T* gk, T* Un,
                                             const T (&xT)[n], bool* bad) const {
     T x[n], u[m], xn[n], tr[NT];
-    T xl[n], ul[m], kl[m][n + 1];
+    T xo[n], ul[m], kl[m][n + 1];  // nominal state (re-rolled), nominal inputs and gains of the step
     for_rows<n>(X, rx(0, 0), [&](auto i_, const T& w) { x[decltype(i_)::value] = w; });
+    // step 0: x_0 is common to the nominal and the candidate, K_0 multiplies zeros and is not read
 #pragma unroll
-    for (int i = 0; i < n; i++) xl[i] = x[i];
+    for (int i = 0; i < n; i++) xo[i] = x[i];
     for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
     for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
 #pragma unroll
@@ -1243,24 +1321,34 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       for (int j = 0; j < n; j++) kl[a][j] = T(0);
     T cost = T(0);
     for (int t = 0; t < N; t++) {
+      T uo[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kl[a][j], x[j] - xl[j], acc);
+        for (int j = 0; j < n; j++) acc = t_fma(kl[a][j], x[j] - xo[j], acc);
         u[a] = clip(ul[a] + kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        uo[a] = ul[a];
       }
-      if (t + 1 < N) {
-        for_rows<n>(X, rx(0, t + 1), [&](auto i_, const T& w) { xl[decltype(i_)::value] = w; });
-        for_rows<m>(U, ru(0, t + 1), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
-        for_rows<m * n>(gK, rK(0, 0, t + 1), [&](auto e_, const T& w) {
+      {  // the words of step t + 1 (the last step loads its own again: no branch)
+        const int tl = t + 1 < N ? t + 1 : t;
+        for_rows<m>(U, ru(0, tl), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
+        for_rows<m * n>(gK, rK(0, 0, tl), [&](auto e_, const T& w) {
           constexpr int e = decltype(e_)::value;
           kl[e / n][e % n] = w;
         });
-        for_rows<m>(gk, ru(0, t + 1), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
+        for_rows<m>(gk, ru(0, tl), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
       }
       for_rows<m>(Un, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
-      Sys::template trig_g<GENERAL>(x, tr, bad);
+      // nominal state of step t + 1, re-rolled from the nominal inputs (the pass streams the gains
+      // at the HBM rate and has issue slots to spare: n fewer rows to read per step)
+      if constexpr (GENERAL) Sys::trig(xo, tr);
+      else Sys::trig_s(xo, tr, bad);
+      Sys::step_tr(c, xo, uo, tr, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) xo[i] = xn[i];
+      if constexpr (GENERAL) Sys::trig(x, tr);
+      else Sys::trig_s(x, tr, bad);
       Sys::step_tr(c, x, u, tr, xn);
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
@@ -1292,7 +1380,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       if (t + 1 < N) load_u(t + 1);
       if constexpr (MERGE)
         for_rows<m>(U, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
-      Sys::template trig_g<GENERAL>(x, tr, &bad);
+      if constexpr (GENERAL) Sys::trig(x, tr);
+      else Sys::trig_s(x, tr, &bad);
       Sys::step_tr(c, x, u, tr, xn);
       for_rows<n>(X, rx(0, t + 1), [&](auto i_, T& w) { w = xn[decltype(i_)::value]; });
 #pragma unroll
@@ -1507,6 +1596,7 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   T* const X = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
+  __shared__ T lds_gains[LaneWorker<T, Sys, false, TILED>::kGainWords];
   T cost = w.rollout(X, Uc, xT);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
@@ -1514,13 +1604,20 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   const bool general = !(sizeof(T) == 8 && c.fast_barrier);  // configurations outside the hot form
   while (it < a.n_iters && it0 + it < a.max_total) {
     // hot, branch-free passes first; the general forms only if a lane asked for them
-    if (__builtin_expect(__any(general || w.template backward_blocked<true, false>(X, Uc, xT, ob, lamb, gK, gk)), 0))
-      w.template backward_blocked<true, true>(X, Uc, xT, ob, lamb, gK, gk);
+    if (__builtin_expect(__any(general || w.template backward_blocked<true, false>(X, Uc, xT, ob, lamb, gK, gk, lds_gains)), 0))
+      w.template backward_blocked<true, true>(X, Uc, xT, ob, lamb, gK, gk, lds_gains);
     bool big = false;
+#ifdef I2LQR_STAMPS
+    auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+    STAMP_BEGIN();
+#endif
     T cost_new = w.template forward_rows<false>(X, Uc, gK, gk, Un, xT, &big);
     if (__builtin_expect(__any(big), 0))
       cost_new = w.template forward_rows<true>(X, Uc, gK, gk, Un, xT, &big);
     it++;
+#ifdef I2LQR_STAMPS
+    STAMP_END(4);
+#endif
     const bool accepted = cost_new < cost;
     if (__all(accepted)) {  // the two input buffers change roles for the whole wavefront
       T* tp = Uc; Uc = Un; Un = tp;
@@ -1530,6 +1627,9 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
       if (__builtin_expect(__any(w.template restore_rows<true, false>(X, Uc, Un, accepted)), 0))
         w.template restore_rows<true, true>(X, Uc, Un, accepted);
     }
+#ifdef I2LQR_STAMPS
+    STAMP_END(5);
+#endif
     if (accepted) {  // control/iterative_ilqr.py:74-80
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
@@ -1557,6 +1657,10 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   a.cost[b] = cost_ret;
   if (a.iters) a.iters[b] = it0 + it;
   if (a.status) a.status[b] = status;
+#ifdef I2LQR_STAMPS
+  if (a.dbg && threadIdx.x == 0)
+    for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,36 +30,49 @@ template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 // common case has no branch inside the loop at all, so the compiler can interleave the polynomial
 // with the neighbouring arithmetic (a branch ends the scheduling region, and a TAKEN branch costs
 // a wavefront alone on its SIMD ~100 cycles: tools/ubench_issue.hip).
+// SLIT (the one-problem-per-lane kernels of the row-block plants, where registers are the scarce
+// resource): every fp64 literal is placed in SCALAR registers at its point of use.  A v_fma_f64
+// cannot encode a 64-bit literal, and the compiler otherwise materialises each one in a vector
+// register pair, hoists the pair out of the horizon loop as an invariant — ~35 literals of exp /
+// sincos = 70 vector registers — and spills it to scratch.  Same values, same arithmetic.
+template <bool SLIT> __device__ __forceinline__ double t_lit(double v) {
+  if constexpr (SLIT) asm volatile("" : "+s"(v));
+  return v;
+}
 template <class T> __device__ __forceinline__ void t_sincos_fast(T x, T* s, T* c, bool* big_out);
-template <> __device__ __forceinline__ void t_sincos_fast<double>(double x, double* s, double* c,
-                                                                   bool* big_out) {
-  const bool big = !(__builtin_fabs(x) < 1.0e5);
+template <bool SLIT>
+__device__ __forceinline__ void t_sincos_fast_d(double x, double* s, double* c, bool* big_out) {
+  const bool big = !(__builtin_fabs(x) < t_lit<SLIT>(1.0e5));
   *big_out = *big_out || big;
   const double xs = big ? 0.0 : x;
-  const double kf = __builtin_rint(xs * 6.36619772367581382433e-01);  // 2/pi
-  double r = __builtin_fma(-kf, 1.57079632679489655800e+00, xs);     // pi/2 hi
-  r = __builtin_fma(-kf, 6.12323399573676603587e-17, r);            // pi/2 mid
-  r = __builtin_fma(-kf, -1.49738490485916983327e-33, r);           // pi/2 lo
+  const double kf = __builtin_rint(xs * t_lit<SLIT>(6.36619772367581382433e-01));  // 2/pi
+  double r = __builtin_fma(-kf, t_lit<SLIT>(1.57079632679489655800e+00), xs);     // pi/2 hi
+  r = __builtin_fma(-kf, t_lit<SLIT>(6.12323399573676603587e-17), r);            // pi/2 mid
+  r = __builtin_fma(-kf, t_lit<SLIT>(-1.49738490485916983327e-33), r);           // pi/2 lo
   const int q = (int)kf;
   const double z = r * r;
-  double ps = 1.58969099521155010221e-10;
-  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  double ps = t_lit<SLIT>(1.58969099521155010221e-10);
+  ps = __builtin_fma(ps, z, t_lit<SLIT>(-2.50507602534068634195e-08));
+  ps = __builtin_fma(ps, z, t_lit<SLIT>(2.75573137070700676789e-06));
+  ps = __builtin_fma(ps, z, t_lit<SLIT>(-1.98412698298579493134e-04));
+  ps = __builtin_fma(ps, z, t_lit<SLIT>(8.33333333332248946124e-03));
+  ps = __builtin_fma(ps, z, t_lit<SLIT>(-1.66666666666666324348e-01));
   const double sr = __builtin_fma(ps * z, r, r);
-  double pc = -1.13596475577881948265e-11;
-  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  double pc = t_lit<SLIT>(-1.13596475577881948265e-11);
+  pc = __builtin_fma(pc, z, t_lit<SLIT>(2.08757232129817482790e-09));
+  pc = __builtin_fma(pc, z, t_lit<SLIT>(-2.75573143513906633035e-07));
+  pc = __builtin_fma(pc, z, t_lit<SLIT>(2.48015872894767294178e-05));
+  pc = __builtin_fma(pc, z, t_lit<SLIT>(-1.38888888888741095749e-03));
+  pc = __builtin_fma(pc, z, t_lit<SLIT>(4.16666666666666019037e-02));
   const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
   const bool swap = q & 1;
   const double sv = swap ? cr : sr, cv = swap ? sr : cr;
   *s = (q & 2) ? -sv : sv;
   *c = ((q + 1) & 2) ? -cv : cv;
+}
+template <> __device__ __forceinline__ void t_sincos_fast<double>(double x, double* s, double* c,
+                                                                   bool* big_out) {
+  t_sincos_fast_d<false>(x, s, c, big_out);
 }
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
   // The short kernel runs unconditionally and the library routine, which only arguments of
@@ -117,49 +130,66 @@ template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, f
 template <class T> __device__ __forceinline__ T t_exp(T x);
 // fp64 exp: x = k ln2 + r (Cody-Waite), degree-13 Horner on |r| <= ln2/2, v_ldexp (<= ~2 ulp;
 // overflow / underflow / NaN through ldexp and the clamped exponent).
+// exp of NE arguments at once with the SLIT literals shared: e[q] = t_exp(x[q]) for q < NE - NB,
+// t_exp_bounded(x[q]) for the last NB (bit for bit the single-argument functions below)
+template <bool SLIT, int NE, int NB>
+__device__ __forceinline__ void t_exp_d(const double (&x0)[NE], double (&e)[NE]) {
+  double x[NE], kf[NE], r[NE], p[NE];
+#pragma unroll
+  for (int q = 0; q < NE; q++)
+    x[q] = q < NE - NB ? (x0[q] < t_lit<SLIT>(-746.0) ? -746.0 : (x0[q] > t_lit<SLIT>(710.0) ? 710.0 : x0[q]))
+                       : x0[q];  // NaN passes through
+  const double l2e = t_lit<SLIT>(1.44269504088896338700e+00);
+#pragma unroll
+  for (int q = 0; q < NE; q++) kf[q] = __builtin_rint(x[q] * l2e);
+  const double ln2h = t_lit<SLIT>(6.93147180369123816490e-01);
+#pragma unroll
+  for (int q = 0; q < NE; q++) r[q] = __builtin_fma(-kf[q], ln2h, x[q]);
+  const double ln2l = t_lit<SLIT>(1.90821492927058770002e-10);
+#pragma unroll
+  for (int q = 0; q < NE; q++) r[q] = __builtin_fma(-kf[q], ln2l, r[q]);
+  const double c13 = t_lit<SLIT>(1.6059043836821614599e-10);  // 1/13!
+#pragma unroll
+  for (int q = 0; q < NE; q++) p[q] = c13;
+#define I2LQR_EXP_STEP(lit)                                          \
+  {                                                                  \
+    const double ck = t_lit<SLIT>(lit);                              \
+    _Pragma("unroll") for (int q = 0; q < NE; q++) p[q] = __builtin_fma(p[q], r[q], ck); \
+  }
+  I2LQR_EXP_STEP(2.0876756987868098979e-09)
+  I2LQR_EXP_STEP(2.5052108385441718775e-08)
+  I2LQR_EXP_STEP(2.7557319223985890653e-07)
+  I2LQR_EXP_STEP(2.7557319223985892511e-06)
+  I2LQR_EXP_STEP(2.4801587301587301566e-05)
+  I2LQR_EXP_STEP(1.9841269841269841253e-04)
+  I2LQR_EXP_STEP(1.3888888888888889419e-03)
+  I2LQR_EXP_STEP(8.3333333333333332177e-03)
+  I2LQR_EXP_STEP(4.1666666666666664354e-02)
+  I2LQR_EXP_STEP(1.6666666666666665741e-01)
+#undef I2LQR_EXP_STEP
+#pragma unroll
+  for (int q = 0; q < NE; q++) {
+    p[q] = __builtin_fma(p[q], r[q], 0.5);
+    p[q] = __builtin_fma(p[q], r[q], 1.0);
+    p[q] = __builtin_fma(p[q], r[q], 1.0);
+    const double v = __builtin_ldexp(p[q], (int)kf[q]);
+    e[q] = q < NE - NB ? (x0[q] < t_lit<SLIT>(-745.14) ? 0.0 : (x0[q] > t_lit<SLIT>(709.79) ? __builtin_inf() : v))
+                       : v;
+  }
+}
 template <> __device__ __forceinline__ double t_exp<double>(double x0) {
-  const double x = x0 < -746.0 ? -746.0 : (x0 > 710.0 ? 710.0 : x0);  // NaN passes through
-  const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
-  double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
-  r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;  // 1/13!
-  p = __builtin_fma(p, r, 2.0876756987868098979e-09);
-  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
-  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
-  p = __builtin_fma(p, r, 2.7557319223985892511e-06);
-  p = __builtin_fma(p, r, 2.4801587301587301566e-05);
-  p = __builtin_fma(p, r, 1.9841269841269841253e-04);
-  p = __builtin_fma(p, r, 1.3888888888888889419e-03);
-  p = __builtin_fma(p, r, 8.3333333333333332177e-03);
-  p = __builtin_fma(p, r, 4.1666666666666664354e-02);
-  p = __builtin_fma(p, r, 1.6666666666666665741e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  const double e = __builtin_ldexp(p, (int)kf);
-  return x0 < -745.14 ? 0.0 : (x0 > 709.79 ? __builtin_inf() : e);
+  const double xa[1] = {x0};
+  double ea[1];
+  t_exp_d<false, 1, 0>(xa, ea);
+  return ea[0];
 }
 // The same without the range handling, for arguments known to lie in [-700, 700].
 template <class T> __device__ __forceinline__ T t_exp_bounded(T x);
 template <> __device__ __forceinline__ double t_exp_bounded<double>(double x) {
-  const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
-  double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
-  r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;
-  p = __builtin_fma(p, r, 2.0876756987868098979e-09);
-  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
-  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
-  p = __builtin_fma(p, r, 2.7557319223985892511e-06);
-  p = __builtin_fma(p, r, 2.4801587301587301566e-05);
-  p = __builtin_fma(p, r, 1.9841269841269841253e-04);
-  p = __builtin_fma(p, r, 1.3888888888888889419e-03);
-  p = __builtin_fma(p, r, 8.3333333333333332177e-03);
-  p = __builtin_fma(p, r, 4.1666666666666664354e-02);
-  p = __builtin_fma(p, r, 1.6666666666666665741e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)kf);
+  const double xa[1] = {x};
+  double ea[1];
+  t_exp_d<false, 1, 1>(xa, ea);
+  return ea[0];
 }
 template <> __device__ __forceinline__ float t_exp_bounded<float>(float x) { return __expf(x); }
 // fp32 exp: the hardware exp2 path (v_exp_f32), ~2 ulp
@@ -666,6 +696,15 @@ template <class T> struct Quad12 {
       t_sincos_fast(xe[4], &tr[2], &tr[3], bad);
       t_sincos_fast(xe[5], &tr[4], &tr[5], bad);
     }
+  }
+  // hot form with scalar-register literals (LaneWorker::backward_blocked and friends)
+  static __device__ __forceinline__ void trig_s(const double (&xe)[n], double (&tr)[NTRIG], bool* bad) {
+    t_sincos_fast_d<true>(xe[3], &tr[0], &tr[1], bad);
+    t_sincos_fast_d<true>(xe[4], &tr[2], &tr[3], bad);
+    t_sincos_fast_d<true>(xe[5], &tr[4], &tr[5], bad);
+  }
+  static __device__ __forceinline__ void trig_s(const float (&xe)[n], float (&tr)[NTRIG], bool* bad) {
+    trig_g<false>(xe, tr, bad);
   }
   // The three angles on three lanes at once: `g` is the lane's index inside a 16-lane DPP row whose
   // lanes all hold the same xe; lane q < 3 evaluates angle q, the results are broadcast along the

@@ -883,6 +883,106 @@ def test_quad12_full_size_properties_and_oracle_sample(torch_mod):
     assert batch_rel_err(a["k"][tidx].cpu().numpy()[same], ref["k"][same], floor=1.0) < 1e-6
 
 
+@pytest.mark.parametrize("layout_id,B", [(1, 100), (2, 192)])
+def test_quad12_one_problem_per_lane_kernel_vs_oracle(torch_mod, layout_id, B):
+    """configs[4] shape on the batch-minor / batch-tiled layouts: k_lane_iterate_rows (one problem
+    per lane, row-block form of the Riccati step, gains staged through LDS) against the CPU oracle
+    — fused iterations with gains, the solve to termination, a ragged batch on the batch-minor
+    layout — plus the bit-exact replay properties of the other kernel families."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    orc = oracle()
+    cfg = default_config("quad12", 50, "f64", dt=0.02, layout=layout_id)
+    solver = BatchedILQR(cfg)
+    assert solver.iterate_kernel(B) == "k_lane_iterate_rows"
+    host = workloads.make_batch(cfg, B)
+    host["lamb"] = 10.0 ** np.random.default_rng(2).integers(-2, 2, B).astype(float)
+    iters = 4
+    it = solver.iterate(dev_batch(solver, host), iters)
+    so = solver.solve(dev_batch(solver, host))
+    ref_it = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"],
+                            max_iter=iters, early_exit=False)
+    ref_so = orc.ilqr_batch(cfg, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"])
+    assert (it["iters"].cpu().numpy() == iters).all()
+    same = it["lamb"].cpu().numpy() == ref_it["lamb"]
+    assert same.mean() >= 0.97, same.mean()
+    _check_flipped(it, ref_it, same, 1e-6)
+    for key in ("X", "U"):
+        assert batch_rel_err(to_host(solver, it[key])[same], ref_it[key][same]) < TOL_SOLVE, key
+    np.testing.assert_allclose(it["cost"].cpu().numpy()[same], ref_it["cost"][same], rtol=1e-7)
+    assert batch_rel_err(to_host(solver, it["K"])[same], ref_it["K"][same]) < 1e-6
+    assert batch_rel_err(to_host(solver, it["k"])[same], ref_it["k"][same], floor=1.0) < 1e-6
+    same = (so["iters"].cpu().numpy() == ref_so["iters"]) & (so["lamb"].cpu().numpy() == ref_so["lamb"])
+    assert same.mean() >= 0.97, same.mean()
+    _check_flipped(so, ref_so, same, cfg.eps)
+    assert (so["status"].cpu().numpy()[same] == ref_so["status"][same]).all()
+    assert batch_rel_err(to_host(solver, so["X"])[same], ref_so["X"][same]) < TOL_SOLVE
+    # replay properties: 2 + 2 fused iterations == 4, returned X is the rollout of returned U
+    two = solver.iterate(solver.iterate(dev_batch(solver, host), 2), 2)
+    for key in ("X", "U", "lamb", "cost", "K", "k"):
+        assert torch.equal(it[key], two[key]), key
+    X2, U2 = it["X"].clone(), it["U"].clone()
+    cost2 = solver.rollout(X2, U2, it["x_term"])
+    assert torch.equal(U2, it["U"]) and torch.equal(X2, it["X"]) and torch.equal(cost2, it["cost"])
+    # stage weights are not built for this plant on these layouts: a clear error, no fallback
+    from ilqr_iterative_tasks_amd.solver import I2lqrError
+    wcfg = default_config("quad12", 50, "f64", dt=0.02, layout=layout_id)
+    wcfg.set_matrix("R", 0.01 * np.eye(4))
+    ws = BatchedILQR(wcfg)
+    with pytest.raises(I2lqrError, match="Q = R = 0"):
+        ws.iterate(dev_batch(ws, workloads.make_batch(wcfg, 64)), 1)
+
+
+def test_quad12_full_size_on_the_lane_kernel(torch_mod):
+    """BASELINE configs[4] at its full size (n=12, m=4, N=50, B=65536, fp64) on the batch-tiled
+    layout (what bench.py measures): size-independent properties over the whole batch and the CPU
+    oracle on a strided sample of 256 problems spanning the index range; the chunked solve to
+    termination against the oracle on the same sample."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    cfg = default_config("quad12", 50, "f64", dt=0.02, layout=2)
+    solver = BatchedILQR(cfg)
+    B, iters = 65536, 4
+    host = workloads.make_batch(cfg, B)
+    a = solver.iterate(dev_batch(solver, host), iters)
+    b = solver.iterate(dev_batch(solver, host), iters)
+    for key in ("X", "U", "lamb", "cost", "K", "k"):
+        assert torch.equal(a[key], b[key]), key
+    del b
+    assert int(a["iters"].min()) == iters == int(a["iters"].max())
+    X2, U2 = a["X"].clone(), a["U"].clone()
+    cost2 = solver.rollout(X2, U2, a["x_term"])
+    assert torch.equal(U2, a["U"]) and torch.equal(X2, a["X"]) and torch.equal(cost2, a["cost"])
+    assert torch.isfinite(a["cost"]).all() and (a["cost"] >= 0).all()
+    U_pm = solver.to_problem_major(a["U"])
+    u_max = torch.tensor(list(cfg.u_max)[:cfg.m], dtype=solver.dtype, device=solver.device)
+    assert (U_pm.abs() <= u_max[None, :, None]).all()
+    idx = np.unique(np.concatenate([np.arange(0, B, B // 255), [B - 1, B - 2, B - 3]]))
+    orc = oracle()
+    ref = orc.ilqr_batch(cfg, host["X"][idx], host["U"][idx], host["x_term"][idx],
+                         host["lamb"][idx], host["obs"][idx], max_iter=iters, early_exit=False)
+    tidx = torch.as_tensor(idx, device=solver.device)
+    pm = {key: solver.to_problem_major(a[key])[tidx].cpu().numpy() for key in ("X", "U", "K", "k")}
+    same = a["lamb"][tidx].cpu().numpy() == ref["lamb"]
+    assert same.mean() >= 0.97
+    _check_flipped({key: a[key][tidx] for key in ("cost", "status")}, ref, same, 1e-6)
+    for key in ("X", "U"):
+        assert batch_rel_err(pm[key][same], ref[key][same]) < TOL_SOLVE, key
+    assert batch_rel_err(pm["K"][same], ref["K"][same]) < 1e-6
+    assert batch_rel_err(pm["k"][same], ref["k"][same], floor=1.0) < 1e-6
+    del a
+    so = solver.solve(dev_batch(solver, host))  # chunked, compacting
+    ref = orc.ilqr_batch(cfg, host["X"][idx], host["U"][idx], host["x_term"][idx],
+                         host["lamb"][idx], host["obs"][idx])
+    same = (so["iters"][tidx].cpu().numpy() == ref["iters"]) & (so["lamb"][tidx].cpu().numpy() == ref["lamb"])
+    assert same.mean() >= 0.97
+    _check_flipped({key: so[key][tidx] for key in ("cost", "status")}, ref, same, cfg.eps)
+    assert (so["status"][tidx].cpu().numpy()[same] == ref["status"][same]).all()
+    Xs = solver.to_problem_major(so["X"])[tidx].cpu().numpy()
+    assert batch_rel_err(Xs[same], ref["X"][same]) < TOL_SOLVE
+    assert set(np.unique(so["status"].cpu().numpy())) <= {1, 2, 3}
+
+
 def test_negative_curvature_takes_the_eigenvalue_clamping_path(torch_mod, layout):
     """The kernels invert a positive-definite Quu directly and fall back to the reference's
     eig / clamp-negative / add-lamb construction (control/iterative_ilqr.py:118-123) otherwise.

@@ -16,8 +16,9 @@ from ilqr_iterative_tasks_amd import BatchedILQR
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f64"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-iters = 10
-cfg = workloads.config_for("config2", dtype)
+WL = os.environ.get("WORKLOAD", "config2")  # config5: quad12 (k_lane_iterate_rows)
+iters = 4 if WL == "config5" else 10
+cfg = workloads.config_for(WL, dtype)
 cfg.layout = 2
 solver = BatchedILQR(cfg)
 for kv in sys.argv[3:]:
@@ -36,6 +37,9 @@ torch.cuda.synchronize()
 d = dbg.double().mean(0).cpu().numpy() / iters
 names = ["bwd trig+jac+barriers+loads", "bwd Riccati products", "bwd inverse+gains+store",
          "bwd value update", "forward", "accept/reject (+re-roll)", "-", "-"]
+if WL == "config5":
+    names = ["bwd trig+jac+barriers", "bwd G, Quu, inverse, Kc, W", "bwd K = Kc A, loads, gain stores",
+             "bwd state blocks", "forward", "re-roll", "bwd loop top (wait for loads)", "-"]
 tot = d.sum()
 for nm, v in zip(names, d):
     print(f"{nm:30s} {v:9.0f} ticks/iteration  {100 * v / tot:5.1f} %  ({v / cfg.N:7.0f} per step)")
