@@ -111,10 +111,17 @@ def spawn_ranks(args) -> int:
 # wavefront kernel (tools/ab_bench.py, tools/solve_bench.py; fp64, n=6, N=20):
 #   iterate: 8192: 165 vs 152 M it/s, 12288: 171 vs 223;  solve: 8192: 1.18 vs 1.68 ms,
 #   16384: 1.80 vs 1.81 ms, 65536: 5.6 vs 2.5 ms
-# The kernel's launch duration is measured live with HIP events on the launch stream around every
-# EVENT_STRIDE-th timed step (25 samples of the default 200 steps): an event pair around EVERY
-# launch costs the timed region 5 us per 220 us step in marker packets.
-EVENT_STRIDE = 8
+# The kernel's launch duration is measured live with HIP events on the launch stream around
+# KERNEL_SAMPLES evenly spaced timed steps (an event pair around EVERY launch costs the timed region
+# 5 us per 220 us step in marker packets): 10 samples at the driver's --steps 20 and at the default
+# 200 alike.  The cost of an EMPTY event pair (measured after the timed region, median of 20) is
+# subtracted: the two marker packets themselves sit inside the bracket, and at 0.2 ms per launch
+# they are 5 % of it (rocprofv3's kernel duration, profiles/, is the check).  Secondary workloads:
+# EXTRA_LAUNCHES individually bracketed launches after EXTRA_WARMUP, median and spread reported.
+KERNEL_SAMPLES = 10
+EXTRA_LAUNCHES = 20
+EXTRA_WARMUP = 3
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec; = 1024 SIMDs x 16 lanes x 2 x 2.4 GHz)
 LANE_THRESHOLD = 10240
 LANE_THRESHOLD_SOLVE = 16384
 QUAD_LANE_THRESHOLD = 8192
@@ -163,6 +170,32 @@ def make_step_buffers(solver, host, n_sets, torch):
         buf.update(X=X0.clone(), U=U0.clone(), lamb=l0.clone())
         sets.append(buf)
     return sets
+
+
+def event_stride_for(steps):
+    return max(1, steps // KERNEL_SAMPLES)
+
+
+def empty_bracket_ms(torch, n=20):
+    """Median duration HIP reports for an event pair with nothing in between (the marker packets)."""
+    torch.cuda.synchronize()
+    vals = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        torch.cuda.synchronize()
+        vals.append(a.elapsed_time(b))
+    vals.sort()
+    return vals[len(vals) // 2]
+
+
+def spread(vals):
+    """median, min, max and (max - min) / median of a list of durations."""
+    v = sorted(vals)
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    return {"median": med, "min": v[0], "max": v[-1], "rel_spread": (v[-1] - v[0]) / med,
+            "samples": len(v)}
 
 
 def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True,
@@ -260,11 +293,16 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         rank_seconds = [float(x.item()) for x in allt]
         seconds = max(rank_seconds)
     timed = range(0, steps, event_stride)
-    kern_ms = sum(ev0[i].elapsed_time(ev1[i]) for i in timed) / len(timed)
+    overhead = empty_bracket_ms(torch)
+    raw = [ev0[i].elapsed_time(ev1[i]) for i in timed]
+    kstat = spread([max(v - overhead, 0.0) for v in raw])
+    kern_ms = kstat["median"]
     # every problem executes exactly `iters` iterations (no early exit): check on the last set
     assert int(sets[-1]["iters"].min()) == args.iters == int(sets[-1]["iters"].max())
     kernel = solver.iterate_kernel(B)
-    res = dict(seconds=seconds, kernel_ms=kern_ms, iterations=world * B * args.iters * steps,
+    res = dict(seconds=seconds, kernel_ms=kern_ms, kernel_ms_stats=kstat,
+               kernel_ms_raw_median=spread(raw)["median"], event_pair_overhead_ms=overhead,
+               iterations=world * B * args.iters * steps,
                rank_seconds=rank_seconds, kernel=kernel,
                layout=(LAYOUT_NAME[layout] if kernel != "k_group_iterate" else
                        "problem-major (eight problems per wavefront)"))
@@ -286,6 +324,56 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 res["native_exchange_error"] = native_error
     solver.close()
     return res
+
+
+def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EXTRA_WARMUP):
+    """`launches` individually bracketed i2lqr_iterate launches after `warmup` untimed ones, each
+    on its OWN copy of the batch (allocated and filled before the first launch: no launch finds its
+    inputs warm in the 256 MB Infinity Cache because a restore copy has just written them):
+    median / min / max kernel time (empty-bracket overhead subtracted)."""
+    from ilqr_iterative_tasks_amd import BatchedILQR, workloads
+    cfg = cfg.copy()
+    layout = pick_layout(args, B, cfg=cfg)
+    cfg.layout = LAYOUT_ID[layout]
+    solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
+    host = workloads.make_batch(cfg, B)
+    sets = make_step_buffers(solver, host, warmup + launches, torch)
+    overhead = empty_bracket_ms(torch)
+    vals = []
+    for i in range(warmup + launches):
+        buf = sets[i]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        solver.iterate(buf, iters)
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= warmup:
+            vals.append(max(e0.elapsed_time(e1) - overhead, 0.0))
+    assert int(sets[-1]["iters"].min()) == iters == int(sets[-1]["iters"].max())
+    kernel = solver.iterate_kernel(B)
+    name = (LAYOUT_NAME[layout] if kernel not in ("k_group_iterate", "k_quad_iterate") else
+            {"k_group_iterate": "problem-major (eight problems per wavefront)",
+             "k_quad_iterate": "problem-major (four problems per wavefront)"}[kernel])
+    solver.close()
+    st = spread(vals)
+    return {"kernel": kernel, "layout": name, "kernel_ms": st["median"], "kernel_ms_min": st["min"],
+            "kernel_ms_max": st["max"], "kernel_ms_rel_spread": st["rel_spread"],
+            "launches": st["samples"], "warmup": warmup,
+            "iterations_per_s": B * iters / (st["median"] * 1e-3)}
+
+
+def roofline_entry(cfg, B, iters, r, traffic):
+    """HBM (and fp64) fractions of one timed workload from its median kernel time."""
+    from ilqr_iterative_tasks_amd import workloads
+    bts = workloads.algorithmic_bytes_per_iteration(cfg)
+    ach = bts * B * iters / (r["kernel_ms"] * 1e-3) / 1e9
+    out = dict(r)
+    out.update({"batch": B, "iterations_per_launch": iters,
+                "algorithmic_bytes_per_iteration": bts, "achieved_GBs": ach,
+                "hbm_frac": ach / HBM_PEAK_GBS, "traffic": traffic})
+    if traffic:
+        out["traffic_over_algorithmic"] = traffic / (bts * B * iters)
+    return out
 
 
 def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
@@ -357,33 +445,62 @@ def issue_roofline(pmc, key, kernel_ms, waves):
     wavefront issues at most one instruction per 4 cycles, whatever the instruction
     (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').  achieved = wavefront-instructions
     issued per second (SQ_INSTS_VALU + SALU + LDS + ... = SQ_INSTS of the --pmc pass, per launch,
-    / the kernel time measured here); peak = occupied SIMDs x clock / 4."""
+    / the kernel time measured here); peak = SIMDs occupied by ALL launched wavefronts x clock / 4
+    (helper wavefronts included: their instructions are in the numerator, so their SIMDs are in
+    the denominator)."""
     insts = pmc.get(key, "wave_instructions_per_launch")
-    simds = min(waves, SIMDS)
+    launched = pmc.get(key, "waves_per_launch")
+    occupied = int(launched) if launched and launched > waves else waves
+    simds = min(occupied, SIMDS)
     peak = simds * CLOCK_GHZ / 4.0  # G wave-instructions / s
     out = {"bound": "issue", "unit": "G wavefront-instructions/s", "peak": peak,
            "simds_occupied": simds, "achieved": None, "frac": None,
            "wave_instructions_per_launch": insts}
-    launched = pmc.get(key, "waves_per_launch")
-    if launched and launched > waves:
+    if occupied > waves:
         # k_group_iterate up to 2048 problems: two helper wavefronts per workgroup take a share of
-        # the per-step records and sleep at a barrier otherwise; the roofline is that of the SIMDs
-        # that carry the serial recursion (their instructions are in the count)
-        out["helper_wavefronts"] = int(launched - waves)
+        # the per-step records and sleep at a barrier otherwise
+        out["helper_wavefronts"] = int(occupied - waves)
+        out["main_wavefronts"] = int(waves)
     if insts:
         out["achieved"] = insts / (kernel_ms * 1e-3) / 1e9
         out["frac"] = out["achieved"] / peak
     return out
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a
+    container that SEES 256 logical CPUs may be allowed 16 CPUs' worth of time: threads beyond
+    the quota are throttled, which reads as an OpenMP port that does not scale)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            pass
+    usable = avail if quota is None else max(1, min(avail, int(quota)))
+    return avail, quota, usable
+
+
 def cpu_baseline(cfg, B, iters, budget_s):
     """The CPU oracle (a port of the reference algorithm, oracle/ilqr_oracle.c, OpenMP over the
-    batch) on the host cores of this box: same synthetic workload, same fixed iteration count,
-    bounded sample (about `budget_s` seconds of wall time)."""
+    batch, static chunks, threads pinned: OMP_PROC_BIND=spread) on the host cores of this box:
+    same synthetic workload, same fixed iteration count, sweeps of 65536 problems for about
+    `budget_s` seconds of wall time.  Threads = the CPUs the cgroup quota grants this process."""
+    os.environ.setdefault("OMP_PROC_BIND", "spread")  # before libgomp starts its first team
+    os.environ.setdefault("OMP_PLACES", "cores")
     from ilqr_iterative_tasks_amd import workloads
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    host = workloads.make_batch(cfg, 8192)
+    avail, quota, usable = cpu_quota()
+    NB = 65536
+    host = workloads.make_batch(cfg, NB)
 
     def run(nprob):
         sl = slice(0, nprob)
@@ -393,34 +510,38 @@ def cpu_baseline(cfg, B, iters, budget_s):
         return time.perf_counter() - t0
 
     orc.set_threads(1)
-    t1 = run(256)
-    one_thread = 256 * iters / t1
-    # the host may expose more logical CPUs than this process can use (affinity, cgroup quota):
-    # probe power-of-two thread counts and keep the fastest
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
-    best_t, best_rate, probes = 1, one_thread, {}
-    nt = 2
-    while nt <= avail:
+    run(256)
+    one_thread = 1024 * iters / run(1024)
+    # the quota's thread count, and half / twice of it (SMT siblings, a quota below the mask):
+    # keep the fastest
+    probes = {}
+    for nt in sorted({max(1, usable // 2), usable, min(avail, 2 * usable)}):
         orc.set_threads(nt)
-        run(min(8192, 32 * nt))  # warm the pool
-        rate = 8192 * iters / run(8192)
-        probes[nt] = rate
-        if rate > best_rate:
-            best_t, best_rate = nt, rate
-        nt *= 2
+        run(min(NB, 1024 * nt))  # warm the team
+        probes[nt] = NB * iters / run(NB)
+    best_t = max(probes, key=probes.get)
     threads = orc.set_threads(best_t)
-    t_all = run(8192)
+    t_all = NB * iters / probes[best_t]
     sweeps = max(1, min(400, int(budget_s / max(t_all, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(sweeps):
-        run(8192)
+        run(NB)
     dt = time.perf_counter() - t0
-    return dict(value=8192 * sweeps * iters / dt, unit="iLQR iterations/s", cores=threads,
+    return dict(value=NB * sweeps * iters / dt, unit="iLQR iterations/s", cores=threads,
                 kind="port",
-                sample=f"8192 problems x {iters} iterations x {sweeps} sweeps of the bench "
-                       f"workload, OpenMP on {threads} threads (fastest of the probed counts; "
-                       f"{avail} logical CPUs visible; {dt:.1f} s wall)",
-                value_1thread=one_thread, logical_cpus=avail)
+                sample=f"{NB} problems x {iters} iterations x {sweeps} sweeps of the bench "
+                       f"workload, OpenMP (static chunks, OMP_PROC_BIND=spread) on {threads} "
+                       f"threads; {avail} logical CPUs visible, cgroup quota "
+                       f"{'none' if quota is None else f'{quota:g} CPUs'}; {dt:.1f} s wall",
+                value_1thread=one_thread, logical_cpus=avail, cgroup_cpu_quota=quota,
+                threads_probed={str(k): v for k, v in probes.items()},
+                reference_python={
+                    "value": 756.0, "unit": "iLQR iterations/s", "cores": 1,
+                    "provenance": "BASELINE.md section 2: the reference's own ilqr() (NumPy), imported "
+                                  "in the build container (1 thread of an 8-core Xeon @ 2.1 GHz), "
+                                  "config 1: n=4, m=2, N=6, 56073 iterations in 74.16 s; 268 it/s "
+                                  "at N=20.  Not measured on this box: the reference's Python does "
+                                  "not travel."})
 
 
 def run_exchange_only(args, rank, world, torch, dist_mod):
@@ -506,7 +627,7 @@ def run_rank(args) -> int:
     pmc = PmcFile()
 
     res = run_gpu(args, cfg, B, rank, world, torch, dist_mod, args.steps, args.warmup,
-                  event_stride=EVENT_STRIDE)
+                  event_stride=event_stride_for(args.steps))
     value = res["iterations"] / res["seconds"]
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
@@ -536,8 +657,14 @@ def run_rank(args) -> int:
         "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc.get(key), "algorithmic_bytes_per_iteration": alg_bytes,
+                     # median of the sampled launches of the timed region, empty event pair
+                     # subtracted (kernel_ms_raw_median is what the events report as is)
                      "kernel_ms_avg": res["kernel_ms"],
-                     "kernel_ms_samples": len(range(0, args.steps, EVENT_STRIDE)), **pmc.stamp(),
+                     "kernel_ms_samples": res["kernel_ms_stats"]["samples"],
+                     "kernel_ms_min": res["kernel_ms_stats"]["min"],
+                     "kernel_ms_max": res["kernel_ms_stats"]["max"],
+                     "kernel_ms_raw_median": res["kernel_ms_raw_median"],
+                     "event_pair_overhead_ms": res["event_pair_overhead_ms"], **pmc.stamp(),
                      # SQ counters of the same kernel (separate --pmc pass): shares of the
                      # wavefronts' lifetime spent issuing (any / VALU), parked on s_waitcnt, stalled
                      "sq_shares_of_wave_cycles": pmc.get(key, "sq_shares_of_wave_cycles")},
@@ -571,32 +698,35 @@ def run_rank(args) -> int:
             "hbm_frac_per_gpu": ach / HBM_PEAK_GBS,
             "exchange_ms_per_step": r.get("exchange_ms"), "nccl_world": r.get("nccl_world")}
     if world == 1 and not args.no_extra:
-        # secondary single-GPU workloads (not the headline): large batches of the same problem
+        # secondary single-GPU workloads (not the headline): EXTRA_LAUNCHES individually timed
+        # launches each after EXTRA_WARMUP, median kernel time (min / max / spread beside it)
+        def timed(workload, edt, eb, iters):
+            ecfg = workloads.config_for(workload, edt)
+            r = time_launches(args, ecfg, eb, torch, iters)
+            return roofline_entry(ecfg, eb, iters, r, pmc.get(f"{workload}:{edt}:B{eb}:it{iters}"))
+
         for name, eb, edt in (("B4096_f64", 4096, "f64"), ("B8192_f64", 8192, "f64"),
-                              ("B65536_f64", 65536, "f64"), ("B65536_f32", 65536, "f32"),
+                              ("B16384_f64", 16384, "f64"), ("B32768_f64", 32768, "f64"),
+                              ("B65536_f32", 65536, "f32"),
                               ("B1048576_f64", 1 << 20, "f64"), ("B1048576_f32", 1 << 20, "f32")):
-            ecfg = workloads.config_for(args.workload, edt)
-            nst = 3 if eb > 100000 else 6
-            r = run_gpu(args, ecfg, eb, 0, 1, torch, dist_mod, nst, 2, with_tail=False)
-            eb_bytes = workloads.algorithmic_bytes_per_iteration(ecfg)
-            ach = eb_bytes * eb * args.iters / (r["kernel_ms"] * 1e-3) / 1e9
-            extra[name] = {"iterations_per_s": r["iterations"] / r["seconds"],
-                           "kernel": r["kernel"], "layout": r["layout"],
-                           "kernel_ms": r["kernel_ms"], "achieved_GBs": ach,
-                           "hbm_frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc.get(f"{args.workload}:{edt}:B{eb}:it{args.iters}")}
+            extra[name] = timed(args.workload, edt, eb, args.iters)
+        # the large-batch fp64 regime as a first-class object: BASELINE's roofline batch (65536)
+        # and the per-GPU shard of configs[3] (2^20 / 8 = 131072)
+        out["roofline_large_batch"] = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "dtype": "f64",
+            "B65536": timed(args.workload, "f64", 65536, args.iters),
+            "B131072": timed(args.workload, "f64", 131072, args.iters)}
         # BASELINE configs[4]: quadrotor-sized n=12, m=4, N=50, B=65536, fp64 (33912 algorithmic
-        # bytes per iteration); 4 fused iterations per launch
-        qcfg = workloads.config_for("config5", "f64")
-        qargs = argparse.Namespace(**{**vars(args), "iters": 4})
-        r = run_gpu(qargs, qcfg, 65536, 0, 1, torch, dist_mod, 2, 1, with_tail=False)
-        qb = workloads.algorithmic_bytes_per_iteration(qcfg)
-        ach = qb * 65536 * 4 / (r["kernel_ms"] * 1e-3) / 1e9
-        extra["config5_quad12_B65536_f64"] = {
-            "iterations_per_s": r["iterations"] / r["seconds"], "kernel": r["kernel"],
-            "layout": r["layout"], "kernel_ms": r["kernel_ms"], "iterations_per_launch": 4,
-            "algorithmic_bytes_per_iteration": qb, "achieved_GBs": ach,
-            "hbm_frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("config5:f64:B65536:it4")}
+        # bytes and 600 k algorithmic flops per iteration); 4 fused iterations per launch
+        q = timed("config5", "f64", 65536, 4)
+        qflops = workloads.algorithmic_flops_per_iteration(workloads.config_for("config5", "f64"))
+        q["algorithmic_flops_per_iteration"] = qflops
+        q["achieved_fp64_TFLOPs"] = q["iterations_per_s"] * qflops / 1e12
+        q["fp64_vector_peak_TFLOPs"] = FP64_VECTOR_PEAK_TFLOPS
+        q["fp64_flop_frac"] = q["achieved_fp64_TFLOPs"] / FP64_VECTOR_PEAK_TFLOPS
+        q["note"] = ("flops in the reference's dense form (SURVEY.md 8d); the kernel executes about "
+                     "40 % of them: the sparsity of [A | B] is folded into the instruction stream")
+        extra["config5_quad12_B65536_f64"] = q
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
         # problem is done, so this is below the fixed-count rate.  Default = chunked solve with

@@ -110,3 +110,13 @@ def algorithmic_bytes_per_iteration(cfg: I2lqrConfig) -> int:
     n, m, N = cfg.n, cfg.m, cfg.N
     words = 2 * n * (N + 1) + 3 * m * N + m * n * N + n + 3
     return words * (8 if cfg.dtype == _abi.F64 else 4)
+
+
+def algorithmic_flops_per_iteration(cfg: I2lqrConfig) -> int:
+    """flops of one iLQR iteration per problem in the reference's dense form,
+    N (4 n^3 + 6 m n^2 + 6 m^2 n + 2 n^2 + 4 n m) for the backward pass (the rollouts and barrier
+    terms add a few per cent): 600 k at n=12, m=4, N=50; 35 k at n=6, m=2, N=20.  The kernels
+    execute fewer (they fold the sparsity of [A | B] into the instruction stream)."""
+    n, m, N = cfg.n, cfg.m, cfg.N
+    return N * (4 * n ** 3 + 6 * m * n ** 2 + 6 * m ** 2 * n + 2 * n ** 2 + 4 * n * m)
+

@@ -649,7 +649,7 @@ void orc_ilqr_batch(const cfg_t* c, int64_t B, int max_iter, int early_exit, dou
                     const double* x_term, double* lamb, const double* obs, double* K, double* k,
                     double* cost, int32_t* iters, int32_t* status) {
   const int n = c->n, m = c->m, N = c->N;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < B; b++) {
     double Ktmp[MAXM * MAXN * MAXH], ktmp[MAXM * MAXH];
     int st = 0;

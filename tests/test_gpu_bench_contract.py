@@ -35,13 +35,18 @@ def test_bench_json_line_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["traffic_stale"] in (True, False) and (r["traffic"] is None or not r["traffic_stale"])
     ri = d["roofline_issue"]
-    # 1024 problems on the eight-problems-per-wavefront kernel: 128 wavefronts, one SIMD each
-    assert ri["bound"] == "issue" and ri["simds_occupied"] == 128
-    assert abs(ri["peak"] - 128 * 2.4 / 4) < 1e-9
+    # 1024 problems on the eight-problems-per-wavefront kernel: 128 main wavefronts, one SIMD each
+    # (+ 256 helper wavefronts when the counter file of this library knows about them: their
+    # instructions are in the numerator, so their SIMDs are in the denominator)
+    assert ri["bound"] == "issue" and ri["simds_occupied"] in (128, 384)
+    assert abs(ri["peak"] - ri["simds_occupied"] * 2.4 / 4) < 1e-9
+    assert r["kernel_ms_samples"] >= 3 and r["kernel_ms_avg"] <= d["ms_per_step"]
+    assert r["kernel_ms_min"] <= r["kernel_ms_avg"] <= r["kernel_ms_max"]
     assert r["kernel"] == "k_group_iterate"
     assert ri["frac"] is None or 0 < ri["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["reference_python"]["value"] == 756.0 and "BASELINE.md" in c["reference_python"]["provenance"]
 
 
 def test_bench_under_torchrun_world_of_one_uses_the_native_rccl_exchange():
