@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="--gpus N > 1 without a launcher: seconds one attempt of the N ranks may "
+                         "take before its process group is ended")
     return ap.parse_args(argv)
 
 
@@ -79,10 +82,11 @@ def parse_args(argv=None):
 # launcher: python bench.py --gpus N  ->  N rank processes
 # ------------------------------------------------------------------------------------------------
 
-def spawn_ranks(args) -> int:
-    """Start args.gpus ranks of this script as fresh processes and relay rank 0's JSON line.  Runs
-    before torch is imported: the launcher never initialises a GPU, and nothing is exec'ed from a
-    process that has."""
+def _run_ranks(args, extra_argv, timeout_s):
+    """One attempt: N fresh rank processes through torch.distributed.run, in a process group of
+    their own so that a hung attempt (a rank stuck in a communicator bootstrap) can be ended as a
+    whole.  Returns (returncode or None on timeout, stdout)."""
+    import signal
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -92,15 +96,61 @@ def spawn_ranks(args) -> int:
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
-    if proc.returncode != 0 or not lines:
-        sys.stderr.write(proc.stdout)
-        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode})\n")
-        return proc.returncode or 1
-    print(lines[-1], flush=True)
-    return 0
+           str(port), str(Path(__file__).resolve())] + sys.argv[1:] + extra_argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+        return proc.returncode, out
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):  # exactly the group this attempt started
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        out = ""
+        try:
+            out, _ = proc.communicate(timeout=5)
+        except Exception:  # noqa: BLE001
+            pass
+        return None, out or ""
+
+
+def spawn_ranks(args) -> int:
+    """Start args.gpus ranks of this script as fresh processes and relay rank 0's JSON line.  Runs
+    before torch is imported: the launcher never initialises a GPU, and nothing is exec'ed from a
+    process that has.  An attempt that fails or exceeds --launch-timeout is ended (its whole
+    process group) and, if it used the native exchange, repeated ONCE as a fresh set of processes
+    with --exchange torch (torch.distributed's all-gather instead of the library's own RCCL
+    communicator); the JSON line then carries the story under "launcher".  Exit code non-zero if
+    that fails too."""
+    attempts = []
+    plans = [[]]
+    if args.exchange == "native":
+        plans.append(["--exchange", "torch"])
+    for extra_argv in plans:
+        t0 = time.perf_counter()
+        rc, out = _run_ranks(args, extra_argv, args.launch_timeout)
+        lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+        attempts.append({"argv": extra_argv, "returncode": rc, "timed_out": rc is None,
+                         "seconds": round(time.perf_counter() - t0, 1)})
+        if rc == 0 and lines:
+            d = json.loads(lines[-1])
+            d["launcher"] = {"attempts": attempts,
+                             "fallback": None if not extra_argv else
+                             "first attempt failed or timed out: ranks restarted with "
+                             "--exchange torch"}
+            print(json.dumps(d), flush=True)
+            return 0
+        sys.stderr.write(out[-4000:])
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run "
+                         f"{'timed out after %g s' % args.launch_timeout if rc is None else 'failed (exit %s)' % rc}"
+                         f"{' [' + ' '.join(extra_argv) + ']' if extra_argv else ''}\n")
+    return (attempts[-1]["returncode"] or 1) if attempts else 1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -223,7 +273,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             # the communicator behind i2lqr_allgather_costs is created here by every rank at once;
             # if RCCL cannot be bound or bootstrapped that way on this node, all ranks fall back
             # to torch.distributed's all-gather together and the JSON line says so
-            try:
+            try:  # (raises on every rank or on none: CostExchange agrees on each bring-up step)
                 exchange = dist_mod.CostExchange(solver)
                 ok = 1
             except Exception as e:  # noqa: BLE001
@@ -545,6 +595,10 @@ def cpu_baseline(cfg, B, iters, budget_s):
 
 
 def run_exchange_only(args, rank, world, torch, dist_mod):
+    # test hook of the launcher's timeout / fresh-process fallback (tests/test_dist_gloo.py): a
+    # "native" attempt that never returns, as a rank stuck in a communicator bootstrap would
+    if os.environ.get("I2LQR_BENCH_TEST_HANG") == args.exchange:
+        time.sleep(3600)
     """The multi-rank harness without the solve (CPU tensors, gloo): per step every rank
     contributes a synthetic cost shard, all-gathers, and picks; the pick is checked against the
     shards every rank can regenerate from the seeds."""

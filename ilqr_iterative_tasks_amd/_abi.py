@@ -158,6 +158,7 @@ EXPORTS = {
                                           C.c_int32, _P, _P, _P, _P]),
     "i2lqr_init_candidates": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P, _P, _P]),
     "i2lqr_pick_best": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_comm_available": (C.c_int, []),
     "i2lqr_comm_unique_id": (C.c_int, [_P]),
     "i2lqr_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "i2lqr_comm_destroy": (C.c_int, [_P]),

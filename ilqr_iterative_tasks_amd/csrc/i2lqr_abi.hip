@@ -1233,6 +1233,12 @@ int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, 
   return I2LQR_OK;
 }
 
+int i2lqr_comm_available(void) {
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  return I2LQR_OK;
+}
+
 int i2lqr_comm_unique_id(void* id) {
   if (!id) return fail(I2LQR_ERR_INVALID, "null id buffer");
   const RcclApi& api = rccl_api();

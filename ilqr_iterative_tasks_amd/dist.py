@@ -67,6 +67,23 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
     return torch.cat([gathered[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)])
 
 
+def _agree(ok: bool, device, group=None) -> bool:
+    """True on every rank iff `ok` is true on every rank (one all-reduce; a world of one agrees
+    with itself)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+class CostExchangeUnavailable(RuntimeError):
+    """The native communicator could not be brought up — raised on EVERY rank of the group (the
+    ranks agree on the outcome before and after the bootstrap), so the callers' fallbacks stay in
+    step."""
+
+
 class CostExchange:
     """The all-gather of the candidates' terminal costs through the C-ABI (i2lqr_allgather_costs:
     one RCCL ncclAllGather on a communicator the library creates itself).
@@ -74,40 +91,94 @@ class CostExchange:
     The ranks agree on the communicator's unique id through the torch.distributed group that is
     already up (any backend: the id is 128 bytes of host data, sent with broadcast_object_list);
     without a process group this is a world of one.  A host language other than Python does the
-    same with i2lqr_comm_unique_id / i2lqr_comm_create and its own side channel."""
+    same with i2lqr_comm_available / i2lqr_comm_unique_id / i2lqr_comm_create and its own side
+    channel.
+
+    Bring-up never leaves the ranks in different collectives: (1) every rank checks that RCCL can
+    be bound and the ranks agree on that; (2) rank 0 makes the id and broadcasts it — an EMPTY id
+    if it failed, so the others do not sit in the broadcast; (3) every rank joins
+    ncclCommInitRank; (4) the ranks agree on the outcome.  Any failure raises
+    CostExchangeUnavailable on all ranks."""
 
     def __init__(self, solver, group=None):
         import ctypes as C
         from . import _abi
         self.solver, self.lib = solver, solver.lib
+        self._comm = None
         grouped = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if grouped else 1
         self.rank = dist.get_rank(group) if grouped else 0
+        self._group = group
+        # (1) can every rank bind RCCL?
+        err = None
+        try:
+            solver._check(self.lib.i2lqr_comm_available())
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not _agree(err is None, solver.device, group):
+            raise CostExchangeUnavailable(f"RCCL cannot be bound on every rank ({err or 'another rank'})")
+        # (2) the unique id, or an empty marker
         uid = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        payload = b""
         if self.rank == 0:
-            solver._check(self.lib.i2lqr_comm_unique_id(uid))
-        box = [uid.raw]
+            try:
+                solver._check(self.lib.i2lqr_comm_unique_id(uid))
+                payload = uid.raw
+            except Exception as e:  # noqa: BLE001
+                err = e
+        box = [payload]
         if grouped and self.world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        self._comm = C.c_void_p()
-        with torch.cuda.device(solver.device):
-            solver._check(self.lib.i2lqr_comm_create(C.c_char_p(box[0]), self.world, self.rank,
-                                                     C.byref(self._comm)))
+        if not box[0]:
+            raise CostExchangeUnavailable(f"rank 0 could not create the RCCL unique id ({err or 'see rank 0'})")
+        # (3) the bootstrap, (4) agreement on its outcome
+        comm = C.c_void_p()
+        try:
+            with _device_ctx(solver.device):
+                solver._check(self.lib.i2lqr_comm_create(C.c_char_p(box[0]), self.world, self.rank,
+                                                         C.byref(comm)))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not _agree(err is None, solver.device, group):
+            if err is None and comm.value:
+                self.lib.i2lqr_comm_destroy(comm)
+            raise CostExchangeUnavailable(f"ncclCommInitRank failed ({err or 'on another rank'})")
+        self._comm = comm
         w, r = C.c_int32(), C.c_int32()
         solver._check(self.lib.i2lqr_comm_info(self._comm, C.byref(w), C.byref(r)))
         self.comm_world, self.comm_rank = int(w.value), int(r.value)  # what RCCL itself reports
 
-    def allgather(self, cost_local: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """cost_local[n] on this rank -> cost_all[world * n] in rank order, on the current stream."""
+    def allgather(self, cost_local: torch.Tensor, out: torch.Tensor | None = None,
+                  total: int | None = None) -> torch.Tensor:
+        """cost_local[n] on this rank -> the costs of all ranks in rank order, on the current
+        stream.  Equal shards (total None or world * n): cost_all[world * n], written into `out`
+        if given.  Ragged shards (`total` candidates split by shard_range): every shard is padded
+        to the largest with +inf — which never wins the arg-min — gathered, and compacted to
+        cost_all[total] (as allgather_costs does for the torch path)."""
         import ctypes as C
         n = cost_local.numel()
+        if total is not None and total != n * self.world:
+            sizes = [shard_range(total, r, self.world) for r in range(self.world)]
+            if sizes[self.rank][1] - sizes[self.rank][0] != n:
+                raise ValueError(f"rank {self.rank} owns {sizes[self.rank][1] - sizes[self.rank][0]} "
+                                 f"of {total} candidates, got {n}")
+            width = max(hi - lo for lo, hi in sizes)
+            padded = torch.full((width,), float("inf"), dtype=cost_local.dtype,
+                                device=cost_local.device)
+            padded[:n] = cost_local
+            gathered = self.allgather(padded).view(self.world, width)
+            res = torch.cat([gathered[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)])
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res
         if out is None:
             out = torch.empty(n * self.world, dtype=cost_local.dtype, device=cost_local.device)
         if out.numel() != n * self.world or not out.is_contiguous() or not cost_local.is_contiguous():
             raise ValueError("cost_all must be a contiguous tensor of world * n_local elements")
         if cost_local.dtype != self.solver.dtype or out.dtype != self.solver.dtype:
             raise ValueError(f"cost tensors must be {self.solver.dtype}")
-        with torch.cuda.device(self.solver.device):
+        with _device_ctx(self.solver.device):
             self.solver._check(self.lib.i2lqr_allgather_costs(
                 self.solver._handle, self._comm, C.c_void_p(cost_local.data_ptr()),
                 C.c_void_p(out.data_ptr()), n, self.solver._stream()))
@@ -115,7 +186,8 @@ class CostExchange:
 
     def close(self):
         if getattr(self, "_comm", None) is not None and self._comm.value:
-            torch.cuda.synchronize(self.solver.device)
+            if torch.device(self.solver.device).type == "cuda":
+                torch.cuda.synchronize(self.solver.device)
             self.lib.i2lqr_comm_destroy(self._comm)
             self._comm = None
 
@@ -124,6 +196,12 @@ class CostExchange:
             self.close()
         except Exception:
             pass
+
+
+def _device_ctx(device):
+    """torch.cuda.device(device) for a HIP device, nothing for the CPU doubles of the tests."""
+    import contextlib
+    return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
 def select_best_flat(cost_all: torch.Tensor) -> tuple[int, float]:

@@ -322,9 +322,16 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
  * bound at run time: a librccl already loaded in the process is used, else the ROCm one;
  * I2LQR_ERR_UNSUPPORTED if neither is available.
  * cost_local[n_local] and cost_all[world * n_local] are device buffers of `real`; the collective
- * is enqueued on `stream`.
+ * is enqueued on `stream`.  n_local must be the SAME on every rank (ncclAllGather semantics: a
+ * mismatch is not detectable from inside one rank); ragged shards are padded by the caller to the
+ * largest shard with +inf, which never wins the arg-min (the Python host does that:
+ * CostExchange.allgather(total=...)).
  */
 #define I2LQR_COMM_ID_BYTES 128
+/* I2LQR_OK if RCCL can be bound in this process (no communicator is created, no GPU touched):
+ * every rank checks this and the ranks agree on the answer BEFORE any of them enters
+ * i2lqr_comm_create, whose bootstrap blocks until all `world` ranks have arrived. */
+int i2lqr_comm_available(void);
 int i2lqr_comm_unique_id(void* id);
 int i2lqr_comm_create(const void* id, int32_t world, int32_t rank, void** comm);
 int i2lqr_comm_destroy(void* comm);

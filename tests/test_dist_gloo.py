@@ -117,3 +117,116 @@ def test_bench_without_gpu_fails_loudly():
         pytest.skip("GPU box: covered by the gpu-marked contract test")
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launcher_ends_a_hung_attempt_and_restarts_fresh_ranks_on_the_torch_exchange():
+    """A first attempt that never returns (a rank stuck in a communicator bootstrap) is ended
+    after --launch-timeout — its whole process group — and the ranks are started again as fresh
+    processes with --exchange torch; the JSON line tells the story."""
+    import json
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--exchange-only", "--batch", "64",
+                 "--launch-timeout", "20", env=dict(I2LQR_BENCH_TEST_HANG="native"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    att = d["launcher"]["attempts"]
+    assert len(att) == 2 and att[0]["timed_out"] and att[0]["returncode"] is None
+    assert att[1]["argv"] == ["--exchange", "torch"] and att[1]["returncode"] == 0
+    assert "--exchange torch" in d["launcher"]["fallback"] and d["n_gpus"] == 2
+    assert "timed out" in out.stderr
+
+
+def test_launcher_exits_nonzero_when_the_fallback_fails_too():
+    out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--exchange-only", "--batch", "64",
+                 "--exchange", "torch", "--launch-timeout", "12",
+                 env=dict(I2LQR_BENCH_TEST_HANG="torch"))
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+# -- bring-up of the native communicator: all ranks fall back together ---------------------------------
+
+class _FakeLib:
+    """The five i2lqr_comm_* entry points with injectable failures (return codes as the C-ABI)."""
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.calls, self.destroyed = rank, fail, [], 0
+
+    def _rc(self, name):
+        self.calls.append(name)
+        return -3 if self.fail.get(name) == self.rank else 0
+
+    def i2lqr_comm_available(self):
+        return self._rc("available")
+
+    def i2lqr_comm_unique_id(self, uid):
+        rc = self._rc("unique_id")
+        if rc == 0:
+            uid.raw = bytes(range(128))
+        return rc
+
+    def i2lqr_comm_create(self, uid, world, rank, comm_ref):
+        rc = self._rc("create")
+        if rc == 0:
+            comm_ref._obj.value = 0x1000 + rank
+        return rc
+
+    def i2lqr_comm_destroy(self, comm):
+        self.destroyed += 1
+        return 0
+
+    def i2lqr_comm_info(self, comm, w, r):
+        w._obj.value, r._obj.value = 2, self.rank
+        return 0
+
+
+class _FakeSolver:
+    def __init__(self, lib):
+        self.lib, self.device, self.dtype = lib, torch.device("cpu"), torch.float64
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"i2lqr error {rc}")
+
+
+def _exchange_worker(rank, world, port, fail, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    idist.init_from_env("gloo")
+    lib = _FakeLib(rank, fail)
+    outcome = "ok"
+    try:
+        ex = idist.CostExchange(_FakeSolver(lib))
+        assert (ex.comm_world, ex.comm_rank) == (2, rank)
+    except idist.CostExchangeUnavailable as e:
+        outcome = "unavailable: " + str(e)
+    # the ranks are still in step: a collective right after the bring-up completes
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    assert float(t.item()) == 1.0
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{outcome}|{','.join(lib.calls)}|{lib.destroyed}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail,expect_calls", [
+    ({}, ["available", "unique_id", "create"]),
+    ({"available": 1}, ["available"]),                      # rank 1 cannot bind RCCL: nobody goes on
+    ({"unique_id": 0}, ["available", "unique_id"]),         # rank 0 cannot make the id
+    ({"create": 1}, ["available", "unique_id", "create"]),  # rank 1 fails in the bootstrap
+])
+def test_native_exchange_bring_up_fails_on_all_ranks_or_none(tmp_path, fail, expect_calls):
+    port = _free_port()
+    mp.spawn(_exchange_worker, args=(2, port, fail, str(tmp_path)), nprocs=2, join=True)
+    res = [open(tmp_path / f"rank{r}.txt").read().split("|") for r in range(2)]
+    outcomes = [r[0] for r in res]
+    if not fail:
+        assert outcomes == ["ok", "ok"]
+    else:
+        assert all(o.startswith("unavailable") for o in outcomes), outcomes
+    assert res[0][1].split(",") == expect_calls                     # rank 0 made the id if it got there
+    assert res[1][1].split(",") == [c for c in expect_calls if c != "unique_id"]
+    if fail.get("create") == 1:
+        assert res[0][2] == "1"  # rank 0's communicator was created, then destroyed again
