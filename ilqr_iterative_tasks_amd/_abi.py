@@ -129,7 +129,11 @@ def default_config(system="bicycle4", num_horizon=6, dtype="f64", dt=1.0,
 
 _PKG_DIR = Path(__file__).resolve().parent
 LIB_NAME = "libi2lqr_hip.so"
-LIB_PATH = _PKG_DIR / "csrc" / LIB_NAME
+# I2LQR_LIB_PATH: another build of the same library (the index-checked debug build of
+# `make -C ilqr_iterative_tasks_amd/csrc debug`, an A/B build under tools/); there is no other
+# fallback: a missing library is an error
+LIB_PATH = Path(os.environ["I2LQR_LIB_PATH"]) if os.environ.get("I2LQR_LIB_PATH") else \
+    _PKG_DIR / "csrc" / LIB_NAME
 
 # name -> (restype, argtypes); the exports include/i2lqr.h declares.
 _P = C.c_void_p

@@ -46,6 +46,70 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+namespace i2lqr {
+#ifdef I2LQR_DEBUG
+unsigned long long* debug_trap_word() {
+  constexpr int kMaxDev = 64;
+  static unsigned long long* word[kMaxDev] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!word[dev]) {
+    if (hipMalloc((void**)&word[dev], sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(word[dev], 0, sizeof(unsigned long long));
+  }
+  return word[dev];
+}
+#else
+unsigned long long* debug_trap_word() { return nullptr; }
+#endif
+}  // namespace i2lqr
+
+#ifdef I2LQR_DEBUG
+__global__ void k_debug_self_test(double* buf, unsigned long long* trap) {
+  const auto s = i2lqr::make_slice(buf, 8, trap, i2lqr::TAG_WAVE_LDS);
+  if (threadIdx.x == 0) s[8] = 1.0;  // one past the end: recorded, redirected to s[0]
+}
+#endif
+
+namespace {
+// Debug build: after a call's launches, wait for the stream and turn a recorded index violation
+// into I2LQR_ERR_LAUNCH (the record is cleared).  The product build returns rc untouched and does
+// not synchronise.
+int debug_check(int rc, void* stream) {
+#ifdef I2LQR_DEBUG
+  if (rc != I2LQR_OK) return rc;
+  unsigned long long* w = i2lqr::debug_trap_word();
+  if (!w) return rc;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess &&
+      cap != hipStreamCaptureStatusNone)
+    return rc;  // a stream being captured into a graph cannot be waited for: the next eager call checks
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return fail(I2LQR_ERR_LAUNCH, "debug build: the stream reported an error");
+  unsigned long long rec = 0;
+  if (hipMemcpy(&rec, w, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(I2LQR_ERR_LAUNCH, "debug build: could not read the violation record");
+  if (rec) {
+    (void)hipMemset(w, 0, sizeof(rec));
+    static const char* const names[] = {"?", "wave-kernel LDS slice", "eight-lane LDS slice",
+                                        "sixteen-lane LDS slice", "quad12 HBM workspace slot",
+                                        "lane kernel row of X", "lane kernel row of U / k",
+                                        "lane kernel row of K", "lane kernel LDS word",
+                                        "compaction row / problem index"};
+    const int tag = (int)((rec >> 56) & 0x7f);
+    return fail(I2LQR_ERR_LAUNCH, "debug build: index check failed: %s, index %lld, limit %lld",
+                names[tag < 10 ? tag : 0], (long long)((rec >> 28) & 0xfffffff),
+                (long long)(rec & 0xfffffff));
+  }
+#else
+  (void)stream;
+#endif
+  return rc;
+}
+}  // namespace
+
 struct i2lqr_handle {
   i2lqr_config cfg;
   int lanes;        // lanes of a wavefront that cooperate on one problem (1: batch-minor layout)
@@ -470,7 +534,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     while (done < max_iter) {
       HIP_TRY(hipMemsetAsync(cv.count + cur, 0, sizeof(int32_t), s));
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
-                         src_user ? 1 : 0, count_in, cv.set[cur], cv.count + cur, usr);
+                         src_user ? 1 : 0, count_in, cv.set[cur], cv.count + cur, usr, c.trap);
       const LaneSet<T>& w = cv.set[cur];
       // Latency tail: once few problems survive, the rest of the solve is bound by the slowest
       // problem's iteration latency, which is ~2.8x lower with one problem per WAVEFRONT.  If the
@@ -534,7 +598,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       LaneSet<T> none;
       std::memset(&none, 0, sizeof(none));
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src, 0,
-                         count_in, none, cv.count + cur, usr);
+                         count_in, none, cv.count + cur, usr, c.trap);
     }
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
@@ -683,6 +747,26 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   } while (0)
 
 int prepare_dispatch(i2lqr_handle* h) { I2LQR_DISPATCH(h, prepare(h)); }
+int dispatch_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
+                     void* stream) {
+  I2LQR_DISPATCH(h, rollout(h, B, X, U, x_term, cost, (hipStream_t)stream));
+}
+int dispatch_backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                      const void* lamb, const void* obs, void* K, void* k, void* stream) {
+  I2LQR_DISPATCH(h, backward(h, B, X, U, x_term, lamb, obs, K, k, (hipStream_t)stream));
+}
+int dispatch_forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
+                     const void* K, const void* k, void* X_new, void* U_new, void* cost_new,
+                     void* stream) {
+  I2LQR_DISPATCH(h, forward(h, B, X, U, x_term, K, k, X_new, U_new, cost_new,
+                            (hipStream_t)stream));
+}
+int dispatch_iterate(i2lqr_handle* h, int64_t B, int n_iters, int early_exit, void* X, void* U,
+                     const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                     int32_t* iters, int32_t* status, void* stream) {
+  I2LQR_DISPATCH(h, iterate(h, B, n_iters, early_exit, X, U, x_term, lamb, obs, cost, K, k, iters,
+                            status, (hipStream_t)stream));
+}
 
 // Live handles: i2lqr_destroy of NULL is a no-op, of a pointer that is not (or no longer) a live
 // handle an error code instead of a double free.
@@ -1019,6 +1103,22 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "debug_self_test")) {
+    // Debug build only: provoke one index violation on purpose (a Slice of 8 words indexed at 8)
+    // and return what the next call would: I2LQR_ERR_LAUNCH with the decoded record.
+#ifdef I2LQR_DEBUG
+    unsigned long long* w = i2lqr::debug_trap_word();
+    double* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, 8 * sizeof(double)));
+    hipLaunchKernelGGL(k_debug_self_test, dim3(1), dim3(64), 0, (hipStream_t)0, buf, w);
+    const int rc = debug_check(I2LQR_OK, nullptr);
+    (void)hipFree(buf);
+    return rc;
+#else
+    return fail(I2LQR_ERR_UNSUPPORTED, "\"debug_self_test\" exists in the index-checked debug build "
+                "only (make -C ilqr_iterative_tasks_amd/csrc debug)");
+#endif
+  }
   else if (!strcmp(name, "group_lanes")) {
     if (v != -1 && v != 8 && v != 16 && v != 64)
       return fail(I2LQR_ERR_INVALID, "\"group_lanes\" is 8, 16, 64 or -1");
@@ -1058,7 +1158,7 @@ int i2lqr_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_te
   if (int rc = check_common(h, B)) return rc;
   if (B == 0) return I2LQR_OK;
   if (!X || !U || !x_term || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
-  I2LQR_DISPATCH(h, rollout(h, B, X, U, x_term, cost, (hipStream_t)stream));
+  return debug_check(dispatch_rollout(h, B, X, U, x_term, cost, stream), stream);
 }
 
 int i2lqr_backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
@@ -1066,7 +1166,7 @@ int i2lqr_backward(i2lqr_handle* h, int64_t B, const void* X, const void* U, con
   if (int rc = check_common(h, B)) return rc;
   if (B == 0) return I2LQR_OK;
   if (!X || !U || !x_term || !lamb || !K || !k) return fail(I2LQR_ERR_INVALID, "null buffer");
-  I2LQR_DISPATCH(h, backward(h, B, X, U, x_term, lamb, obs, K, k, (hipStream_t)stream));
+  return debug_check(dispatch_backward(h, B, X, U, x_term, lamb, obs, K, k, stream), stream);
 }
 
 int i2lqr_forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, const void* x_term,
@@ -1076,8 +1176,8 @@ int i2lqr_forward(i2lqr_handle* h, int64_t B, const void* X, const void* U, cons
   if (B == 0) return I2LQR_OK;
   if (!X || !U || !x_term || !K || !k || !X_new || !U_new || !cost_new)
     return fail(I2LQR_ERR_INVALID, "null buffer");
-  I2LQR_DISPATCH(h, forward(h, B, X, U, x_term, K, k, X_new, U_new, cost_new,
-                            (hipStream_t)stream));
+  return debug_check(dispatch_forward(h, B, X, U, x_term, K, k, X_new, U_new, cost_new, stream),
+                     stream);
 }
 
 int i2lqr_iterate(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
@@ -1089,8 +1189,8 @@ int i2lqr_iterate(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
   if (!X || !U || !x_term || !lamb || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
   if ((K == nullptr) != (k == nullptr))
     return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
-  I2LQR_DISPATCH(h, iterate(h, B, n_iters, 0, X, U, x_term, lamb, obs, cost, K, k, iters, status,
-                            (hipStream_t)stream));
+  return debug_check(dispatch_iterate(h, B, n_iters, 0, X, U, x_term, lamb, obs, cost, K, k, iters,
+                                      status, stream), stream);
 }
 
 int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* lamb,
@@ -1101,8 +1201,8 @@ int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term
   if (!X || !U || !x_term || !lamb || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
   if ((K == nullptr) != (k == nullptr))
     return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
-  I2LQR_DISPATCH(h, iterate(h, B, h->cfg.max_iter, 1, X, U, x_term, lamb, obs, cost, K, k, iters,
-                            status, (hipStream_t)stream));
+  return debug_check(dispatch_iterate(h, B, h->cfg.max_iter, 1, X, U, x_term, lamb, obs, cost, K, k,
+                                      iters, status, stream), stream);
 }
 
 int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_term,

@@ -8,6 +8,10 @@
 
 namespace i2lqr {
 
+// Debug build: the device word the kernels record an index violation in (i2lqr_debug.hpp), one
+// per process and device, allocated on first use (i2lqr_abi.hip); null in the product build.
+unsigned long long* debug_trap_word();
+
 template <class T, int n, int m> inline DevCfg<T, n, m> make_dev_cfg(const i2lqr_config& h) {
   DevCfg<T, n, m> d;
   std::memset(&d, 0, sizeof(d));
@@ -64,6 +68,7 @@ template <class T, int n, int m> inline DevCfg<T, n, m> make_dev_cfg(const i2lqr
     }
   }
   d.flags = (hasQ ? FLAG_HAS_Q : 0) | (hasR ? FLAG_HAS_R : 0);
+  d.trap = debug_trap_word();
   return d;
 }
 

@@ -137,7 +137,7 @@ template <class T, class Sys> struct GroupWorker {
   static_assert(GP::ok(), "plant does not have the column structure this kernel is written for");
   const Cfg& c;
   const GL L;
-  T* const S;        // this problem's LDS slice
+  const Slice<T> S;  // this problem's LDS slice
   const T* const Qt; // the wavefront's copy of Q_terminal
   const int g;       // lane inside the group = column index
   const int N;
@@ -158,7 +158,8 @@ template <class T, class Sys> struct GroupWorker {
 
   __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
       : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N).total,
-                    smem + GLayout<Sys>(c_.N).qt_base(), lane % kGroup) {
+                    smem + GLayout<Sys>(c_.N).qt_base(), lane % kGroup,
+                    GLayout<Sys>(c_.N).total) {
     const int p = lane / kGroup;
     T1c = smem + L.t1_base() + p * GL::kT1Stride;
     rho = (p >> 1) & 1;
@@ -168,9 +169,10 @@ template <class T, class Sys> struct GroupWorker {
     return (row >> 1) * (2 * kGroup) + ((col + rho) & (kGroup - 1)) * 2 + (row & 1);
   }
 
-  // slice: this problem's LDS slice; qt: Q_terminal in LDS
-  __device__ GroupWorker(const Cfg& c_, T* slice, const T* qt, int g_)
-      : c(c_), L(c_.N), S(slice), Qt(qt), g(g_), N(c_.N) {
+  // slice: this problem's LDS slice of slice_words words; qt: Q_terminal in LDS
+  __device__ GroupWorker(const Cfg& c_, T* slice, const T* qt, int g_, int slice_words)
+      : c(c_), L(c_.N), S(make_slice(slice, slice_words, c_.trap, TAG_GROUP_LDS)), Qt(qt), g(g_),
+        N(c_.N) {
     oR = L.R; oKk = L.Kk;
     T1c = nullptr;  // set by the caller (with rho) before the first pass
     rho = 0;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   GroupWorker<T, Sys> w(c, smem, lane);
   const int N = c.N, g = w.g;
   const GL& L = w.L;
-  T* S = w.S;
+  const auto S = w.S;
 
   // entry: x0, U, x_term, lamb, obs (HBM, problem-major records) -> LDS / registers.  Only the
   // main wavefront stores: rollout() clips the inputs IN these LDS words right away, and a late
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   T* const S = smem + p * SLay.total;
   T* const QtL = smem + kGroupsPerWave * SLay.total;
   T* const CN = QtL + n * n;  // [V + 1][8]: candidate cost of wavefront v / rollout cost at row V
-  GroupWorker<T, Sys> w(c, S, QtL, g);
+  GroupWorker<T, Sys> w(c, S, QtL, g, SLay.total);
   w.oR = SLay.R;
   w.oKk = SLay.var0 + v * SLay.var_words + SLay.Kk_in_var;
   w.T1c = S + SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;

@@ -166,6 +166,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   }
   template <int CNT, class P, class F>
   __device__ __forceinline__ void for_rows(P* p, int row0, F&& f) const {
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, row0 + CNT - 1, m * n * N + n);  // (largest array)
     static_for<0, (CNT + 7) / 8>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
       P* q = rows(p, row0 + 8 * g);
@@ -175,13 +176,30 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       });
     });
   }
-  static __device__ __forceinline__ int rx(int i, int t) { return t * n + i; }
-  static __device__ __forceinline__ int ru(int a, int t) { return t * m + a; }
-  static __device__ __forceinline__ int rK(int a, int j, int t) { return (t * m + a) * n + j; }
+  // (debug build: the indices are checked against the array's extent, i2lqr_debug.hpp)
+  __device__ __forceinline__ int rx(int i, int t) const {
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_X, t * n + i, n * (N + 1));
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_X, i, n);
+    return t * n + i;
+  }
+  __device__ __forceinline__ int ru(int a, int t) const {
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_U, t * m + a, m * N);
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_U, a, m);
+    return t * m + a;
+  }
+  __device__ __forceinline__ int rK(int a, int j, int t) const {
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, (t * m + a) * n + j, m * n * N);
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, j, n);
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, a, m);
+    return (t * m + a) * n + j;
+  }
   __device__ __forceinline__ T& lds_gain(int t, int q) const {  // 1 <= t <= lds_steps
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, t - 1, lds_steps);
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, q, m * (n + 1));
     return lds[((t - 1) * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
   }
   __device__ __forceinline__ T& lds_k0(int a) const {
+    I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, a, m);
     return lds[(lds_steps * (m * (n + 1)) + a) * 64 + (threadIdx.x & 63)];
   }
   // write the LDS-resident gains of this lane to HBM (kernel exit; K_0 is there already)
@@ -510,7 +528,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     const unsigned l64 = threadIdx.x & 63;
     // state k of the current segment (k = 0: the checkpoint), component i: conflict-free LDS words
-    auto seg_at = [&](int k, int i) -> T& { return seg[(k * n + i) * 64 + l64]; };
+    auto seg_at = [&](int k, int i) -> T& {
+      I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, k * n + i, (kSeg + 1) * n);
+      return seg[(k * n + i) * 64 + l64];
+    };
     T useg[kSeg][m];  // inputs of the current segment
     // re-roll segment sg (steps sg kSeg .. sg kSeg + len - 1) from its checkpoint into LDS
     auto roll_segment = [&](const int sg, const int len) __attribute__((always_inline)) {
@@ -1097,6 +1118,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           T acc = T(0);
 #pragma unroll
           for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], g[bb], acc);
+          I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, (a * (n + 1) + j) * 64 + l64, kGainWords);
           kcs[(a * (n + 1) + j) * 64 + l64] = -acc;
         }
       });
@@ -1680,18 +1702,24 @@ template <class T, bool USER_TILED>
 __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneSet<T> src,
                                                       int src_is_user, const int32_t* count_in,
                                                       LaneSet<T> dst, int32_t* count_out,
-                                                      LaneSet<T> usr) {
+                                                      LaneSet<T> usr,
+                                                      unsigned long long* trap = nullptr) {
+  (void)trap;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t live = count_in ? (int64_t)*count_in : src.B;
   if (i >= live) return;
   const int rx = n * (N + 1), ru = m * N, rK = m * n * N;
   // address of (row, problem) in the caller's layout / in a batch-minor work set
   auto uaddr = [&](int rows, int row, int64_t p) -> int64_t {
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, row, rows);
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, p, usr.B);
     if (USER_TILED) return ((p >> 6) * rows + row) * 64 + (p & 63);
     return (int64_t)row * usr.B + p;
   };
   auto saddr = [&](int rows, int row, int64_t p) -> int64_t {
     if (src_is_user) return uaddr(rows, row, p);
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, row, rows);
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, p, src.B);
     return (int64_t)row * src.B + p;
   };
   // rows are moved eight at a time: eight independent loads in flight, then eight stores (the
@@ -1729,6 +1757,7 @@ __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneS
   }
   if (!dst.X) return;  // final pass: nothing survives (every problem has a terminal status)
   const int64_t j = atomicAdd(count_out, 1);
+  I2LQR_DBG_CHECK(trap, TAG_COMPACT, j, dst.B);
   // a survivor carries its inputs and x_0 only (the rows t = 0 of the time-major X): every chunk
   // starts by rolling the states out again
   move_rows(n, [&](int r, T v) { dst.X[(int64_t)r * dst.B + j] = v; },

@@ -141,8 +141,8 @@ template <class T, class Sys> struct QuadWorker {
   static constexpr int NZ = QP::NZ;
   const Cfg& c;
   const QL L;
-  T* const S;    // this problem's LDS slice
-  T* const Wp;   // this problem's HBM workspace
+  const Slice<T> S;   // this problem's LDS slice
+  const Slice<T> Wp;  // this problem's HBM workspace
   const int g;   // lane inside the group = column index
   const int N;
   T pc[NC];      // plant constants
@@ -160,15 +160,19 @@ template <class T, class Sys> struct QuadWorker {
 #endif
 
   __device__ QuadWorker(const Cfg& c_, T* smem, T* ws, int lane, int64_t prob)
-      : c(c_), L(c_.N), S(smem + (lane / kQG) * QLayout<Sys>(c_.N).lds_total),
-        Wp(ws + prob * (int64_t)QLayout<Sys>(c_.N).ws_total), g(lane % kQG), N(c_.N) {
+      : c(c_), L(c_.N),
+        S(make_slice(smem + (lane / kQG) * QLayout<Sys>(c_.N).lds_total,
+                     QLayout<Sys>(c_.N).lds_total, c_.trap, TAG_QUAD_LDS)),
+        Wp(make_slice(ws + prob * (int64_t)QLayout<Sys>(c_.N).ws_total,
+                      QLayout<Sys>(c_.N).ws_total, c_.trap, TAG_QUAD_WS)),
+        g(lane % kQG), N(c_.N) {
 #pragma unroll
     for (int q = 0; q < NC; q++) pc[q] = Sys::plant_const(c, q);
     // Bank phase: a ds_read_b128 is served in lane groups that hold eight lanes of one problem
     // and eight of its neighbour; the columns are rotated so that problem p's column c sits in
     // 16-byte slot (c + 12 p) mod 16 of the bank row whatever the slice size is (the rotation that
     // leaves the fewest shared slots for this plant's column lists).
-    const int slot0 = (int)(((unsigned)(uintptr_t)(S + L.EX) >> 4) & 15u);
+    const int slot0 = (int)(((unsigned)(uintptr_t)(T*)(S + L.EX) >> 4) & 15u);
     const int rot = (12 * (lane / kQG) - slot0) & 15;
 #pragma unroll
     for (int s = 0; s < NZ; s++) { off_c[s] = QL::R_ZERO; srcw[s] = 2 * (rot & 15); }
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(64) void k_quad_iterate(const DevCfg<T, Sys::n, Sys
   QuadWorker<T, Sys> w(c, smem, ws, lane, prob0);
   const int N = c.N, g = w.g;
   const QL& L = w.L;
-  T* S = w.S;
+  const auto S = w.S;
 
   {
     const T* gX = a.X + prob * (int64_t)(n * (N + 1));

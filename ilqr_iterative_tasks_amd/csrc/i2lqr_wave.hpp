@@ -18,6 +18,7 @@
 
 #include <type_traits>
 
+#include "i2lqr_debug.hpp"
 #include "i2lqr_systems.hpp"
 
 // A wavefront alone on its SIMD pays ~100 cycles for every TAKEN branch (instruction-fetch bubble;
@@ -47,6 +48,7 @@ template <class T, int n, int m> struct DevCfg {
   // plant_const(0..5)}).
   T ctrl_q12, ctrl_q122, obs_q12, obs_q122;
   T pd[16];
+  unsigned long long* trap;  // debug build: the handle's violation record (i2lqr_debug.hpp); null otherwise
 };
 
 template <class T> struct IterArgs {
@@ -170,15 +172,17 @@ template <class T, class Sys, int LANES, bool HASQR, bool FSTEP = false> struct 
   using Cfg = DevCfg<T, n, m>;
   const Cfg& c;
   const Layout<Sys> L;
-  T* const S;   // this problem's LDS slice
-  const int sl; // lane index inside the problem's lane group
+  const Slice<T> S;  // this problem's LDS slice
+  const int sl;      // lane index inside the problem's lane group
   const int N;
 #ifdef I2LQR_STAMPS
   mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
 #endif
 
   __device__ Worker(const Cfg& c_, T* smem, int lane)
-      : c(c_), L(c_.N, FSTEP), S(smem + (lane / LANES) * Layout<Sys>(c_.N, FSTEP).total),
+      : c(c_), L(c_.N, FSTEP),
+        S(make_slice(smem + (lane / LANES) * Layout<Sys>(c_.N, FSTEP).total,
+                     Layout<Sys>(c_.N, FSTEP).total, c_.trap, TAG_WAVE_LDS)),
         sl(lane % LANES),
         N(c_.N) {}
 
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(64) void k_iterate(const DevCfg<T, Sys::n, Sys::m> 
   Worker<T, Sys, LANES, HASQR, FSTEP> w(c, reinterpret_cast<T*>(smem_raw), lane);
   const int N = c.N;
   const auto& L = w.L;
-  T* S = w.S;
+  const auto S = w.S;
   const int64_t Bs = SETIO ? a.set_stride : 0;
 
   // entry: x0, U, x_term, lamb, obs  (HBM -> LDS/registers)

@@ -32,7 +32,10 @@
  *  - obs record = {x, y, width, height, spd, moving_option}; moving_option 0 = static,
  *    1 = moving up (+y), 2 = moving left (-x) (utils/base.py:23-34, control/ilqr_helper.py:34-43);
  *    moving_option < 0 disables the obstacle for that problem (the reference's `obstacle is None`).
- *    A NULL obs pointer disables it for the whole batch.
+ *    A NULL obs pointer disables it for the whole batch.  A record with moving_option 0 is a
+ *    STATIC obstacle whatever its spd word holds (the word is not read); the reference raises a
+ *    NameError for spd != 0 with moving_option None — the Python host rejects that combination
+ *    (ValueError in control/params.py:obstacle_record), the C-ABI defines it.
  */
 #ifndef I2LQR_H
 #define I2LQR_H
@@ -225,13 +228,20 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.
  *                     Automatic: on while every wavefront of the launch fits on the chip at once
  *                     (n <= 6 systems).
+ *   "debug_self_test" index-checked debug build only (make -C ilqr_iterative_tasks_amd/csrc debug ->
+ *                     libi2lqr_hip_debug.so): provokes one recorded index violation and returns
+ *                     what the next call would, I2LQR_ERR_LAUNCH with the decoded record; the
+ *                     product library answers I2LQR_ERR_UNSUPPORTED.  In that build every call
+ *                     synchronises its stream and reports violations of its LDS slices, HBM
+ *                     workspace slots and row addressing as I2LQR_ERR_LAUNCH.
  */
 int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 
 /* Name of the kernel i2lqr_iterate (fixed iteration count) launches for a batch of B problems
  * with the handle's current options ("k_iterate", "k_group_iterate", "k_group_spec",
- * "k_quad_iterate", "k_lane_iterate"): what to look for in a rocprofv3 kernel trace.  Host only;
- * "" for a NULL handle. */
+ * "k_quad_iterate", "k_lane_iterate", "k_lane_iterate_rows"; "unsupported" if a forced option
+ * cannot be honoured and the launch would return I2LQR_ERR_UNSUPPORTED): what to look for in a
+ * rocprofv3 kernel trace.  Host only; "" for a NULL handle. */
 const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B);
 /* The same for i2lqr_solve / early-exit calls (the dominant kernel; the chunked solves of the lane
  * layouts also launch k_lane_compact and a tail kernel). */

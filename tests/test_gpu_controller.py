@@ -202,3 +202,34 @@ def test_ilqr_dropin_signature_matches_reference_calls(golden_dir):
     for t in range(6):
         roll.append(plant_step(roll[-1], [2.0, 1.57], 1))
     np.testing.assert_allclose(xvar, np.array(roll).T, rtol=1e-13, atol=1e-13)
+
+
+def test_ilqr_dropin_with_moving_obstacles_matches_reference_calls(golden_dir):
+    """The drop-in ilqr() with Obstacle objects of both moving options (up: option 1, left: option
+    2; control/ilqr_helper.py:37-43, result/ilqr_test_add_moving_obstacle.py:18-31) against the
+    reference's own calls (golden G3), beside the static and the no-obstacle ones."""
+    g = np.load(golden_dir / "g3_scenarios.npz")
+    param, sysp = iLqrParam(num_horizon=6, timestep=1), KineticBicycleParam()
+    seen = set()
+    for i in range(len(g["x0"])):
+        rec = g["obs"][i]
+        kind = (float(rec[4]), int(rec[5]))
+        seen.add(kind)
+        if sum(1 for j in range(i) if (float(g["obs"][j][4]), int(g["obs"][j][5])) == kind) >= 12:
+            continue  # a dozen calls per obstacle kind
+        if rec[5] < 0:
+            obstacle = None
+        elif rec[5] == 0:
+            obstacle = Obstacle(*rec[:4])
+        else:
+            obstacle = Obstacle(rec[0], rec[1], rec[2], rec[3], spd=rec[4], timestep=1,
+                                moving_option=int(rec[5]))
+        uvar, xvar, dX = np.zeros((2, 6)), np.zeros((4, 7)), np.zeros((4, 7))
+        xvar[:, 0] = g["x0"][i]
+        dX[:, 0] = xvar[:, 0]
+        u, x, lamb = ilqr(param, 6, np.zeros(4), 1, obstacle, sysp, g["x_term"][i], dX, uvar, xvar,
+                          g["lamb_in"][i])
+        assert lamb == g["lamb_out"][i], (i, kind)
+        assert batch_rel_err(x[None], g["X"][i][None]) < 1e-8, (i, kind)
+        assert batch_rel_err(u[None], g["U"][i][None], floor=1e-2) < 1e-8, (i, kind)
+    assert (1.0, 1) in seen and (0.2, 2) in seen  # both moving options were exercised
