@@ -459,7 +459,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // k_0 of 64 lanes: step 0 keeps only its feed-forward term in LDS (LaneWorker::lds_k0)
   static constexpr int kK0Bytes = 64 * m * (int)sizeof(T);
   // State checkpointing (i2lqr_lane.hpp): fp64 with deferred, merged states and the re-rolling
-  // forward pass, Q = R = 0; automatic from 262144 problems (where the kernel sits on the HBM
+  // forward pass, Q = R = 0; automatic from 65536 problems (where the kernel sits on the HBM
   // roof).  Its segment buffer takes the place of LDS-resident gain steps.  Must be called again
   // after any later change of defer / reroll / merge (the early-exit path does).
   static void finish_options(const i2lqr_handle* h, int64_t B, LaneArgs<T>& a) {
@@ -467,9 +467,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     for (int i = 0; i < I2LQR_MAX_N * I2LQR_MAX_N && !hasqr; i++) hasqr = h->cfg.Q[i] != 0.0;
     for (int i = 0; i < I2LQR_MAX_M * I2LQR_MAX_M && !hasqr; i++) hasqr = h->cfg.R[i] != 0.0;
     const bool can = sizeof(T) == 8 && !hasqr && a.defer && a.merge && a.reroll && h->cfg.N >= 2;
-    // (tools/ab_bench.py: -4 % at 65536 problems, -2 % at 131072, +5.7 % at 262144, +4-6 % at
-    // 2^20; HBM bytes per problem-iteration at 2^20: 7224 -> 6457)
-    a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= 262144);
+    // (tools/ab_bench.py --cold, round 3: -2 % at 65536 problems, +-0 at 131072, +5 % at 262144,
+    // +4-6 % at 2^20; HBM bytes per problem-iteration 6993 -> 6243 (1.41 -> 1.26 x algorithmic):
+    // on from 65536 problems, BASELINE's roofline batch and half a per-GPU shard of configs[3] —
+    // where the kernel already sits on the HBM roof the bytes are what is left to win)
+    a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= 65536);
     if (a.ckpt) {
       const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
       int steps = (37 * 1024 - kSegBytes - kK0Bytes) / per_step;

@@ -179,7 +179,7 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     HBM; the backward pass re-rolls the states of four horizon steps at a time
  *                     from their checkpoint into LDS (bit-identical values).  A quarter of the
  *                     state traffic for one more plant step per horizon step; the segment buffer
- *                     replaces two LDS-resident gain steps.  Automatic: 1 from 262144 problems.
+ *                     replaces two LDS-resident gain steps.  Automatic: 1 from 65536 problems.
  *   "reroll_nominal"  1: the forward pass re-rolls the nominal states it needs for the feedback
  *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
  *   "lds_gain_steps"  upper bound on the horizon steps 1, 2, ... whose gains stay in LDS between
