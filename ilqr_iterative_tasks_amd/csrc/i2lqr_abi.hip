@@ -119,7 +119,7 @@ struct i2lqr_handle {
   int64_t ws_bytes;
   int64_t compact_min_batch;  // i2lqr_solve uses the chunked, compacting form from this batch; 0: never; -1: automatic
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
-  int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt;
+  int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt, opt_stagger;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
@@ -423,6 +423,12 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.merge = sizeof(T) == 8 ? 1 : 0;
     if (h->opt_merge >= 0) a.merge = h->opt_merge;
     a.ckpt = 0;  // decided in finish_options() once the other options are final
+    a.stagger = 0;
+    if constexpr (Sys::NBLK > 0) {
+      // automatic where the launch fills the chip (one wavefront per SIMD: 65536 problems)
+      a.stagger = B >= 65536 ? 45 : 0;
+      if (h->opt_stagger >= 0) a.stagger = h->opt_stagger > 999 ? 999 : h->opt_stagger;
+    }
     a.dbg = nullptr;
 #ifdef I2LQR_STAMPS
     if (const char* e = getenv("I2LQR_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -1031,7 +1037,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
-  h->opt_merge = h->opt_ckpt = h->opt_spec = -1;
+  h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -1102,6 +1108,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "lds_gain_steps")) h->opt_lds_steps = v;
   else if (!strcmp(name, "merge_inputs")) h->opt_merge = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "checkpoint_states")) h->opt_ckpt = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "stagger")) h->opt_stagger = v;
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);

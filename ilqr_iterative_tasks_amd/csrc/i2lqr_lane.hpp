@@ -61,6 +61,7 @@ template <class T> struct LaneArgs {
   int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
   int merge;      // deferred mode: accepted candidate inputs are merged into ONE input buffer
   int ckpt;       // only every kSeg-th state lives in HBM between the passes (see backward<.., CK>)
+  int stagger;    // k_lane_iterate_rows: every second half-thousand of workgroups starts this many x ~8000 cycles late
 };
 
 // State checkpointing (fp64, large batches: the kernel sits on the HBM roof).  Between the passes of
@@ -1325,42 +1326,49 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // re-rolled from the nominal inputs next to the candidate (bit-identical to the stored X: same
   // code, same inputs), the candidate inputs go to Un, no candidate state is stored (an accepted
   // step re-rolls them: restore_rows()).  Same arithmetic, word for word, as forward<true, false>;
-  // the step's 56 words are loaded one step ahead through row groups.
+  // the step's 56 words are loaded two steps ahead through row groups.
   template <bool GENERAL>
   __device__ __forceinline__ T forward_rows(const T* X, const T* U, const T* gK, const T* gk, T* Un,
                                             const T (&xT)[n], bool* bad) const {
     T x[n], u[m], xn[n], tr[NT];
-    T xo[n], ul[m], kl[m][n + 1];  // nominal state (re-rolled), nominal inputs and gains of the step
+    T xo[n];  // nominal state (re-rolled)
+    // Nominal inputs and gains of a step: two register sets take turns, each re-loaded for step
+    // t + 2 right after step t has consumed it.  A step is ~550 instructions (~1 us) — less than
+    // an HBM round trip under load (~3 us with every wavefront streaming): with a one-step
+    // distance every step waited ~8000 cycles for its 56 words.
+    struct Buf { T ul[m], kl[m][n + 1]; };
+    Buf A, B;
     for_rows<n>(X, rx(0, 0), [&](auto i_, const T& w) { x[decltype(i_)::value] = w; });
-    // step 0: x_0 is common to the nominal and the candidate, K_0 multiplies zeros and is not read
 #pragma unroll
     for (int i = 0; i < n; i++) xo[i] = x[i];
-    for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
-    for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
+    auto load_step = [&](const int t, Buf& q) __attribute__((always_inline)) {
+      for_rows<m>(U, ru(0, t), [&](auto a_, const T& w) { q.ul[decltype(a_)::value] = w; });
+      for_rows<m * n>(gK, rK(0, 0, t), [&](auto e_, const T& w) {
+        constexpr int e = decltype(e_)::value;
+        q.kl[e / n][e % n] = w;
+      });
+      for_rows<m>(gk, ru(0, t), [&](auto a_, const T& w) { q.kl[decltype(a_)::value][n] = w; });
+    };
+    // step 0: x_0 is common to the nominal and the candidate, K_0 multiplies zeros and is not read
+    for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { A.ul[decltype(a_)::value] = w; });
+    for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { A.kl[decltype(a_)::value][n] = w; });
 #pragma unroll
     for (int a = 0; a < m; a++)
 #pragma unroll
-      for (int j = 0; j < n; j++) kl[a][j] = T(0);
+      for (int j = 0; j < n; j++) A.kl[a][j] = T(0);
+    load_step(N >= 2 ? 1 : 0, B);
     T cost = T(0);
-    for (int t = 0; t < N; t++) {
+    auto body = [&](const int t, Buf& q) __attribute__((always_inline)) {
       T uo[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kl[a][j], x[j] - xo[j], acc);
-        u[a] = clip(ul[a] + kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
-        uo[a] = ul[a];
+        for (int j = 0; j < n; j++) acc = t_fma(q.kl[a][j], x[j] - xo[j], acc);
+        u[a] = clip(q.ul[a] + q.kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        uo[a] = q.ul[a];
       }
-      {  // the words of step t + 1 (the last step loads its own again: no branch)
-        const int tl = t + 1 < N ? t + 1 : t;
-        for_rows<m>(U, ru(0, tl), [&](auto a_, const T& w) { ul[decltype(a_)::value] = w; });
-        for_rows<m * n>(gK, rK(0, 0, tl), [&](auto e_, const T& w) {
-          constexpr int e = decltype(e_)::value;
-          kl[e / n][e % n] = w;
-        });
-        for_rows<m>(gk, ru(0, tl), [&](auto a_, const T& w) { kl[decltype(a_)::value][n] = w; });
-      }
+      load_step(t + 2 < N ? t + 2 : N - 1, q);  // (the last steps load a row again: no branch)
       for_rows<m>(Un, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
       // nominal state of step t + 1, re-rolled from the nominal inputs (the pass streams the gains
       // at the HBM rate and has issue slots to spare: n fewer rows to read per step)
@@ -1375,7 +1383,13 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       cost = cost + stage_cost(x, xT, u);
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
+    };
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      body(t, A);
+      body(t + 1, B);
     }
+    if (t < N) body(t, A);
     cost = cost + terminal_cost(x, xT);
     return cost;
   }
@@ -1619,6 +1633,15 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
   __shared__ T lds_gains[LaneWorker<T, Sys, false, TILED>::kGainWords];
+  // Stagger: every wavefront of a full-chip launch does the same work in the same order, so all of
+  // them stream their gains at once (the forward pass: at the HBM rate, issue slots idle) and all
+  // of them compute at once (the backward pass: issue-bound, HBM half idle).  Workgroups 512-1023
+  // of every 1024 — two of the four wavefronts a CU holds — start a.stagger x ~8000 cycles late,
+  // so that one half streams while the other computes (+5-7 % at 65536 problems; the delay itself
+  // is paid once per launch).
+  if (a.stagger > 0 && ((blockIdx.x >> 9) & 1)) {
+    for (int q = 0; q < a.stagger; q++) __builtin_amdgcn_s_sleep(127);
+  }
   T cost = w.rollout(X, Uc, xT);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
