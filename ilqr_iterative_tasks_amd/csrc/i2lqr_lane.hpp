@@ -824,7 +824,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // products associated differently (K^T Quu K = A^T (Kc^T Quu Kc) A): agreement with the other
   // kernel families and the oracle is to round-off, not bit for bit.  Nothing of size n x n lives
   // next to V, and the gains are stored and dead before the state blocks are applied.
-  static constexpr int kGainWords = m * (n + 1) * 64;  // LDS words per wavefront (backward_blocked)
+  // LDS words per wavefront of backward_blocked: the step's [Kc | k] and, parked there between
+  // their producer and their (late) consumers instead of occupying registers through the sweep:
+  // the obstacle terms o[5], l_u[m], the sin / cos values, the Sys::NJX state entries and u[m]
+  // that the second evaluation of the Jacobian needs
+  static constexpr int kParkO = m * (n + 1), kParkLu = kParkO + 5, kParkTr = kParkLu + m,
+                       kParkJx = kParkTr + NT, kParkU = kParkJx + Sys::NJX,
+                       kStepSlots = kParkU + m;
+  static constexpr int kGainWords = kStepSlots * 64;
   static constexpr bool e_nz(int i, int j) {
     return i == j ? Sys::pat(i, j) != 1 : Sys::pat(i, j) != 0;
   }
@@ -1056,6 +1063,17 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
         lxq[a] = l;
       }
+      // park what only the end of the step reads (see kStepSlots)
+#pragma unroll
+      for (int q = 0; q < 5; q++) kcs[(kParkO + q) * 64 + l64] = o[q];
+#pragma unroll
+      for (int a = 0; a < m; a++) kcs[(kParkLu + a) * 64 + l64] = lu[a];
+#pragma unroll
+      for (int q = 0; q < NT; q++) kcs[(kParkTr + q) * 64 + l64] = tr[q];
+#pragma unroll
+      for (int q = 0; q < Sys::NJX; q++) kcs[(kParkJx + q) * 64 + l64] = xe[Sys::jx(q)];
+#pragma unroll
+      for (int a = 0; a < m; a++) kcs[(kParkU + a) * 64 + l64] = u[a];
       // ---- gains.  [Kc | k] never lives in registers as a whole (52 doubles next to the 90 of
       // [Vxx | Vx]): its columns go to this wavefront's LDS slice as they are formed and come back
       // in the order the two consumers want them — word (a, j) of lane l at kcs[(a (n+1) + j) 64 + l],
@@ -1112,7 +1130,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         gcol(j_, g);
         if constexpr (j == n) {
 #pragma unroll
-          for (int a = 0; a < m; a++) g[a] = lu[a] + g[a];  // Qu = l_u + B^T Vx
+          for (int a = 0; a < m; a++) g[a] = kcs[(kParkLu + a) * 64 + lrd] + g[a];  // Qu = l_u + B^T Vx
         }
 #pragma unroll
         for (int a = 0; a < m; a++) {
@@ -1125,7 +1143,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       });
       // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu
       // (control/iterative_ilqr.py:128-129 before the state Jacobian is applied), one row b of
-      // Y = Quu Kc at a time: [W | w][i][j] -= Y[b][i] [Kc | k][b][j]
+      // Y = Quu Kc at a time: [W | w][i][j] -= Y[b][i] [Kc | k][b][j].  The rows of Kc come back
+      // from LDS two at a time (24 words in flight, one wait per pair, fenced: with the loads left
+      // to the scheduler every pair of words was waited for on its own, ~100 cycles each — 60 % of
+      // the step's time in this phase).
       I2LQR_PHASE_FENCE();
       static_for<0, m>([&](auto b_) {
         constexpr int bb = decltype(b_)::value;
@@ -1133,14 +1154,22 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         asm volatile("" : "+v"(lrd));  // this pass reads its words again (no reuse across passes)
 #pragma unroll
         for (int i = 0; i < n; i++) y[i] = T(0);
-        static_for<0, m>([&](auto a_) {
-          constexpr int a = decltype(a_)::value;
+        static_for<0, m / 2>([&](auto h_) {
+          constexpr int a0 = 2 * decltype(h_)::value;
+          T r0[n], r1[n];
 #pragma unroll
           for (int i = 0; i < n; i++) {
-            const T kai = kcs[(a * (n + 1) + i) * 64 + lrd];
-            if constexpr (a == bb) kb[i] = kai;
-            y[i] = t_fma(Quu[bb * m + a], kai, y[i]);
+            r0[i] = kcs[(a0 * (n + 1) + i) * 64 + lrd];
+            r1[i] = kcs[((a0 + 1) * (n + 1) + i) * 64 + lrd];
           }
+          I2LQR_PHASE_FENCE();
+#pragma unroll
+          for (int i = 0; i < n; i++) {
+            y[i] = t_fma(Quu[bb * m + a0], r0[i], y[i]);
+            y[i] = t_fma(Quu[bb * m + a0 + 1], r1[i], y[i]);
+            if constexpr (a0 == (bb & ~1)) kb[i] = (bb & 1) ? r1[i] : r0[i];
+          }
+          I2LQR_PHASE_FENCE();
         });
         kb[n] = kcs[(bb * (n + 1) + n) * 64 + lrd];
 #pragma unroll
@@ -1156,18 +1185,15 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       {  // the A entries of the Jacobian, formed again (hidden from value numbering: the compiler
          // would otherwise keep the first evaluation's 25 doubles live through the phases above)
         T xr[n], ur[m], trr[NT];
+        asm volatile("" : "+v"(lrd));
 #pragma unroll
-        for (int i = 0; i < n; i++) xr[i] = xe[i];
+        for (int i = 0; i < n; i++) xr[i] = T(0);
 #pragma unroll
-        for (int a = 0; a < m; a++) ur[a] = u[a];
+        for (int q = 0; q < Sys::NJX; q++) xr[Sys::jx(q)] = kcs[(kParkJx + q) * 64 + lrd];
 #pragma unroll
-        for (int q = 0; q < NT; q++) trr[q] = tr[q];
+        for (int a = 0; a < m; a++) ur[a] = kcs[(kParkU + a) * 64 + lrd];
 #pragma unroll
-        for (int i = 0; i < n; i++) opaque(xr[i]);
-#pragma unroll
-        for (int a = 0; a < m; a++) opaque(ur[a]);
-#pragma unroll
-        for (int q = 0; q < NT; q++) opaque(trr[q]);
+        for (int q = 0; q < NT; q++) trr[q] = kcs[(kParkTr + q) * 64 + lrd];
         Sys::jac_var(c, xr, ur, trr, jv);
       }
       // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1} — issued BEFORE
@@ -1206,8 +1232,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
         vx[i] = lxq[i] + vx[i];
       }
-      V[0][0] += o[2]; V[0][1] += o[3]; V[1][1] += o[4];
-      vx[0] += o[0]; vx[1] += o[1];
+      {
+        asm volatile("" : "+v"(lrd));
+        T op[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) op[q] = kcs[(kParkO + q) * 64 + lrd];
+        V[0][0] += op[2]; V[0][1] += op[3]; V[1][1] += op[4];
+        vx[0] += op[0]; vx[1] += op[1];
+      }
       STAMP_END(3);
     }
     return bad;

@@ -525,6 +525,8 @@ __device__ __forceinline__ void t_quu_inverse_m(const T (&Quu)[m * m], T lamb, T
 template <class T> struct Bicycle4 {
   static constexpr int n = 4, m = 2, NTRIG = 2, NVAR = 6;
   static constexpr int NCONST = 0, NBLK = 0;  // no plant-constant entries in F, no row-block form
+  static constexpr int NJX = 0;
+  static constexpr int jx(int) { return 0; }
   static constexpr int blk(int) { return 0; }
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 0;
@@ -601,6 +603,8 @@ template <class T> struct Bicycle4 {
 template <class T> struct Bicycle6 {
   static constexpr int n = 6, m = 2, NTRIG = 2, NVAR = 6;
   static constexpr int NCONST = 0, NBLK = 0;  // no plant-constant entries in F, no row-block form
+  static constexpr int NJX = 0;
+  static constexpr int jx(int) { return 0; }
   static constexpr int blk(int) { return 0; }
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 1;
@@ -837,6 +841,10 @@ template <class T> struct Quad12 {
   // exactly (all cross products vanish), and A^T V A, K A, A^T v become nine IN-PLACE updates that
   // touch only the columns a block's rows reach — no n x n intermediate next to V.  Checked at
   // compile time where it is used.
+  // entries of the evaluation state that jac_var() reads besides the sin / cos values (the body
+  // rates): what LaneWorker::backward_blocked keeps to form the A entries a second time
+  static constexpr int NJX = 3;
+  static constexpr int jx(int k) { return 9 + k; }
   static constexpr int NBLK = 9;
   static constexpr int blk(int i) {
     return i >= 9 ? 0 : (i == 3 || i == 4) ? 1 : i == 5 ? 2 : i >= 6 ? i - 3 : i + 6;

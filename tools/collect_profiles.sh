@@ -7,23 +7,27 @@
 #                  sha256 of the library the counters were collected on
 #                  bench.py JSON line + kernel stats of the bench command itself
 # Results land in gpurun_out/profiles_new/ — copy them into profiles/ afterwards.
-#   bash tools/collect_profiles.sh [round tag, default r02]
+#   bash tools/collect_profiles.sh [round tag, default r03]
 set -u
 ROOT=$(pwd)
-TAG=${1:-r02}
+TAG=${1:-r03}
 NEW=$ROOT/gpurun_out/profiles_new
 RAW=$ROOT/gpurun_out/prof_raw
 rm -rf "$NEW" "$RAW"; mkdir -p "$NEW" "$RAW"
 cd /tmp && export TMPDIR=/tmp
-# name            workload dtype batch    layout iters launches
+# name            workload dtype batch    layout iters launches (>= 10 launches per kernel-trace row)
 WORKLOADS="
-config2_f64_B1024    config2 f64 1024    wave  10 20
-config2_f64_B4096    config2 f64 4096    wave  10 10
-config2_f64_B65536   config2 f64 65536   tiled 10 6
-config2_f32_B65536   config2 f32 65536   tiled 10 6
-config2_f64_B1048576 config2 f64 1048576 tiled 10 3
-config2_f32_B1048576 config2 f32 1048576 tiled 10 3
-config5_f64_B65536   config5 f64 65536   wave  4  2
+config2_f64_B1024    config2 f64 1024    wave  10 24
+config2_f64_B4096    config2 f64 4096    wave  10 24
+config2_f64_B8192    config2 f64 8192    wave  10 24
+config2_f64_B16384   config2 f64 16384   tiled 10 24
+config2_f64_B32768   config2 f64 32768   tiled 10 24
+config2_f64_B65536   config2 f64 65536   tiled 10 24
+config2_f64_B131072  config2 f64 131072  tiled 10 24
+config2_f32_B65536   config2 f32 65536   tiled 10 24
+config2_f64_B1048576 config2 f64 1048576 tiled 10 12
+config2_f32_B1048576 config2 f32 1048576 tiled 10 12
+config5_f64_B65536   config5 f64 65536   tiled 4  16
 "
 SQ_CYC="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES"
 SQ_INS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH"

@@ -68,11 +68,13 @@ for d in sorted(glob.glob(f"{raw}/*_kstats")):
         for r in csv.DictReader(open(f)):
             if "iterate" in r["Name"]:
                 kname, kavg, kcalls = r["Name"], float(r["AverageNs"]), int(r["Calls"])
+                kmin, kmax = float(r.get("MinNs", 0) or 0), float(r.get("MaxNs", 0) or 0)
                 break
     if kname:
         rec["kernel"] = kname.split("<")[0].replace("void ", "").replace("i2lqr::", "")
         rec["kernel_avg_ms_kernel_trace"] = kavg / 1e6
         rec["kernel_calls_kernel_trace"] = kcalls
+        rec["kernel_min_ms_kernel_trace"], rec["kernel_max_ms_kernel_trace"] = kmin / 1e6, kmax / 1e6
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for (kn, c), v in counters(f"{raw}/{name}_{ctr}/**/*counter_collection.csv").items():
             if "iterate" in kn and c == ctr:
