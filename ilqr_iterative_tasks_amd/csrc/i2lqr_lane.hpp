@@ -100,6 +100,9 @@ template <bool TILED> struct LaneView {
 #ifndef I2LQR_DEEP_PREFETCH
 #define I2LQR_DEEP_PREFETCH 1
 #endif
+#ifndef I2LQR_DEEP64
+#define I2LQR_DEEP64 0  // experiment: the two-step prefetch distance of the fp32 kernels in fp64 too
+#endif
 #ifndef I2LQR_F64_WAVES
 #define I2LQR_F64_WAVES 1
 #endif
@@ -512,7 +515,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // what lets the unrolled step stay in registers.  Cost weights must be symmetric (checked in
   // i2lqr_create for these layouts).  The one-problem-per-wavefront kernels keep the full blocks.
   static constexpr bool SYM = true;
-  static constexpr bool DEEP = sizeof(T) == 4 && I2LQR_DEEP_PREFETCH;
+  static constexpr bool DEEP = (sizeof(T) == 4 || I2LQR_DEEP64) && I2LQR_DEEP_PREFETCH;
 
   // CK: checkpointed states (kSeg above); seg = (kSeg + 1) n 64 words of LDS for this wavefront.
   template <bool FASTBAR = false, bool CK = false>
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
   // checkpointed states (fp64 only; host: deferred + merged + re-rolling forward pass, Q = R = 0)
-  constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR && Sys::NBLK == 0;
+  constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR && Sys::NBLK == 0 && !I2LQR_DEEP64;
   const bool ckpt = kCanCkpt && a.ckpt;
   T cost = w.rollout(X, Uc, xT, ckpt);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
