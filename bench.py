@@ -226,17 +226,21 @@ def event_stride_for(steps):
     return max(1, steps // KERNEL_SAMPLES)
 
 
-def empty_bracket_ms(torch, n=20):
-    """Median duration HIP reports for an event pair with nothing in between (the marker packets)."""
-    torch.cuda.synchronize()
-    vals = []
+def empty_bracket_ms(torch, n=30):
+    """Median duration HIP reports for an event pair with nothing in between, on a BUSY stream (a
+    small kernel is enqueued in front of every pair, as in the timed loop where the previous step's
+    kernels are still in flight): the two marker packets themselves.  On an idle stream the same
+    pair reads 2-3 times longer (wake-up), which is not what the brackets of the timed region pay."""
+    x = torch.zeros(1024, device="cuda")
+    pairs = []
     for _ in range(n):
+        x.add_(1.0)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         b.record()
-        torch.cuda.synchronize()
-        vals.append(a.elapsed_time(b))
-    vals.sort()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    vals = sorted(a.elapsed_time(b) for a, b in pairs)
     return vals[len(vals) // 2]
 
 
@@ -244,8 +248,8 @@ def spread(vals):
     """median, min, max and (max - min) / median of a list of durations."""
     v = sorted(vals)
     med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-    return {"median": med, "min": v[0], "max": v[-1], "rel_spread": (v[-1] - v[0]) / med,
-            "samples": len(v)}
+    return {"median": med, "mean": sum(v) / len(v), "min": v[0], "max": v[-1],
+            "rel_spread": (v[-1] - v[0]) / med, "samples": len(v)}
 
 
 def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail=True,
@@ -406,7 +410,9 @@ def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EX
              "k_quad_iterate": "problem-major (four problems per wavefront)"}[kernel])
     solver.close()
     st = spread(vals)
-    return {"kernel": kernel, "layout": name, "kernel_ms": st["median"], "kernel_ms_min": st["min"],
+    return {"kernel": kernel, "layout": name, "kernel_ms": st["median"],
+            "kernel_ms_mean": st["mean"],  # (what a kernel-trace summary's AverageNs compares with)
+            "kernel_ms_min": st["min"],
             "kernel_ms_max": st["max"], "kernel_ms_rel_spread": st["rel_spread"],
             "launches": st["samples"], "warmup": warmup,
             "iterations_per_s": B * iters / (st["median"] * 1e-3)}
@@ -420,7 +426,9 @@ def roofline_entry(cfg, B, iters, r, traffic):
     out = dict(r)
     out.update({"batch": B, "iterations_per_launch": iters,
                 "algorithmic_bytes_per_iteration": bts, "achieved_GBs": ach,
-                "hbm_frac": ach / HBM_PEAK_GBS, "traffic": traffic})
+                "hbm_frac": ach / HBM_PEAK_GBS,
+                "hbm_frac_of_mean": bts * B * iters / (r["kernel_ms_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic})
     if traffic:
         out["traffic_over_algorithmic"] = traffic / (bts * B * iters)
     return out
@@ -715,6 +723,7 @@ def run_rank(args) -> int:
                      # subtracted (kernel_ms_raw_median is what the events report as is)
                      "kernel_ms_avg": res["kernel_ms"],
                      "kernel_ms_samples": res["kernel_ms_stats"]["samples"],
+                     "kernel_ms_mean": res["kernel_ms_stats"]["mean"],
                      "kernel_ms_min": res["kernel_ms_stats"]["min"],
                      "kernel_ms_max": res["kernel_ms_stats"]["max"],
                      "kernel_ms_raw_median": res["kernel_ms_raw_median"],
