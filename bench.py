@@ -358,7 +358,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                kernel_ms_raw_median=spread(raw)["median"], event_pair_overhead_ms=overhead,
                iterations=world * B * args.iters * steps,
                rank_seconds=rank_seconds, kernel=kernel,
-               layout=(LAYOUT_NAME[layout] if kernel != "k_group_iterate" else
+               layout=(LAYOUT_NAME[layout] if not kernel.startswith("k_group_iterate") else
                        "problem-major (eight problems per wavefront)"))
     if exchange is not None:
         res["exchange_ms"] = sum(xv0[i].elapsed_time(xv1[i]) for i in timed) / len(timed)
@@ -405,9 +405,9 @@ def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EX
             vals.append(max(e0.elapsed_time(e1) - overhead, 0.0))
     assert int(sets[-1]["iters"].min()) == iters == int(sets[-1]["iters"].max())
     kernel = solver.iterate_kernel(B)
-    name = (LAYOUT_NAME[layout] if kernel not in ("k_group_iterate", "k_quad_iterate") else
-            {"k_group_iterate": "problem-major (eight problems per wavefront)",
-             "k_quad_iterate": "problem-major (four problems per wavefront)"}[kernel])
+    name = ("problem-major (eight problems per wavefront)" if kernel.startswith("k_group_iterate")
+            else "problem-major (four problems per wavefront)" if kernel == "k_quad_iterate"
+            else LAYOUT_NAME[layout])
     solver.close()
     st = spread(vals)
     return {"kernel": kernel, "layout": name, "kernel_ms": st["median"],
@@ -694,7 +694,8 @@ def run_rank(args) -> int:
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
     key = f"{args.workload}:{dtype}:B{B}:it{args.iters}"
-    waves = {"k_iterate": B, "k_group_iterate": (B + 7) // 8}.get(res["kernel"], (B + 63) // 64)
+    waves = (B if res["kernel"] == "k_iterate" else (B + 7) // 8
+             if res["kernel"].startswith("k_group_iterate") else (B + 63) // 64)
 
     out = {
         "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"

@@ -124,13 +124,14 @@ struct i2lqr_handle {
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
   int opt_spec;   // eight-lane kernel: speculative form (2-3 wavefronts per eight problems); -1 = automatic
+  int opt_group_ws;  // eight-lane kernel: workspace form (records / gains in HBM); -1 = automatic
 };
 
 namespace {
 
 // Which fused kernel a problem-major call runs on: ONE function, used by the launchers and by
 // i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
-enum FusedKernel { K_WAVE, K_GROUP, K_SPEC, K_QUAD, K_INVALID };
+enum FusedKernel { K_WAVE, K_GROUP, K_GROUP_WS, K_SPEC, K_QUAD, K_INVALID };
 constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
 constexpr int64_t kAutoSpecBatch = 8192;   // speculative form for solves up to here (automatic)
 
@@ -169,7 +170,21 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
         (h->opt_spec == 1 ||
          (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
       return K_SPEC;
-    if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) return K_GROUP;
+    if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
+      // more than 4096 problems (two wavefronts per CU are full): the workspace form, four
+      // wavefronts per CU, whenever the caller's workspace is registered ("group_workspace" 0 / 1
+      // pins the choice)
+      const int64_t need = group_workspace_bytes(h->cfg, B);
+      const bool have_ws = need > 0 && h->ws && h->ws_bytes >= need;
+      if (h->opt_group_ws == 1 && !have_ws) {
+        *why = "\"group_workspace\" = 1 needs a registered workspace of i2lqr_workspace_bytes() "
+               "for this batch";
+        return K_INVALID;
+      }
+      if (have_ws && (h->opt_group_ws == 1 || (h->opt_group_ws < 0 && B > kGroupWsBatch)))
+        return K_GROUP_WS;
+      return K_GROUP;
+    }
   } else if (h->opt_group == 8) {
     *why = "\"group_lanes\" = 8 is built for the m = 2 plants only";
     return K_INVALID;
@@ -269,6 +284,12 @@ template <class T, class Sys> struct Launch {
       case K_GROUP:
         if constexpr (m == 2 && n + m <= 8) {
           HIP_TRY(group_iterate<T>(h->cfg, a, s));
+          return I2LQR_OK;
+        }
+        break;
+      case K_GROUP_WS:
+        if constexpr (m == 2 && n + m <= 8) {
+          HIP_TRY(group_iterate_ws<T>(h->cfg, a, h->ws, s));
           return I2LQR_OK;
         }
         break;
@@ -1037,7 +1058,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
-  h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = -1;
+  h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = h->opt_group_ws = -1;
   h->wave_tail = -1;
   HIP_TRY(hipGetDevice(&h->device));
   const int rc = prepare_dispatch(h);
@@ -1068,7 +1089,12 @@ int i2lqr_destroy(i2lqr_handle* h) {
 
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
   if (!h || B < 0) return 0;
-  if (h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) return quad_workspace_bytes(h->cfg, B);
+  if (h->cfg.layout == I2LQR_LAYOUT_PROBLEM_MAJOR) {
+    if (h->cfg.system_id == I2LQR_SYS_QUAD12) return quad_workspace_bytes(h->cfg, B);
+    // the bicycles: the workspace form of the eight-lane kernel, above kGroupWsBatch problems
+    // (or whenever it is pinned); nothing below
+    return (B > kGroupWsBatch || h->opt_group_ws == 1) ? group_workspace_bytes(h->cfg, B) : 0;
+  }
   const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
   const int N = h->cfg.N;
   const bool f64 = h->cfg.dtype == I2LQR_F64;
@@ -1112,6 +1138,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "debug_self_test")) {
     // Debug build only: provoke one index violation on purpose (a Slice of 8 words indexed at 8)
     // and return what the next call would: I2LQR_ERR_LAUNCH with the decoded record.
@@ -1144,6 +1171,7 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
   switch (select_fused(h, B, early_exit, nullptr)) {
     case K_SPEC: return "k_group_spec";
     case K_GROUP: return "k_group_iterate";
+    case K_GROUP_WS: return "k_group_iterate (workspace form)";
     case K_QUAD: return "k_quad_iterate";
     case K_WAVE: return "k_iterate";
     default: return "unsupported";  // the launch returns I2LQR_ERR_UNSUPPORTED

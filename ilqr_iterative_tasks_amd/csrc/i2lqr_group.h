@@ -15,6 +15,14 @@ bool group_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                             hipStream_t stream);
 
+// Workspace form of the same kernel (records and gains in a caller-provided HBM workspace of
+// group_workspace_bytes() for B problems: 4 KB of LDS per problem, four wavefronts per CU): the
+// choice above kGroupWsBatch problems.  0 bytes if the configuration is not supported.
+constexpr int64_t kGroupWsBatch = 4096;
+int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B);
+template <class T> hipError_t group_iterate_ws(const i2lqr_config& cfg, const IterArgs<T>& a,
+                                               void* ws, hipStream_t stream);
+
 // The speculative form of the eight-lane kernel (k_group_spec: three wavefronts per eight problems,
 // wavefront v runs the iteration that follows v rejects): small batches only.
 bool group_spec_supported(const i2lqr_config& cfg);

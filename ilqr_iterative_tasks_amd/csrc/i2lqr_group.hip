@@ -54,6 +54,17 @@ hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s
 // a CU to itself (<= 256 workgroups = 2048 problems): 0.2216 -> 0.2107 ms per 10 iterations at
 // 1024 problems (two / four wavefronts: 0.2122 / 0.2102).  With two workgroups per CU the extra
 // wavefronts crowd the main ones off their SIMDs: 0.25 -> 0.40 ms at 4096 problems.
+// Workspace form (k_group_iterate<.., 1, true>): records and gains in HBM, 4 KB of LDS per problem
+template <class T, class Sys>
+hipError_t launch_ws(const i2lqr_config& cfg, const IterArgs<T>& a, void* ws, hipStream_t s) {
+  const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
+  const size_t lds = (size_t)GLayout<Sys>(cfg.N, true).wave_words() * sizeof(T);
+  if (hipError_t e = raise_lds_limit<k_group_iterate<T, Sys, 1, true>>(lds); e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
+  hipLaunchKernelGGL((k_group_iterate<T, Sys, 1, true>), dim3(grid), dim3(64), lds, s, c, a, (T*)ws);
+  return hipGetLastError();
+}
+
 template <class T, class Sys>
 hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   constexpr int64_t kCUs = 256;
@@ -147,6 +158,33 @@ bool group_supported(const i2lqr_config& cfg) {
       : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<float, Bicycle4<float>>(cfg.N)
                                              : group_lds_bytes<float, Bicycle6<float>>(cfg.N));
   return lds <= 160 * 1024;
+}
+
+int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B) {
+  if (!group_supported(cfg) || B <= 0) return 0;
+  const int64_t probs = (B + kGroupsPerWave - 1) / kGroupsPerWave * kGroupsPerWave;
+  const int64_t words = cfg.system_id == I2LQR_SYS_BICYCLE4
+      ? GLayout<Bicycle4<double>>(cfg.N, true).ws_words()
+      : GLayout<Bicycle6<double>>(cfg.N, true).ws_words();
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4
+             ? (size_t)GLayout<Bicycle4<double>>(cfg.N, true).wave_words() * 8
+             : (size_t)GLayout<Bicycle6<double>>(cfg.N, true).wave_words() * 8)
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4
+             ? (size_t)GLayout<Bicycle4<float>>(cfg.N, true).wave_words() * 4
+             : (size_t)GLayout<Bicycle6<float>>(cfg.N, true).wave_words() * 4);
+  if (lds > 160 * 1024) return 0;
+  return probs * words * (cfg.dtype == I2LQR_F64 ? 8 : 4);
+}
+template <> hipError_t group_iterate_ws<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                                void* ws, hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_ws<double, Bicycle4<double>>(cfg, a, ws, s);
+  return launch_ws<double, Bicycle6<double>>(cfg, a, ws, s);
+}
+template <> hipError_t group_iterate_ws<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                               void* ws, hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_ws<float, Bicycle4<float>>(cfg, a, ws, s);
+  return launch_ws<float, Bicycle6<float>>(cfg, a, ws, s);
 }
 
 template <> hipError_t group_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,

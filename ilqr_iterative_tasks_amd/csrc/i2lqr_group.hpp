@@ -106,12 +106,16 @@ template <class Sys> struct GLayout {
   int N;
   static constexpr int kT1Stride = 80;
   int XU0, XU1, Kk, R, TR0, TR1, total;
-  __host__ __device__ explicit GLayout(int N_) : N(N_) {
+  // ws (k_group_iterate<.., WS = true>): the records and the gains live in a caller-provided HBM
+  // workspace (ws_words() words per problem, L2-resident at the batch sizes this form is for),
+  // LDS keeps the trajectories, the sin / cos caches and ONE step's gain exchange (Kk = m KW
+  // words): 4 KB per problem at n=6, N=20 instead of 9.5 KB — four wavefronts per CU instead of two.
+  __host__ __device__ explicit GLayout(int N_, bool ws = false) : N(N_) {
     int o = 0;
     XU0 = o; o += W * (N + 1); o = (o + 3) & ~3;
     XU1 = o; o += W * (N + 1); o = (o + 3) & ~3;
-    Kk = o; o += m * KW * N; o = (o + 3) & ~3;
-    R = o; o += RW * (N + 1);
+    Kk = o; o += ws ? m * KW : m * KW * N; o = (o + 3) & ~3;
+    R = o; o += ws ? 0 : RW * (N + 1);
     TR0 = o; o += NT * (N + 1); o = (o + 3) & ~3;
     TR1 = o; o += NT * (N + 1); o = (o + 3) & ~3;
     // keep consecutive problem slices on different LDS banks for group-uniform 16-byte reads:
@@ -126,9 +130,13 @@ template <class Sys> struct GLayout {
   // each problem, int flags
   __host__ __device__ int ctl_base() const { return (qt_base() + n * n + 3) & ~3; }
   __host__ __device__ int wave_words() const { return ctl_base() + 16; }
+  // HBM workspace of the ws form, words per problem: records [N+1][RW], gains [N][m][KW]
+  __host__ __device__ int ws_rec() const { return 0; }
+  __host__ __device__ int ws_gain() const { return RW * (N + 1); }
+  __host__ __device__ int ws_words() const { return (RW * (N + 1) + m * KW * N + 15) & ~15; }
 };
 
-template <class T, class Sys> struct GroupWorker {
+template <class T, class Sys, bool WS = false> struct GroupWorker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
   static constexpr int NA = n + 1;
   using Cfg = DevCfg<T, n, m>;
@@ -145,6 +153,7 @@ template <class T, class Sys> struct GroupWorker {
                      // the speculative kernel gives each wavefront its own)
   T* T1c;            // this problem's exchange buffer
   int rho;           // its column rotation (see GLayout)
+  T* Wp = nullptr;   // WS: this problem's HBM workspace (records, gains)
 
   // per-lane column description (constant over the kernel)
   int off_c0, off_c1;        // record offsets of F[0][g], F[1][g]
@@ -157,12 +166,35 @@ template <class T, class Sys> struct GroupWorker {
 #endif
 
   __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
-      : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N).total,
-                    smem + GLayout<Sys>(c_.N).qt_base(), lane % kGroup,
-                    GLayout<Sys>(c_.N).total) {
+      : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N, WS).total,
+                    smem + GLayout<Sys>(c_.N, WS).qt_base(), lane % kGroup,
+                    GLayout<Sys>(c_.N, WS).total) {
     const int p = lane / kGroup;
     T1c = smem + L.t1_base() + p * GL::kT1Stride;
     rho = (p >> 1) & 1;
+  }
+  // record t / gains of step t (LDS slice, or the HBM workspace in the WS form); gain_x: where the
+  // lanes exchange the gain columns of step t (the gains themselves in LDS; one buffer in WS)
+  __device__ __forceinline__ T* rec(int t) const {
+    if constexpr (WS) return Wp + L.ws_rec() + t * GL::RW;
+    else return S + oR + t * GL::RW;
+  }
+  __device__ __forceinline__ T* gain(int t) const {
+    if constexpr (WS) return Wp + L.ws_gain() + t * (m * GL::KW);
+    else return S + oKk + t * (m * GL::KW);
+  }
+  __device__ __forceinline__ T* gain_x(int t) const {
+    if constexpr (WS) return S + oKk;
+    else return S + oKk + t * (m * GL::KW);
+  }
+  // WS: stores to the workspace by one lane are read by the other lanes of the wavefront
+  __device__ __forceinline__ void ws_publish() const {
+    if constexpr (WS) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      wave_sync();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
   }
   // word of (column, row) in the problem's exchange buffer
   __device__ __forceinline__ int t1_word(int col, int row) const {
@@ -171,8 +203,8 @@ template <class T, class Sys> struct GroupWorker {
 
   // slice: this problem's LDS slice of slice_words words; qt: Q_terminal in LDS
   __device__ GroupWorker(const Cfg& c_, T* slice, const T* qt, int g_, int slice_words)
-      : c(c_), L(c_.N), S(make_slice(slice, slice_words, c_.trap, TAG_GROUP_LDS)), Qt(qt), g(g_),
-        N(c_.N) {
+      : c(c_), L(c_.N, WS), S(make_slice(slice, slice_words, c_.trap, TAG_GROUP_LDS)), Qt(qt),
+        g(g_), N(c_.N) {
     oR = L.R; oKk = L.Kk;
     T1c = nullptr;  // set by the caller (with rho) before the first pass
     rho = 0;
@@ -287,7 +319,7 @@ template <class T, class Sys> struct GroupWorker {
       const int t0 = first + r * stride;
       const int t = t0 < N ? t0 : N;          // record index (obstacle term of x_t)
       const int ts = t0 < N ? t0 : N - 1;     // step index (Jacobian entries, input barrier)
-      T* Rs = S + oR + ts * GL::RW;
+      T* Rs = rec(ts);
       {
         T xe[n], tr[NT], u[m], jv[NV];
 #pragma unroll
@@ -314,7 +346,7 @@ template <class T, class Sys> struct GroupWorker {
                               c.ctrl_q122 * e_lo;
         }
       }
-      T* R = S + oR + t * GL::RW;
+      T* R = rec(t);
       R[GL::R_ZERO] = T(0);
       R[GL::R_ONE] = T(1);
       // obstacle barrier: control/ilqr_helper.py:32-51 (stage) / :121-147 (terminal, index N);
@@ -333,6 +365,7 @@ template <class T, class Sys> struct GroupWorker {
       R[GL::R_OB + 4] = has_ob ? c2 * (hd1 * hd1) : T(0);
     }
     wave_sync();
+    ws_publish();
   }
 
   // regularised inverse of Q_uu, m == 2 (control/iterative_ilqr.py:118-123)
@@ -356,7 +389,7 @@ template <class T, class Sys> struct GroupWorker {
     // va[i] = column g of [Vxx | Vx]
     T va[n];
     {
-      const T* Rn = S + oR + N * GL::RW;
+      const T* Rn = rec(N);
       T dx[n];
 #pragma unroll
       for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
@@ -378,22 +411,30 @@ template <class T, class Sys> struct GroupWorker {
     const int gcol = g < GL::KW ? g : GL::KW - 1;  // lanes past the gain row write its padding word
     // The record of a step (uniform and per-lane words) is loaded one step ahead, behind the gain
     // exchange of the previous step: its LDS latency hides under that step's value update.
-    T jv[NV], luu[m], c0, c1, l0, l1, lrow[m];
-    auto load_record = [&](int t) __attribute__((always_inline)) {
-      const T* R = S + oR + t * GL::RW;
+    // WS: the record comes from the HBM workspace (L2): a whole step ahead, into the other of two
+    // register sets.
+    struct Rec { T jv[NV], luu[m], c0, c1, l0, l1, lrow[m]; };
+    Rec ra, rb;
+    auto load_record = [&](int t, Rec& r) __attribute__((always_inline)) {
+      const T* R = rec(t);
 #pragma unroll
-      for (int q = 0; q < NV; q++) jv[q] = R[GL::R_JV + q];
+      for (int q = 0; q < NV; q++) r.jv[q] = R[GL::R_JV + q];
 #pragma unroll
-      for (int a = 0; a < m; a++) luu[a] = R[GL::R_LUU + a];
-      c0 = R[off_c0];
-      c1 = R[off_c1];
-      l0 = R[off_l0];
-      l1 = R[off_l1];
+      for (int a = 0; a < m; a++) r.luu[a] = R[GL::R_LUU + a];
+      r.c0 = R[off_c0];
+      r.c1 = R[off_c1];
+      r.l0 = R[off_l0];
+      r.l1 = R[off_l1];
 #pragma unroll
-      for (int a = 0; a < m; a++) lrow[a] = R[off_lu[a]];
+      for (int a = 0; a < m; a++) r.lrow[a] = R[off_lu[a]];
     };
-    load_record(N - 1);
-    auto step = [&](const int t) __attribute__((always_inline)) {
+    load_record(N - 1, ra);
+    auto step = [&](const int t, Rec& rc, Rec& rn) __attribute__((always_inline)) {
+      if constexpr (WS) load_record(t > 0 ? t - 1 : 0, rn);
+      const T (&jv)[NV] = rc.jv;
+      const T (&luu)[m] = rc.luu;
+      const T (&lrow)[m] = rc.lrow;
+      const T c0 = rc.c0, c1 = rc.c1, l0 = rc.l0, l1 = rc.l1;
       STAMP_BEGIN();
       // P1: own column of T1 = F^T [Vxx | Vx]  (f.T @ V of control/iterative_ilqr.py:112-116)
       T t1[W];
@@ -462,10 +503,21 @@ template <class T, class Sys> struct GroupWorker {
         for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], h[n + b], acc);
         kc[a] = -acc;
       }
-      T* Kt = S + oKk + t * (m * GL::KW);
+      T* Kt = gain_x(t);
+      if constexpr (WS) {
+        // the exchange buffer is one step's: always written; the stored gains (workspace) keep
+        // those of the problem's last executed iteration
+        T* Kg = gain(t);
 #pragma unroll
-      for (int a = 0; a < m; a++)
-        if (commit) Kt[a * GL::KW + gcol] = kc[a];
+        for (int a = 0; a < m; a++) {
+          Kt[a * GL::KW + gcol] = kc[a];
+          if (commit) Kg[a * GL::KW + gcol] = kc[a];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < m; a++)
+          if (commit) Kt[a * GL::KW + gcol] = kc[a];
+      }
       wave_sync();
       STAMP_END(4);
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
@@ -475,7 +527,7 @@ template <class T, class Sys> struct GroupWorker {
       for (int a = 0; a < m; a++)
 #pragma unroll
         for (int i = 0; i < n; i++) kr[a][i] = Kt[a * GL::KW + i];
-      load_record(t > 0 ? t - 1 : 0);
+      if constexpr (!WS) load_record(t > 0 ? t - 1 : 0, rn);
       T qk[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
@@ -496,10 +548,11 @@ template <class T, class Sys> struct GroupWorker {
     // two horizon steps per loop iteration: a taken branch costs a lone wavefront ~100 cycles
     int t = N - 1;
     for (; t >= 1; t -= 2) {
-      step(t);
-      step(t - 1);
+      step(t, ra, rb);
+      step(t - 1, rb, ra);
     }
-    if (t == 0) step(0);
+    if (t == 0) step(0, ra, rb);
+    ws_publish();  // WS: the gains are read back by all lanes of the group in the forward pass
     return bad;
   }
 
@@ -514,27 +567,43 @@ template <class T, class Sys> struct GroupWorker {
     for (int i = 0; i < n; i++) x[i] = S[XUo + i];
 #pragma unroll
     for (int i = 0; i < n; i++) S[XUn + i] = x[i];
-    T xo[n], uo[m], kk[m][NA];
-    auto load_step = [&](int t) {
+    // WS: the gains come from the HBM workspace (L2): two steps ahead, two register sets in turn
+    T xo[n], uo[m];
+    struct Gains { T kk[m][NA]; };
+    Gains ga, gb;
+    auto load_gains = [&](int t, Gains& q) __attribute__((always_inline)) {
+      const T* Kg = gain(t);
+#pragma unroll
+      for (int a = 0; a < m; a++)
+#pragma unroll
+        for (int j = 0; j < NA; j++) q.kk[a][j] = Kg[a * GL::KW + j];
+    };
+    auto load_step = [&](int t, Gains& q) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < n; j++) xo[j] = S[XUo + t * W + j];
 #pragma unroll
-      for (int a = 0; a < m; a++) {
-        uo[a] = S[XUo + t * W + n + a];
-#pragma unroll
-        for (int j = 0; j < NA; j++) kk[a][j] = S[oKk + (t * m + a) * GL::KW + j];
-      }
+      for (int a = 0; a < m; a++) uo[a] = S[XUo + t * W + n + a];
+      if constexpr (!WS) load_gains(t, q);
     };
-    load_step(0);
-    auto step = [&](const int t) __attribute__((always_inline)) {
+    if constexpr (WS) {
+      load_gains(0, ga);
+      load_gains(N >= 2 ? 1 : 0, gb);
+    }
+    load_step(0, ga);
+    auto step = [&](const int t, Gains& q, Gains& qn) __attribute__((always_inline)) {
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(kk[a][j], x[j] - xo[j], acc);
-        u[a] = clip(uo[a] + kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        for (int j = 0; j < n; j++) acc = t_fma(q.kk[a][j], x[j] - xo[j], acc);
+        u[a] = clip(uo[a] + q.kk[a][n] + acc, -c.u_max[a], c.u_max[a]);
       }
-      load_step(t + 1 < N ? t + 1 : t);
+      if constexpr (WS) {
+        load_gains(t + 2 < N ? t + 2 : N - 1, q);  // the set just consumed
+        load_step(t + 1 < N ? t + 1 : t, qn);
+      } else {
+        load_step(t + 1 < N ? t + 1 : t, q);       // one set, reloaded in place
+      }
 #pragma unroll
       for (int a = 0; a < m; a++) S[XUn + t * W + n + a] = u[a];
       Sys::template trig_g<GENERAL>(x, tr, bad);
@@ -547,11 +616,19 @@ template <class T, class Sys> struct GroupWorker {
       for (int i = 0; i < n; i++) x[i] = xn[i];
     };
     int t = 0;
-    for (; t + 1 < N; t += 2) {
-      step(t);
-      step(t + 1);
+    if constexpr (WS) {
+      for (; t + 1 < N; t += 2) {
+        step(t, ga, gb);
+        step(t + 1, gb, ga);
+      }
+      if (t < N) step(t, ga, gb);
+    } else {
+      for (; t + 1 < N; t += 2) {
+        step(t, ga, ga);
+        step(t + 1, ga, ga);
+      }
+      if (t < N) step(t, ga, ga);
     }
-    if (t < N) step(t);
     Sys::template trig_g<GENERAL>(x, tr, bad);
 #pragma unroll
     for (int q = 0; q < NT; q++) S[TRn + N * NT + q] = tr[q];
@@ -567,9 +644,13 @@ template <class T, class Sys> struct GroupWorker {
 // wavefront and one round for three.  They sleep at a workgroup barrier the rest of the time (a
 // batch of 1024 problems leaves seven of eight SIMDs idle anyway).  Same values whoever computes
 // a record: bit-identical to H = 1.
-template <class T, class Sys, int H = 1>
+// WS: records and gains in the HBM workspace `ws` (GLayout::ws_words() words per problem, sized for
+// whole wavefronts: ceil(B / 8) * 8 problems), four wavefronts per CU instead of two — the form
+// for more than 4096 problems on the problem-major layout.  Same arithmetic, bit-identical.
+template <class T, class Sys, int H = 1, bool WS = false>
 __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n, Sys::m> c,
-                                                          const IterArgs<T> a) {
+                                                          const IterArgs<T> a, T* ws = nullptr) {
+  static_assert(!(WS && H > 1), "the workspace form runs without helper wavefronts");
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
   using GL = GLayout<Sys>;
   extern __shared__ __align__(16) unsigned char gsmem_raw[];
@@ -580,10 +661,11 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   // that every lane of the wavefront runs the same control flow
   const bool real = prob0 < a.B;
   const int64_t prob = real ? prob0 : a.B - 1;
-  GroupWorker<T, Sys> w(c, smem, lane);
+  GroupWorker<T, Sys, WS> w(c, smem, lane);
   const int N = c.N, g = w.g;
   const GL& L = w.L;
   const auto S = w.S;
+  if constexpr (WS) w.Wp = ws + prob0 * (int64_t)L.ws_words();
 
   // entry: x0, U, x_term, lamb, obs (HBM, problem-major records) -> LDS / registers.  Only the
   // main wavefront stores: rollout() clips the inputs IN these LDS words right away, and a late
@@ -721,12 +803,12 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
       T* gK = a.K + prob * (int64_t)(m * n * N);
       for (int e = g; e < m * n * N; e += kGroup) {
         const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
-        gK[e] = S[L.Kk + (t * m + aa) * GL::KW + j];
+        gK[e] = w.gain(t)[aa * GL::KW + j];
       }
       T* gk = a.k + prob * (int64_t)(m * N);
       for (int e = g; e < m * N; e += kGroup) {
         const int aa = e / N, t = e - aa * N;
-        gk[e] = S[L.Kk + (t * m + aa) * GL::KW + n];
+        gk[e] = w.gain(t)[aa * GL::KW + n];
       }
     }
 #ifdef I2LQR_STAMPS

@@ -132,10 +132,12 @@ int i2lqr_destroy(i2lqr_handle* h);
 /*
  * Scratch in HBM.  Batch-minor / batch-tiled layouts (one problem per lane): candidate inputs, the
  * gains when the caller does not ask for K/k, the work sets of the chunked solve; a call whose
- * batch needs more than the registered size fails with I2LQR_ERR_INVALID.  Problem-major layout:
- * 0 for the bicycles; for quad12 (n = 12, m = 4) the per-step records, gains and candidate
- * trajectory of the sixteen-lanes-per-problem kernel ("group_lanes" 16: ~60 KB per problem at
- * N = 50) — optional there: without it the one-problem-per-wavefront kernel runs.
+ * batch needs more than the registered size fails with I2LQR_ERR_INVALID.  Problem-major layout,
+ * optional (without it the kernels that need none run): for the bicycles above 4096 problems the
+ * per-step records and gains of the workspace form of the eight-lane kernel ("group_workspace":
+ * 5.6 KB per problem at n = 6, N = 20; 0 up to 4096 problems); for quad12 (n = 12, m = 4) the
+ * per-step records, gains and candidate trajectory of the sixteen-lanes-per-problem kernel
+ * ("group_lanes" 16: ~60 KB per problem at N = 50).
  * The caller owns the memory (device pointer, 16-byte aligned) and registers it on the handle.
  */
 int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B);
@@ -206,6 +208,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     I2LQR_ERR_UNSUPPORTED otherwise).  Automatic: 8 from 1024 problems where built.
  *                     The two agree to round-off (1e-10 on one backward pass), not bit for bit:
  *                     K^T Quu K is associated differently.
+ *   "group_workspace" eight-lane kernel: 1 keeps the per-step records and the gains in the
+ *                     registered HBM workspace instead of LDS (4 KB of LDS per problem instead of
+ *                     9.5 KB at n = 6, N = 20: four wavefronts per CU instead of two), fetched a
+ *                     step (records) / two steps (gains) ahead.  Same arithmetic, bit-identical.
+ *                     Automatic: above 4096 problems whenever the workspace is registered (below,
+ *                     every wavefront has its CU's LDS to itself either way).
  *   "speculate"       ("group_lanes" 8 / automatic) 1: the speculative form of the eight-lane
  *                     kernel — V wavefronts per eight problems (three up to 512 problems, two
  *                     above and in the tail of the chunked solves), wavefront v runs the iteration

@@ -1167,3 +1167,34 @@ def test_quad12_sixteen_lane_solve_returns_the_gains_of_the_last_executed_iterat
     assert batch_rel_err(to_host(solver, out[16]["K"])[same], to_host(solver, out[64]["K"])[same]) < 1e-6
     assert batch_rel_err(to_host(solver, out[16]["k"])[same], to_host(solver, out[64]["k"])[same],
                          floor=1.0) < 1e-6
+
+
+def test_eight_lane_workspace_form_is_bit_identical(torch_mod):
+    """The workspace form of the eight-lane kernel (records and gains in HBM, four wavefronts per
+    CU; automatic above 4096 problems once the workspace is registered) against the LDS form: bit
+    for bit, fused iterations with gains and solves with early exits, ragged batch sizes."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    for system, N, dt, B in (("bicycle6", 20, 0.25, 8192), ("bicycle6", 20, 0.25, 4101),
+                             ("bicycle4", 6, 1.0, 5000)):
+        cfg = default_config(system, N, "f64", dt=dt)
+        host = workloads.make_batch(cfg, B)
+        host["lamb"] = 10.0 ** np.random.default_rng(1).integers(-3, 2, B).astype(float)
+        res = {}
+        for ws in (0, 1):
+            solver = BatchedILQR(cfg)
+            solver.set_option("group_lanes", 8)
+            solver.set_option("speculate", 0)
+            solver.set_option("group_workspace", ws)
+            it = solver.iterate(dev_batch(solver, host), 6)
+            so = solver.solve(dev_batch(solver, host))
+            assert ("workspace" in solver.iterate_kernel(B)) == bool(ws)
+            res[ws] = (it, so)
+        for a, b in zip(res[0], res[1]):
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(a[key], b[key]), (system, B, key)
+    auto = BatchedILQR(default_config("bicycle6", 20, "f64", dt=0.25))
+    assert auto.iterate_kernel(8192) == "k_group_iterate"  # no workspace registered yet
+    auto.ensure_workspace(8192)
+    assert auto.iterate_kernel(8192) == "k_group_iterate (workspace form)"
+    assert auto.iterate_kernel(4096) == "k_group_iterate"
