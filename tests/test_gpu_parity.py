@@ -1198,3 +1198,47 @@ def test_eight_lane_workspace_form_is_bit_identical(torch_mod):
     auto.ensure_workspace(8192)
     assert auto.iterate_kernel(8192) == "k_group_iterate (workspace form)"
     assert auto.iterate_kernel(4096) == "k_group_iterate"
+
+
+def test_inputs_outside_the_benchmark_distribution_vs_oracle(torch_mod, layout):
+    """n = 6 problems the benchmark generator never draws: targets far outside the reachable set
+    (hundreds of metres away, behind the vehicle, opposite heading), lamb0 above max_lamb (the first
+    reject ends the solve), lamb0 tiny, initial inputs beyond the box, a moving obstacle sitting on
+    the start — every kernel family against the oracle, solve to termination."""
+    orc = oracle()
+    solver, cfg = make_solver("bicycle6", 20, dt=0.25, layout=layout)
+    B = 384
+    rng = np.random.default_rng(99)
+    X = np.zeros((B, 6, 21))
+    X[:, 0, 0] = rng.uniform(-50, 50, B)
+    X[:, 1, 0] = rng.uniform(-20, 20, B)
+    X[:, 2, 0] = rng.uniform(-2, 15, B)
+    X[:, 3, 0] = rng.uniform(-3.0, 3.0, B)
+    X[:, 4, 0] = rng.uniform(-1, 1, B)
+    X[:, 5, 0] = rng.uniform(-0.4, 0.4, B)
+    x_term = np.zeros((B, 6))
+    x_term[:, 0] = X[:, 0, 0] + rng.choice([-1, 1], B) * rng.uniform(100, 800, B)
+    x_term[:, 1] = rng.uniform(-300, 300, B)
+    x_term[:, 2] = rng.uniform(-10, 40, B)
+    x_term[:, 3] = rng.uniform(-3.1, 3.1, B)
+    u_max = np.array(cfg.u_max[:2])[None, :, None]
+    U = rng.uniform(-2.5, 2.5, (B, 2, 20)) * u_max
+    lamb = 10.0 ** rng.integers(-12, 6, B).astype(float)  # up to 1e5 > max_lamb = 1e3
+    obs = np.tile(np.array([0.0, 0.0, 6.0, 4.0, 0.5, 1.0]), (B, 1))
+    obs[:, 0] = X[:, 0, 0] + rng.uniform(-3, 3, B)
+    obs[:, 1] = X[:, 1, 0] + rng.uniform(-3, 3, B)
+    obs[::3, 5] = 2.0
+    obs[1::3, 5] = -1.0
+    host = dict(X=X, U=U, x_term=x_term, lamb=lamb, obs=obs)
+    ref = orc.ilqr_batch(cfg, X, U, x_term, lamb, obs)
+    buf = solver.solve(dev_batch(solver, host))
+    it, st = buf["iters"].cpu().numpy(), buf["status"].cpu().numpy()
+    same = (it == ref["iters"]) & (buf["lamb"].cpu().numpy() == ref["lamb"])
+    assert same.mean() > 0.97, same.mean()
+    _check_flipped(buf, ref, same, cfg.eps)
+    assert (st[same] == ref["status"][same]).all()
+    assert set(np.unique(st)) <= {1, 2, 3}
+    assert (ref["lamb"] > cfg.max_lamb).any() and (ref["iters"] == 1).any()
+    assert batch_rel_err(to_host(solver, buf["X"])[same], ref["X"][same]) < TOL_SOLVE
+    assert batch_rel_err(to_host(solver, buf["U"])[same], ref["U"][same], floor=1e-2) < 1e-6
+    np.testing.assert_allclose(buf["cost"].cpu().numpy()[same], ref["cost"][same], rtol=1e-7)
