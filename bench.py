@@ -164,7 +164,7 @@ def spawn_ranks(args) -> int:
 # The kernel's launch duration is measured live with HIP events on the launch stream around
 # KERNEL_SAMPLES evenly spaced timed steps (an event pair around EVERY launch costs the timed region
 # 5 us per 220 us step in marker packets): 10 samples at the driver's --steps 20 and at the default
-# 200 alike.  The cost of an EMPTY event pair (measured after the timed region, median of 20) is
+# 200 alike.  The cost of an EMPTY event pair (measured after the timed region, smallest of 30) is
 # subtracted: the two marker packets themselves sit inside the bracket, and at 0.2 ms per launch
 # they are 5 % of it (rocprofv3's kernel duration, profiles/, is the check).  Secondary workloads:
 # EXTRA_LAUNCHES individually bracketed launches after EXTRA_WARMUP, median and spread reported.
@@ -227,7 +227,7 @@ def event_stride_for(steps):
 
 
 def empty_bracket_ms(torch, n=30):
-    """Median duration HIP reports for an event pair with nothing in between, on a BUSY stream (a
+    """Smallest duration HIP reports for an event pair with nothing in between, on a BUSY stream (a
     small kernel is enqueued in front of every pair, as in the timed loop where the previous step's
     kernels are still in flight): the two marker packets themselves.  On an idle stream the same
     pair reads 2-3 times longer (wake-up), which is not what the brackets of the timed region pay."""
@@ -241,7 +241,9 @@ def empty_bracket_ms(torch, n=30):
         pairs.append((a, b))
     torch.cuda.synchronize()
     vals = sorted(a.elapsed_time(b) for a, b in pairs)
-    return vals[len(vals) // 2]
+    # the smallest reading is the markers' own cost; the median of the same samples moves between
+    # 5 and 13 us from run to run (whatever else the queue processor is doing)
+    return vals[0]
 
 
 def spread(vals):
