@@ -284,7 +284,8 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 ok = 1
             except Exception as e:  # noqa: BLE001
                 native_error, ok = f"{type(e).__name__}: {e}", 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=solver.device)
+            flag = torch.tensor([ok], dtype=torch.int32,
+                                device=solver.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if exchange != "torch" and not isinstance(exchange, str):
@@ -343,7 +344,8 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     seconds = time.perf_counter() - t0
     rank_seconds = [seconds]
     if grouped:
-        t = torch.tensor([seconds], dtype=torch.float64, device=solver.device)
+        t = torch.tensor([seconds], dtype=torch.float64,
+                         device=solver.device if dist.get_backend() == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         rank_seconds = [float(x.item()) for x in allt]
@@ -662,13 +664,19 @@ def run_rank(args) -> int:
 
     gpu_mode = not args.exchange_only
     want = int(os.environ.get("WORLD_SIZE", "1"))
-    if gpu_mode and torch.cuda.device_count() < want:  # (counting devices initialises nothing)
+    # I2LQR_BENCH_SHARE_GPU=1 (test hook for single-GPU boxes): the ranks take the visible devices
+    # round-robin and the process group runs on gloo — RCCL refuses two ranks on one device, so
+    # the native exchange's bring-up fails on the real library and every rank falls back together
+    share_gpu = gpu_mode and os.environ.get("I2LQR_BENCH_SHARE_GPU") == "1" and torch.cuda.device_count() > 0
+    if gpu_mode and not share_gpu and torch.cuda.device_count() < want:  # (counting devices initialises nothing)
         if int(os.environ.get("RANK", "0")) == 0:
             print(f"bench.py: {want} ranks but {torch.cuda.device_count()} HIP devices are "
                   "visible (use --exchange-only for the CPU dry run of the harness)",
                   file=sys.stderr)
         return 3
-    rank, world, local = dist_mod.init_from_env("nccl" if gpu_mode else "gloo")
+    rank, world, local = dist_mod.init_from_env("nccl" if gpu_mode and not share_gpu else "gloo")
+    if share_gpu:
+        local %= torch.cuda.device_count()
     if world != max(1, args.gpus):
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks",

@@ -51,6 +51,10 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
         return cost_local
     world = dist.get_world_size(group)
     n_local = cost_local.numel()
+    if cost_local.device.type != "cpu" and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only: stage through the host (a debugging set-up, e.g. several
+        # ranks sharing one GPU; the production group is "nccl" and stays on the device)
+        return allgather_costs(cost_local.cpu(), total, group).to(cost_local.device)
     if total is None or total == n_local * world:
         out = torch.empty(n_local * world, dtype=cost_local.dtype, device=cost_local.device)
         try:

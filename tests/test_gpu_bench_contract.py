@@ -84,6 +84,33 @@ def test_bench_mismatched_world_exits_nonzero():
     assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
 
 
+def test_two_ranks_sharing_the_gpu_solve_their_shards_and_fall_back_together():
+    """The N = 2 path with the real solve on this one-GPU box (I2LQR_BENCH_SHARE_GPU: both ranks on
+    device 0, process group on gloo).  RCCL itself refuses two ranks on one device, so the bring-up
+    of the native exchange fails inside the real library — as an agreed error or as a timed-out
+    attempt the launcher ends — and the line that comes out is the torch exchange's, for twice the
+    batch, with the pick checked against the gathered vector inside bench.py."""
+    import os
+    env = dict(os.environ, I2LQR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6",
+                          "--warmup", "2", "--no-extra", "--no-cpu-baseline", "--launch-timeout", "240"],
+                         capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["value"] > 1e6
+    assert len(d["per_rank_iterations_per_s"]) == 2
+    ex, att = d["exchange"], d["launcher"]["attempts"]
+    print("exchange:", ex, "launcher:", d["launcher"])
+    assert "torch.distributed" in ex["path"]
+    # either the ranks agreed on the failure inside one attempt, or the launcher restarted them
+    assert ("native_exchange_error" in ex and len(att) == 1) or \
+        (len(att) == 2 and att[1]["argv"] == ["--exchange", "torch"])
+
+
 def test_native_allgather_matches_torch_world_of_one():
     """i2lqr_comm_* / i2lqr_allgather_costs without any process group: a world of one."""
     import torch
