@@ -11,11 +11,14 @@ import torch
 
 from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
 
-for N in (8, 20):
+# argv: list of "N:ws" pairs (ws = 0 LDS form, 1 workspace form, -1 automatic); default both forms
+CASES = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(8, 0), (8, 1), (20, 0), (20, 1)]
+for N, ws in CASES:
     for B in (1024, 2048, 4096, 8192, 16384):
         cfg = default_config("bicycle6", N, "f64", dt=0.25)
         solver = BatchedILQR(cfg)
         solver.set_option("group_lanes", 8)
+        solver.set_option("group_workspace", ws)
         host = workloads.make_batch(cfg, B)
         dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
         bufs = []
@@ -36,4 +39,4 @@ for N in (8, 20):
             if i >= 2:
                 ts.append(e0.elapsed_time(e1))
         t = float(np.median(ts))
-        print(f"N={N:2d} B={B:6d} {solver.iterate_kernel(B):16s} {t:7.3f} ms  {B * 10 / t / 1e3:7.1f} M it/s")
+        print(f"N={N:2d} ws={ws:2d} B={B:6d} {solver.iterate_kernel(B):16s} {t:7.3f} ms  {B * 10 / t / 1e3:7.1f} M it/s")
