@@ -1242,3 +1242,19 @@ def test_inputs_outside_the_benchmark_distribution_vs_oracle(torch_mod, layout):
     assert batch_rel_err(to_host(solver, buf["X"])[same], ref["X"][same]) < TOL_SOLVE
     assert batch_rel_err(to_host(solver, buf["U"])[same], ref["U"][same], floor=1e-2) < 1e-6
     np.testing.assert_allclose(buf["cost"].cpu().numpy()[same], ref["cost"][same], rtol=1e-7)
+
+
+def test_random_configurations_every_family_against_the_oracle():
+    """tools/parity_campaign.py at a size that takes seconds: random horizons, ragged batches,
+    regularisation, obstacles and inputs beyond the box, every kernel family against the oracle —
+    deviations within the suite's bounds where the oracle itself is insensitive to one ulp on U0,
+    within 100 x that sensitivity elsewhere (profiles/r03_parity_campaign.txt is the long run)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "parity_campaign.py"), "12"],
+                         capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "held everywhere" in out.stdout
+    assert sum(l.startswith(("bicycle4", "bicycle6", "quad12")) for l in out.stdout.splitlines()) == 16
