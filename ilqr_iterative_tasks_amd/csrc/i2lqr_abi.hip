@@ -382,12 +382,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   using Cfg = DevCfg<T, n, m>;
   static unsigned grid(int64_t B) { return (unsigned)((B + 63) / 64); }
   // Workspace (bytes) for B problems: candidate trajectory + gains scratch (every call), and for
-  // the chunked solve two compacted work sets, scratch iters/status and the two slot counters.
+  // the chunked solve two compacted work sets, scratch iters/status and one counter per round.
+  static constexpr int kMaxRounds = 24;  // compaction rounds of the chunked solve (one counter each)
   static int64_t set_words(int N) { return (int64_t)(n * (N + 1) + m * N + n + 6 + 2); }
   static int64_t ws_bytes(int N, int64_t B) {
     const int64_t Bp = TILED ? (B + 63) / 64 * 64 : B;
     const int64_t words = lane_workspace_words<Sys>(N, Bp) + 2 * set_words(N) * Bp;
-    return words * (int64_t)sizeof(T) + (2 * 3 + 2) * Bp * 4 + 64;
+    return words * (int64_t)sizeof(T) + (2 * 3 + 2) * Bp * 4 + 16 + kMaxRounds * 4;
   }
   static int prepare(i2lqr_handle* h) {
     h->lanes = 1;
@@ -419,7 +420,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     LaneSet<T> set[2];
     int32_t* uiters;
     int32_t* ustatus;
-    int32_t* count;  // [2]
+    int32_t* count;  // [kMaxRounds]: the live count after each compaction round
   };
   static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a, Carved* cv = nullptr) {
     const int N = h->cfg.N;
@@ -553,17 +554,21 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a0.X = usr.X; a0.U = usr.U; a0.x_term = usr.x_term; a0.lamb = usr.lamb; a0.obs = usr.obs;
     a0.cost = usr.cost; a0.K = usr.K; a0.k = usr.k; a0.iters = usr.iters; a0.status = usr.status;
     a0.max_total = max_iter;
+    // one live counter per compaction round, all cleared by ONE fill in front of the first chunk (a
+    // fill per round was a 5 us launch of its own in each of the rounds that follow the tail)
+    HIP_TRY(hipMemsetAsync(cv.count, 0, kMaxRounds * sizeof(int32_t), s));
     launch_iterate<TILED>(c, a0, B, s);
     done += len;
     const unsigned cgrid = (unsigned)((B + 255) / 256);
-    int cur = 0;  // work set that receives the survivors
+    int cur = 0;    // work set that receives the survivors
+    int round = 0;  // its counter
     bool src_user = true;
     const int32_t* count_in = nullptr;
     LaneSet<T> src = usr;
     while (done < max_iter) {
-      HIP_TRY(hipMemsetAsync(cv.count + cur, 0, sizeof(int32_t), s));
+      int32_t* const count = cv.count + round;
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
-                         src_user ? 1 : 0, count_in, cv.set[cur], cv.count + cur, usr, c.trap);
+                         src_user ? 1 : 0, count_in, cv.set[cur], count, usr, c.trap);
       const LaneSet<T>& w = cv.set[cur];
       // Latency tail: once few problems survive, the rest of the solve is bound by the slowest
       // problem's iteration latency, which is ~2.8x lower with one problem per WAVEFRONT.  If the
@@ -589,7 +594,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
         t.X = w.X; t.U = w.U; t.x_term = w.x_term; t.lamb = w.lamb; t.obs = w.obs;
         t.cost = w.cost; t.K = w.K; t.k = w.k; t.iters = w.iters; t.status = w.status;
         t.dbg = nullptr;
-        t.count = cv.count + cur; t.count_max = wave_tail; t.max_total = max_iter;
+        t.count = count; t.count_max = wave_tail; t.max_total = max_iter;
         t.set_stride = B;
         if (spec_tail) {
           if constexpr (m == 2 && n + m <= 8) HIP_TRY(group_spec_tail<T>(h->cfg, t, s));
@@ -604,30 +609,32 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           }
         }
       }
-      // chunk lengths 8, 4, 4, 8, 8, 16, 16, 32, ...: compaction points at 8, 12, 16, 24, 32, 48,
-      // 64, 96 iterations (a late compaction costs little: its work scales with the survivors).
-      // Measured against 4, 4, 4, 4, ... with a tail of 2048: 1.69 -> 1.35 ms at 16384 problems,
-      // 2.35 -> 2.18 at 65536, 6.5 -> 5.9 at 262144.
-      len = done < 16 ? 4 : (done < 32 ? 8 : (done < 64 ? 16 : 32));
-      if (done + len > max_iter) len = max_iter - done;
+      // chunk lengths 8, 4, 4, then doubling (8, 16, 32, ...): compaction points at 8, 12, 16, 24,
+      // 40, 72, 136 iterations.  Short chunks while the tail may still be waiting for the survivors
+      // to fit it; once it has run, every further round is four empty launches (19 us), so few of
+      // them (the schedule 8, 4, 4, 8, 8, 16, 16, 32, 32, ... spent 0.19 of 2.13 ms there at 65536
+      // problems).  Against 4, 4, 4, 4, ... with a tail of 2048: 1.69 -> 1.35 ms at 16384 problems.
+      len = done < 16 ? 4 : done - 8;
+      if (done + len > max_iter || round + 2 >= kMaxRounds) len = max_iter - done;
       LaneArgs<T> a = a0;
       a.X = w.X; a.U = w.U; a.x_term = w.x_term; a.lamb = w.lamb; a.obs = w.obs; a.cost = w.cost;
       a.K = nullptr; a.k = nullptr;  // gains of work sets go to the scratch buffer (w.K == wsK)
       a.iters = w.iters; a.status = w.status;
-      a.count = cv.count + cur; a.resume = 1; a.n_iters = len;
+      a.count = count; a.resume = 1; a.n_iters = len;
       launch_iterate<false>(c, a, B, s);
       done += len;
       src = w;
       src_user = false;
-      count_in = cv.count + cur;
+      count_in = count;
       cur ^= 1;
+      round++;
     }
     // every remaining problem has a terminal status now: scatter them all
     if (!src_user) {
       LaneSet<T> none;
       std::memset(&none, 0, sizeof(none));
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src, 0,
-                         count_in, none, cv.count + cur, usr, c.trap);
+                         count_in, none, cv.count + round, usr, c.trap);
     }
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
