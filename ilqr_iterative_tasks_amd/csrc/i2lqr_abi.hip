@@ -449,8 +449,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if constexpr (Sys::NBLK > 0) {
       // automatic where the launch fills the chip (one wavefront per SIMD: 65536 problems)
       a.stagger = B >= 65536 ? 45 : 0;
-      if (h->opt_stagger >= 0) a.stagger = h->opt_stagger > 999 ? 999 : h->opt_stagger;
+    } else if (sizeof(T) == 8 && B > 960 * 64 && B <= 1280 * 64) {
+      // bicycles, fp64, a launch of about one wavefront per SIMD: +3 % (883 -> 912 M it/s at 65536
+      // problems, tools/ab_bench.py --cold); fp32 (issue-bound) gains nothing, launches of two
+      // and more rounds desynchronise by themselves and only pay the delay (-2 %)
+      a.stagger = 8;
     }
+    if (h->opt_stagger >= 0) a.stagger = h->opt_stagger > 999 ? 999 : h->opt_stagger;
     a.dbg = nullptr;
 #ifdef I2LQR_STAMPS
     if (const char* e = getenv("I2LQR_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);

@@ -61,7 +61,7 @@ template <class T> struct LaneArgs {
   int reroll;     // forward pass re-rolls the nominal states instead of reading them (fp64, big B)
   int merge;      // deferred mode: accepted candidate inputs are merged into ONE input buffer
   int ckpt;       // only every kSeg-th state lives in HBM between the passes (see backward<.., CK>)
-  int stagger;    // k_lane_iterate_rows: every second half-thousand of workgroups starts this many x ~8000 cycles late
+  int stagger;    // fused kernels: every second half-thousand of workgroups starts this many x ~8000 cycles late
 };
 
 // State checkpointing (fp64, large batches: the kernel sits on the HBM roof).  Between the passes of
@@ -1525,6 +1525,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   // checkpointed states (fp64 only; host: deferred + merged + re-rolling forward pass, Q = R = 0)
   constexpr bool kCanCkpt = sizeof(T) == 8 && !HASQR && Sys::NBLK == 0 && !I2LQR_DEEP64;
   const bool ckpt = kCanCkpt && a.ckpt;
+  if (a.stagger > 0 && ((blockIdx.x >> 9) & 1)) {  // see k_lane_iterate_rows
+    for (int q = 0; q < a.stagger; q++) __builtin_amdgcn_s_sleep(127);
+  }
   T cost = w.rollout(X, Uc, xT, ckpt);
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;

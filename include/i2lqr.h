@@ -236,10 +236,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     Riccati recursion has no Jacobian refresh; doubles the LDS per problem.
  *                     Automatic: on while every wavefront of the launch fits on the chip at once
  *                     (n <= 6 systems).
- *   "stagger"         quad12 on the lane layouts (k_lane_iterate_rows): every second half-thousand
+ *   "stagger"         lane layouts (k_lane_iterate_rows, k_lane_iterate): every second half-thousand
  *                     of workgroups starts value x ~8000 cycles late, so that half of the
  *                     wavefronts stream their gains (forward pass) while the other half computes
- *                     (backward pass).  Automatic: 45 from 65536 problems, else 0.
+ *                     (backward pass).  Automatic: quad12 45 from 65536 problems; bicycles in fp64
+ *                     8 for launches of about one wavefront per SIMD (61441 ... 81920 problems:
+ *                     larger launches desynchronise by themselves); else 0.  Result-preserving.
  *   "debug_self_test" index-checked debug build only (make -C ilqr_iterative_tasks_amd/csrc debug ->
  *                     libi2lqr_hip_debug.so): provokes one recorded index violation and returns
  *                     what the next call would, I2LQR_ERR_LAUNCH with the decoded record; the
