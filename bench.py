@@ -816,6 +816,12 @@ def run_rank(args) -> int:
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+        if dist_mod.abandoned_bring_ups():
+            # a thread of this rank is still inside an ncclCommInitRank that never returned: the
+            # regular teardown (process group, library destructors) may wait for it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
     return 0
 

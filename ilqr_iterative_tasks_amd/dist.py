@@ -88,6 +88,24 @@ class CostExchangeUnavailable(RuntimeError):
     step."""
 
 
+# Bring-ups whose ncclCommInitRank never returned: the daemon thread that made the call is still
+# inside the library.  A host that sees a non-zero count should end with os._exit after flushing
+# its output (bench.py does): the library's teardown may wait for that thread.
+_abandoned_bring_ups = 0
+
+
+def abandoned_bring_ups() -> int:
+    return _abandoned_bring_ups
+
+
+def _bring_up_timeout() -> float:
+    """Seconds a rank waits for ncclCommInitRank (I2LQR_COMM_TIMEOUT, default 180; 0: forever)."""
+    try:
+        return float(os.environ.get("I2LQR_COMM_TIMEOUT", "180"))
+    except ValueError:
+        return 180.0
+
+
 class CostExchange:
     """The all-gather of the candidates' terminal costs through the C-ABI (i2lqr_allgather_costs:
     one RCCL ncclAllGather on a communicator the library creates itself).
@@ -102,9 +120,14 @@ class CostExchange:
     be bound and the ranks agree on that; (2) rank 0 makes the id and broadcasts it — an EMPTY id
     if it failed, so the others do not sit in the broadcast; (3) every rank joins
     ncclCommInitRank; (4) the ranks agree on the outcome.  Any failure raises
-    CostExchangeUnavailable on all ranks."""
+    CostExchangeUnavailable on all ranks.  Step (3) blocks inside RCCL until every rank has
+    arrived; it runs in a helper thread and a rank that has waited `timeout` seconds (default
+    I2LQR_COMM_TIMEOUT = 180) gives up, reports failure in step (4) — where the other ranks, which
+    are waiting for the same bootstrap, arrive the same way — and leaves the thread behind
+    (abandoned_bring_ups()): under a launcher that is not bench.py's own (torchrun started by
+    someone else) nothing outside the rank could end a hung bootstrap."""
 
-    def __init__(self, solver, group=None):
+    def __init__(self, solver, group=None, timeout: float | None = None):
         import ctypes as C
         from . import _abi
         self.solver, self.lib = solver, solver.lib
@@ -137,12 +160,7 @@ class CostExchange:
             raise CostExchangeUnavailable(f"rank 0 could not create the RCCL unique id ({err or 'see rank 0'})")
         # (3) the bootstrap, (4) agreement on its outcome
         comm = C.c_void_p()
-        try:
-            with _device_ctx(solver.device):
-                solver._check(self.lib.i2lqr_comm_create(C.c_char_p(box[0]), self.world, self.rank,
-                                                         C.byref(comm)))
-        except Exception as e:  # noqa: BLE001
-            err = e
+        err = self._create(box[0], comm, _bring_up_timeout() if timeout is None else timeout)
         if not _agree(err is None, solver.device, group):
             if err is None and comm.value:
                 self.lib.i2lqr_comm_destroy(comm)
@@ -151,6 +169,32 @@ class CostExchange:
         w, r = C.c_int32(), C.c_int32()
         solver._check(self.lib.i2lqr_comm_info(self._comm, C.byref(w), C.byref(r)))
         self.comm_world, self.comm_rank = int(w.value), int(r.value)  # what RCCL itself reports
+
+    def _create(self, uid: bytes, comm, timeout: float):
+        """i2lqr_comm_create in a helper thread (the device current there too); returns the error
+        or None.  After `timeout` seconds without an answer: a TimeoutError, the thread stays
+        behind."""
+        import ctypes as C
+        import threading
+        global _abandoned_bring_ups
+        result = []
+
+        def call():
+            try:
+                with _device_ctx(self.solver.device):
+                    self.solver._check(self.lib.i2lqr_comm_create(C.c_char_p(uid), self.world,
+                                                                  self.rank, C.byref(comm)))
+                result.append(None)
+            except Exception as e:  # noqa: BLE001
+                result.append(e)
+
+        th = threading.Thread(target=call, name="i2lqr-comm-bring-up", daemon=True)
+        th.start()
+        th.join(timeout if timeout and timeout > 0 else None)
+        if th.is_alive():
+            _abandoned_bring_ups += 1
+            return TimeoutError(f"ncclCommInitRank did not return within {timeout:g} s on rank {self.rank}")
+        return result[0]
 
     def allgather(self, cost_local: torch.Tensor, out: torch.Tensor | None = None,
                   total: int | None = None) -> torch.Tensor:

@@ -167,6 +167,10 @@ class _FakeLib:
         return rc
 
     def i2lqr_comm_create(self, uid, world, rank, comm_ref):
+        if self.fail.get("create_hangs") == self.rank:  # a bootstrap that never returns
+            import time
+            self.calls.append("create")
+            time.sleep(3600)
         rc = self._rc("create")
         if rc == 0:
             comm_ref._obj.value = 0x1000 + rank
@@ -197,7 +201,7 @@ def _exchange_worker(rank, world, port, fail, out_dir):
     lib = _FakeLib(rank, fail)
     outcome = "ok"
     try:
-        ex = idist.CostExchange(_FakeSolver(lib))
+        ex = idist.CostExchange(_FakeSolver(lib), timeout=3.0)
         assert (ex.comm_world, ex.comm_rank) == (2, rank)
     except idist.CostExchangeUnavailable as e:
         outcome = "unavailable: " + str(e)
@@ -206,7 +210,7 @@ def _exchange_worker(rank, world, port, fail, out_dir):
     dist.all_reduce(t)
     assert float(t.item()) == 1.0
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(f"{outcome}|{','.join(lib.calls)}|{lib.destroyed}")
+        f.write(f"{outcome}|{','.join(lib.calls)}|{lib.destroyed}|{idist.abandoned_bring_ups()}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -216,6 +220,7 @@ def _exchange_worker(rank, world, port, fail, out_dir):
     ({"available": 1}, ["available"]),                      # rank 1 cannot bind RCCL: nobody goes on
     ({"unique_id": 0}, ["available", "unique_id"]),         # rank 0 cannot make the id
     ({"create": 1}, ["available", "unique_id", "create"]),  # rank 1 fails in the bootstrap
+    ({"create_hangs": 1}, ["available", "unique_id", "create"]),  # rank 1's bootstrap never returns
 ])
 def test_native_exchange_bring_up_fails_on_all_ranks_or_none(tmp_path, fail, expect_calls):
     port = _free_port()
@@ -228,5 +233,8 @@ def test_native_exchange_bring_up_fails_on_all_ranks_or_none(tmp_path, fail, exp
         assert all(o.startswith("unavailable") for o in outcomes), outcomes
     assert res[0][1].split(",") == expect_calls                     # rank 0 made the id if it got there
     assert res[1][1].split(",") == [c for c in expect_calls if c != "unique_id"]
-    if fail.get("create") == 1:
+    if fail.get("create") == 1 or fail.get("create_hangs") == 1:
         assert res[0][2] == "1"  # rank 0's communicator was created, then destroyed again
+    if fail.get("create_hangs") == 1:  # rank 1 gave up after its timeout and left the thread behind
+        assert "did not return within 3 s" in outcomes[1] or "another rank" in outcomes[1]
+        assert (res[0][3], res[1][3]) == ("0", "1")
