@@ -100,6 +100,9 @@ template <bool TILED> struct LaneView {
 #ifndef I2LQR_DEEP_PREFETCH
 #define I2LQR_DEEP_PREFETCH 1
 #endif
+#ifndef I2LQR_WARM_INPUTS
+#define I2LQR_WARM_INPUTS 1  // k_lane_iterate_rows: LDS-direct warm-up loads of the next step's inputs
+#endif
 #ifndef I2LQR_DEEP64
 #define I2LQR_DEEP64 0  // experiment: the two-step prefetch distance of the fp32 kernels in fp64 too
 #endif
@@ -168,15 +171,53 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     asm volatile("" : "+s"(q));
     return q;
   }
+  // The hidden base has lost its address space with its origin: it is cast back to GLOBAL here.
+  // Left generic, every access was a flat_load / flat_store — 64-bit vector addresses instead of
+  // scalar base + immediate, and counted in BOTH vmcnt and lgkmcnt: every wait for an LDS read then
+  // also waited for the 52 gain stores in flight to HBM.  f takes (index, const T&) to read the
+  // word or (index, T&) to assign it.
   template <int CNT, class P, class F>
   __device__ __forceinline__ void for_rows(P* p, int row0, F&& f) const {
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, row0 + CNT - 1, m * n * N + n);  // (largest array)
+    using V = std::remove_const_t<P>;
+    typedef __attribute__((address_space(1))) P GP;
     static_for<0, (CNT + 7) / 8>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
-      P* q = rows(p, row0 + 8 * g);
+      GP* q = (GP*)rows(p, row0 + 8 * g);
       static_for<0, (CNT - 8 * g < 8 ? CNT - 8 * g : 8)>([&](auto r_) {
         constexpr int r = decltype(r_)::value;
-        f(std::integral_constant<int, 8 * g + r>{}, (q + (int64_t)r * stride())[lane]);
+        using IC = std::integral_constant<int, 8 * g + r>;
+        GP* word = q + (int64_t)r * stride() + lane;
+        if constexpr (std::is_invocable_v<F&, IC, const V&>) {
+          const V v = *word;
+          f(IC{}, v);
+        } else {
+          V v;
+          f(IC{}, v);
+          typedef __attribute__((address_space(1))) V GV;
+          *const_cast<GV*>(word) = v;  // (this branch is only taken with a non-const P)
+        }
+      });
+    });
+  }
+  // Warm-up of CNT consecutive rows (this lane's word of each): a 4-byte LDS-direct load per row
+  // into a 256-byte sink nobody reads.  No vector register is written, so nothing stays allocated
+  // while the loads are in flight — the rows are in the L2 when the real loads ask for them.
+  unsigned* sink = nullptr;  // set by the kernel (an LDS object of its own)
+  template <int CNT, class P>
+  __device__ __forceinline__ void warm_rows(const P* p, int row0) const {
+    typedef __attribute__((address_space(1))) const void gptr;
+    typedef __attribute__((address_space(3))) void lptr;
+    static_for<0, (CNT + 7) / 8>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      const P* q = rows(p, row0 + 8 * g);
+      static_for<0, (CNT - 8 * g < 8 ? CNT - 8 * g : 8)>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if constexpr (TILED)  // rows 512 bytes apart: the instruction's immediate offset
+          __builtin_amdgcn_global_load_lds((gptr*)&q[lane], (lptr*)sink, 4, r * 64 * (int)sizeof(P), 0);
+        else
+          __builtin_amdgcn_global_load_lds((gptr*)&(q + (int64_t)r * stride())[lane], (lptr*)sink, 4,
+                                           0, 0);
       });
     });
   }
@@ -834,7 +875,12 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   static constexpr int kParkO = m * (n + 1), kParkLu = kParkO + 5, kParkTr = kParkLu + m,
                        kParkJx = kParkTr + NT, kParkU = kParkJx + Sys::NJX,
                        kStepSlots = kParkU + m;
-  static constexpr int kGainWords = kStepSlots * 64;
+  // ... and, for the whole pass, the five obstacle parameters the hot loop reads every step (centre,
+  // speed, 1 / width^2, 1 / height^2): per-lane loop invariants that the register allocator
+  // otherwise sends to SCRATCH — three of them were reloaded at the top of every horizon step, each
+  // behind an s_waitcnt vmcnt(0) that also drained the previous step's 52 gain stores
+  static constexpr int kParkOb = kStepSlots;
+  static constexpr int kGainWords = (kStepSlots + 5) * 64;
   static constexpr bool e_nz(int i, int j) {
     return i == j ? Sys::pat(i, j) != 1 : Sys::pat(i, j) != 0;
   }
@@ -964,6 +1010,13 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     asm volatile("" : "+v"(lrd));
     static_assert(blocks_valid(), "Sys::blk does not factor A = I + E into row blocks");
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
+    if constexpr (!GENERAL && sizeof(T) == 8) {
+      kcs[(kParkOb + 0) * 64 + l64] = ob[0];
+      kcs[(kParkOb + 1) * 64 + l64] = ob[1];
+      kcs[(kParkOb + 2) * 64 + l64] = ob[4];
+      kcs[(kParkOb + 3) * 64 + l64] = ob_pa;
+      kcs[(kParkOb + 4) * 64 + l64] = ob_pb;
+    }
     T V[n][n], vx[n];  // Vxx (upper triangle live), Vx
     {
       // get_cost_final(): control/ilqr_helper.py:106-150
@@ -1014,10 +1067,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         // exponentials evaluated together, their literals shared in scalar registers (t_exp_d)
         const bool has = ob[5] >= T(0);
         const int opt = has ? (int)ob[5] : 0;
-        const T dy = opt == 1 ? xp[1] - (ob[1] + T(t) * ob[4]) : xp[1] - ob[1];
-        const T dz = opt == 2 ? xp[0] - (ob[0] - T(t) * ob[4]) : xp[0] - ob[0];
-        const T h = T(1) + c.safety_margin - (dz * ob_pa * dz + dy * ob_pb * dy);
-        const T hd0 = T(-2) * ob_pa * dz, hd1 = T(-2) * ob_pb * dy;
+        asm volatile("" : "+v"(lrd));  // (this step's reads: not the previous step's values)
+        const T ob0 = kcs[(kParkOb + 0) * 64 + lrd], ob1 = kcs[(kParkOb + 1) * 64 + lrd],
+                ob4 = kcs[(kParkOb + 2) * 64 + lrd], pa = kcs[(kParkOb + 3) * 64 + lrd],
+                pb = kcs[(kParkOb + 4) * 64 + lrd];
+        const T dy = opt == 1 ? xp[1] - (ob1 + T(t) * ob4) : xp[1] - ob1;
+        const T dz = opt == 2 ? xp[0] - (ob0 - T(t) * ob4) : xp[0] - ob0;
+        const T h = T(1) + c.safety_margin - (dz * pa * dz + dy * pb * dy);
+        const T hd0 = T(-2) * pa * dz, hd1 = T(-2) * pb * dy;
         T ea[m + 1], ee[m + 1];
         ea[0] = c.obs_q2 * h;
 #pragma unroll
@@ -1083,6 +1140,15 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       // every lane reads only what it wrote (no barrier), consecutive lanes on consecutive words.
       I2LQR_PHASE_FENCE();
       STAMP_END(0);
+      if constexpr (!GENERAL && I2LQR_WARM_INPUTS) {
+        // the rows the end of this step loads for step t-1, on their way to the L2 a whole gain
+        // sweep earlier: under a full chip the loads themselves came back after the next step's
+        // top had waited 2000 cycles for them and its first phase another 2400
+        const int tl = t >= 1 ? t : 1;
+        warm_rows<n>(X, rx(0, tl));
+        warm_rows<NP>(X, rx(0, tl - 1));
+        warm_rows<m>(U, ru(0, tl - 1));
+      }
       auto gcol = [&](auto j_, T (&g)[m]) __attribute__((always_inline)) {  // column j of B^T [Vxx | Vx]
         constexpr int j = decltype(j_)::value;
         static_for<0, m>([&](auto a_) {
@@ -1671,6 +1737,8 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
   __shared__ T lds_gains[LaneWorker<T, Sys, false, TILED>::kGainWords];
+  __shared__ unsigned lds_sink[64];  // LaneWorker::warm_rows
+  w.sink = lds_sink;
   // Stagger: every wavefront of a full-chip launch does the same work in the same order, so all of
   // them stream their gains at once (the forward pass: at the HBM rate, issue slots idle) and all
   // of them compute at once (the backward pass: issue-bound, HBM half idle).  Workgroups 512-1023

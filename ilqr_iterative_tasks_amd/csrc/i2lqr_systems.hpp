@@ -39,36 +39,95 @@ template <bool SLIT> __device__ __forceinline__ double t_lit(double v) {
   if constexpr (SLIT) asm volatile("" : "+s"(v));
   return v;
 }
+// ... and WHEN: the literal is moved into its scalar pair by the two s_mov_b32 of this statement,
+// which the compiler may not place before `dep` has been computed (the statement names it as an
+// input and does not read it).  With the previous Horner accumulator as `dep` the two moves sit
+// between a multiply-add and the one that depends on it — issue slots a wavefront alone on its
+// SIMD cannot use anyway — and the pair is live for one step.  (With t_lit the compiler formed
+// all ~30 literals of a horizon step at the top of the loop, ran out of scalar registers and
+// parked them in vector-register lanes: 236 v_readlane / v_writelane and their s_nop per step.)
+template <bool SLIT, unsigned long long BITS>
+__device__ __forceinline__ double t_lit_at(double dep) {
+  if constexpr (SLIT) {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3"
+                 : "=s"(lo), "=s"(hi)
+                 : "n"((unsigned)(BITS & 0xffffffffull)), "n"((unsigned)(BITS >> 32)), "v"(dep));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  } else {
+    return __builtin_bit_cast(double, BITS);
+  }
+}
+#define I2LQR_LIT(SLIT, value, dep) \
+  t_lit_at<SLIT, __builtin_bit_cast(unsigned long long, (double)(value))>(dep)
 template <class T> __device__ __forceinline__ void t_sincos_fast(T x, T* s, T* c, bool* big_out);
+// NS arguments at once: the same operations per argument as for one (bit for bit), every literal
+// formed once per Horner step and shared by the NS chains
+template <bool SLIT, int NS>
+__device__ __forceinline__ void t_sincos_fast_dn(const double (&x)[NS], double (&s)[NS],
+                                                 double (&c)[NS], bool* big_out) {
+  double xs[NS], kf[NS], r[NS], z[NS], ps[NS], pc[NS];
+  bool big[NS];
+  const double lim = I2LQR_LIT(SLIT, 1.0e5, x[0]);
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    big[q] = !(__builtin_fabs(x[q]) < lim);
+    *big_out = *big_out || big[q];
+    xs[q] = big[q] ? 0.0 : x[q];
+  }
+  const double tpi = I2LQR_LIT(SLIT, 6.36619772367581382433e-01, xs[0]);  // 2/pi
+#pragma unroll
+  for (int q = 0; q < NS; q++) kf[q] = __builtin_rint(xs[q] * tpi);
+  const double p2h = I2LQR_LIT(SLIT, 1.57079632679489655800e+00, kf[0]);  // pi/2 hi
+#pragma unroll
+  for (int q = 0; q < NS; q++) r[q] = __builtin_fma(-kf[q], p2h, xs[q]);
+  const double p2m = I2LQR_LIT(SLIT, 6.12323399573676603587e-17, r[0]);   // pi/2 mid
+#pragma unroll
+  for (int q = 0; q < NS; q++) r[q] = __builtin_fma(-kf[q], p2m, r[q]);
+  const double p2l = I2LQR_LIT(SLIT, -1.49738490485916983327e-33, r[0]);  // pi/2 lo
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    r[q] = __builtin_fma(-kf[q], p2l, r[q]);
+    z[q] = r[q] * r[q];
+  }
+  const double s0 = I2LQR_LIT(SLIT, 1.58969099521155010221e-10, z[0]);
+  const double c0 = I2LQR_LIT(SLIT, -1.13596475577881948265e-11, z[0]);
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    ps[q] = s0;
+    pc[q] = c0;
+  }
+#define I2LQR_SC_STEP(ls, lc)                                                                \
+  {                                                                                          \
+    const double ks = I2LQR_LIT(SLIT, ls, pc[0]);                                            \
+    _Pragma("unroll") for (int q = 0; q < NS; q++) ps[q] = __builtin_fma(ps[q], z[q], ks);   \
+    const double kc = I2LQR_LIT(SLIT, lc, ps[0]);                                            \
+    _Pragma("unroll") for (int q = 0; q < NS; q++) pc[q] = __builtin_fma(pc[q], z[q], kc);   \
+  }
+  I2LQR_SC_STEP(-2.50507602534068634195e-08, 2.08757232129817482790e-09)
+  I2LQR_SC_STEP(2.75573137070700676789e-06, -2.75573143513906633035e-07)
+  I2LQR_SC_STEP(-1.98412698298579493134e-04, 2.48015872894767294178e-05)
+  I2LQR_SC_STEP(8.33333333332248946124e-03, -1.38888888888741095749e-03)
+  I2LQR_SC_STEP(-1.66666666666666324348e-01, 4.16666666666666019037e-02)
+#undef I2LQR_SC_STEP
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const int qd = (int)kf[q];
+    const double sr = __builtin_fma(ps[q] * z[q], r[q], r[q]);
+    const double cr = __builtin_fma(pc[q] * z[q], z[q], __builtin_fma(-0.5, z[q], 1.0));
+    const bool swap = qd & 1;
+    const double sv = swap ? cr : sr, cv = swap ? sr : cr;
+    s[q] = (qd & 2) ? -sv : sv;
+    c[q] = ((qd + 1) & 2) ? -cv : cv;
+  }
+}
 template <bool SLIT>
 __device__ __forceinline__ void t_sincos_fast_d(double x, double* s, double* c, bool* big_out) {
-  const bool big = !(__builtin_fabs(x) < t_lit<SLIT>(1.0e5));
-  *big_out = *big_out || big;
-  const double xs = big ? 0.0 : x;
-  const double kf = __builtin_rint(xs * t_lit<SLIT>(6.36619772367581382433e-01));  // 2/pi
-  double r = __builtin_fma(-kf, t_lit<SLIT>(1.57079632679489655800e+00), xs);     // pi/2 hi
-  r = __builtin_fma(-kf, t_lit<SLIT>(6.12323399573676603587e-17), r);            // pi/2 mid
-  r = __builtin_fma(-kf, t_lit<SLIT>(-1.49738490485916983327e-33), r);           // pi/2 lo
-  const int q = (int)kf;
-  const double z = r * r;
-  double ps = t_lit<SLIT>(1.58969099521155010221e-10);
-  ps = __builtin_fma(ps, z, t_lit<SLIT>(-2.50507602534068634195e-08));
-  ps = __builtin_fma(ps, z, t_lit<SLIT>(2.75573137070700676789e-06));
-  ps = __builtin_fma(ps, z, t_lit<SLIT>(-1.98412698298579493134e-04));
-  ps = __builtin_fma(ps, z, t_lit<SLIT>(8.33333333332248946124e-03));
-  ps = __builtin_fma(ps, z, t_lit<SLIT>(-1.66666666666666324348e-01));
-  const double sr = __builtin_fma(ps * z, r, r);
-  double pc = t_lit<SLIT>(-1.13596475577881948265e-11);
-  pc = __builtin_fma(pc, z, t_lit<SLIT>(2.08757232129817482790e-09));
-  pc = __builtin_fma(pc, z, t_lit<SLIT>(-2.75573143513906633035e-07));
-  pc = __builtin_fma(pc, z, t_lit<SLIT>(2.48015872894767294178e-05));
-  pc = __builtin_fma(pc, z, t_lit<SLIT>(-1.38888888888741095749e-03));
-  pc = __builtin_fma(pc, z, t_lit<SLIT>(4.16666666666666019037e-02));
-  const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
-  const bool swap = q & 1;
-  const double sv = swap ? cr : sr, cv = swap ? sr : cr;
-  *s = (q & 2) ? -sv : sv;
-  *c = ((q + 1) & 2) ? -cv : cv;
+  const double xa[1] = {x};
+  double sa[1], ca[1];
+  t_sincos_fast_dn<SLIT, 1>(xa, sa, ca, big_out);
+  *s = sa[0];
+  *c = ca[0];
 }
 template <> __device__ __forceinline__ void t_sincos_fast<double>(double x, double* s, double* c,
                                                                    bool* big_out) {
@@ -137,23 +196,24 @@ __device__ __forceinline__ void t_exp_d(const double (&x0)[NE], double (&e)[NE])
   double x[NE], kf[NE], r[NE], p[NE];
 #pragma unroll
   for (int q = 0; q < NE; q++)
-    x[q] = q < NE - NB ? (x0[q] < t_lit<SLIT>(-746.0) ? -746.0 : (x0[q] > t_lit<SLIT>(710.0) ? 710.0 : x0[q]))
+    x[q] = q < NE - NB ? (x0[q] < I2LQR_LIT(SLIT, -746.0, x0[q]) ? -746.0
+                          : (x0[q] > I2LQR_LIT(SLIT, 710.0, x0[q]) ? 710.0 : x0[q]))
                        : x0[q];  // NaN passes through
-  const double l2e = t_lit<SLIT>(1.44269504088896338700e+00);
+  const double l2e = I2LQR_LIT(SLIT, 1.44269504088896338700e+00, x[0]);
 #pragma unroll
   for (int q = 0; q < NE; q++) kf[q] = __builtin_rint(x[q] * l2e);
-  const double ln2h = t_lit<SLIT>(6.93147180369123816490e-01);
+  const double ln2h = I2LQR_LIT(SLIT, 6.93147180369123816490e-01, kf[0]);
 #pragma unroll
   for (int q = 0; q < NE; q++) r[q] = __builtin_fma(-kf[q], ln2h, x[q]);
-  const double ln2l = t_lit<SLIT>(1.90821492927058770002e-10);
+  const double ln2l = I2LQR_LIT(SLIT, 1.90821492927058770002e-10, r[0]);
 #pragma unroll
   for (int q = 0; q < NE; q++) r[q] = __builtin_fma(-kf[q], ln2l, r[q]);
-  const double c13 = t_lit<SLIT>(1.6059043836821614599e-10);  // 1/13!
+  const double c13 = I2LQR_LIT(SLIT, 1.6059043836821614599e-10, r[0]);  // 1/13!
 #pragma unroll
   for (int q = 0; q < NE; q++) p[q] = c13;
 #define I2LQR_EXP_STEP(lit)                                          \
   {                                                                  \
-    const double ck = t_lit<SLIT>(lit);                              \
+    const double ck = I2LQR_LIT(SLIT, lit, p[0]);                    \
     _Pragma("unroll") for (int q = 0; q < NE; q++) p[q] = __builtin_fma(p[q], r[q], ck); \
   }
   I2LQR_EXP_STEP(2.0876756987868098979e-09)
@@ -173,7 +233,8 @@ __device__ __forceinline__ void t_exp_d(const double (&x0)[NE], double (&e)[NE])
     p[q] = __builtin_fma(p[q], r[q], 1.0);
     p[q] = __builtin_fma(p[q], r[q], 1.0);
     const double v = __builtin_ldexp(p[q], (int)kf[q]);
-    e[q] = q < NE - NB ? (x0[q] < t_lit<SLIT>(-745.14) ? 0.0 : (x0[q] > t_lit<SLIT>(709.79) ? __builtin_inf() : v))
+    e[q] = q < NE - NB ? (x0[q] < I2LQR_LIT(SLIT, -745.14, v) ? 0.0
+                          : (x0[q] > I2LQR_LIT(SLIT, 709.79, v) ? __builtin_inf() : v))
                        : v;
   }
 }
@@ -703,9 +764,14 @@ template <class T> struct Quad12 {
   }
   // hot form with scalar-register literals (LaneWorker::backward_blocked and friends)
   static __device__ __forceinline__ void trig_s(const double (&xe)[n], double (&tr)[NTRIG], bool* bad) {
-    t_sincos_fast_d<true>(xe[3], &tr[0], &tr[1], bad);
-    t_sincos_fast_d<true>(xe[4], &tr[2], &tr[3], bad);
-    t_sincos_fast_d<true>(xe[5], &tr[4], &tr[5], bad);
+    const double ang[3] = {xe[3], xe[4], xe[5]};  // the three angles at once: literals shared
+    double sn[3], cs[3];
+    t_sincos_fast_dn<true, 3>(ang, sn, cs, bad);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      tr[2 * q] = sn[q];
+      tr[2 * q + 1] = cs[q];
+    }
   }
   static __device__ __forceinline__ void trig_s(const float (&xe)[n], float (&tr)[NTRIG], bool* bad) {
     trig_g<false>(xe, tr, bad);
