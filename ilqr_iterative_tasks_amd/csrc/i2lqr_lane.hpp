@@ -1251,6 +1251,21 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       // K = Kc A row by row, then straight to HBM
       I2LQR_PHASE_FENCE();
       STAMP_END(1);
+      // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1}.  Issued first in
+      // this phase and LANDED (an explicit vmcnt(0), below) before the first of the step's 52 gain
+      // stores: the compiler treats pending loads and stores as unordered among each other, so a
+      // wait for these loads behind the stores was a wait for all of them to be written —
+      // s_waitcnt vmcnt(0) in the middle of the store sequence.  With the rows warm in the L2
+      // (warm_rows) they arrive while the Jacobian and the first gain row are formed, and nothing
+      // in the loop waits on vector memory after that: the stores drain behind the state blocks
+      // and the next step's first phase.  (Step 0 loads the rows of step 1 again: no branch.)
+      {
+        const int tl = t >= 1 ? t : 1;
+        for_rows<n>(X, rx(0, tl), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
+        for_rows<NP>(X, rx(0, tl - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
+        for_rows<m>(U, ru(0, tl - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
+      }
+      I2LQR_PHASE_FENCE();
       {  // the A entries of the Jacobian, formed again (hidden from value numbering: the compiler
          // would otherwise keep the first evaluation's 25 doubles live through the phases above)
         T xr[n], ur[m], trr[NT];
@@ -1265,16 +1280,6 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         for (int q = 0; q < NT; q++) trr[q] = kcs[(kParkTr + q) * 64 + lrd];
         Sys::jac_var(c, xr, ur, trr, jv);
       }
-      // inputs of step t-1: x_t in full (its evaluation state), x_{t-1}, u_{t-1} — issued BEFORE
-      // the step's 52 gain stores: loads and stores share one in-order counter, so the wait for
-      // these loads at the top of the next step leaves the stores in flight instead of draining
-      // them.  (Step 0 loads the rows of step 1 again: no branch.)
-      {
-        const int tl = t >= 1 ? t : 1;
-        for_rows<n>(X, rx(0, tl), [&](auto i_, const T& w) { xe[decltype(i_)::value] = w; });
-        for_rows<NP>(X, rx(0, tl - 1), [&](auto i_, const T& w) { xp[decltype(i_)::value] = w; });
-        for_rows<m>(U, ru(0, tl - 1), [&](auto a_, const T& w) { u[decltype(a_)::value] = w; });
-      }
       static_for<0, m>([&](auto a_) {
         constexpr int a = decltype(a_)::value;
         T g[n];
@@ -1282,6 +1287,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
         for (int j = 0; j < n; j++) g[j] = kcs[(a * (n + 1) + j) * 64 + lrd];
         static_for<0, Sys::NBLK>([&](auto b_) { block_gain_row<decltype(b_)::value>(g, jv); });
+        if constexpr (a == 0) {
+          I2LQR_PHASE_FENCE();
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the inputs of step t-1 have landed
+          I2LQR_PHASE_FENCE();
+        }
         for_rows<n>(gK, rK(a, 0, t), [&](auto j_, T& w) { w = g[decltype(j_)::value]; });
       });
       for_rows<m>(gk, ru(0, t), [&](auto a_, T& w) {
