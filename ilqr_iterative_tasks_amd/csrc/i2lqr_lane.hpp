@@ -39,9 +39,6 @@ template <int Begin, int End, class F> __device__ __forceinline__ void static_fo
 #ifndef I2LQR_PHASE_FENCE
 #define I2LQR_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef I2LQR_LOADS_FIRST
-#define I2LQR_LOADS_FIRST 0
-#endif
 
 template <class T> struct LaneArgs {
   int64_t B;                 // row stride (capacity) of every array; also the batch unless `count`

@@ -35,17 +35,14 @@ template <class T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
 // cannot encode a 64-bit literal, and the compiler otherwise materialises each one in a vector
 // register pair, hoists the pair out of the horizon loop as an invariant — ~35 literals of exp /
 // sincos = 70 vector registers — and spills it to scratch.  Same values, same arithmetic.
-template <bool SLIT> __device__ __forceinline__ double t_lit(double v) {
-  if constexpr (SLIT) asm volatile("" : "+s"(v));
-  return v;
-}
-// ... and WHEN: the literal is moved into its scalar pair by the two s_mov_b32 of this statement,
-// which the compiler may not place before `dep` has been computed (the statement names it as an
-// input and does not read it).  With the previous Horner accumulator as `dep` the two moves sit
-// between a multiply-add and the one that depends on it — issue slots a wavefront alone on its
-// SIMD cannot use anyway — and the pair is live for one step.  (With t_lit the compiler formed
-// all ~30 literals of a horizon step at the top of the loop, ran out of scalar registers and
-// parked them in vector-register lanes: 236 v_readlane / v_writelane and their s_nop per step.)
+// WHERE and WHEN: the literal is moved into its scalar pair by the two s_mov_b32 of t_lit_at's
+// statement, which the compiler may not place before `dep` has been computed (the statement names
+// it as an input and does not read it).  With the previous Horner accumulator as `dep` the two
+// moves sit between a multiply-add and the one that depends on it — issue slots a wavefront alone
+// on its SIMD cannot use anyway — and the pair is live for one step.  (A literal merely hidden
+// behind an empty asm was formed at the top of the loop with the ~30 others of the horizon step;
+// they outran the scalar registers and were parked in vector-register lanes: 236 v_readlane /
+// v_writelane and their s_nop per step.)
 template <bool SLIT, unsigned long long BITS>
 __device__ __forceinline__ double t_lit_at(double dep) {
   if constexpr (SLIT) {
