@@ -97,6 +97,9 @@ template <bool TILED> struct LaneView {
 #ifndef I2LQR_DEEP_PREFETCH
 #define I2LQR_DEEP_PREFETCH 1
 #endif
+#ifndef I2LQR_W_PAIRS
+#define I2LQR_W_PAIRS 1  // k_lane_iterate_rows: the value update takes two rows of Quu Kc per sweep
+#endif
 #ifndef I2LQR_WARM_INPUTS
 #define I2LQR_WARM_INPUTS 1  // k_lane_iterate_rows: LDS-direct warm-up loads of the next step's inputs
 #endif
@@ -1214,6 +1217,53 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       // to the scheduler every pair of words was waited for on its own, ~100 cycles each — 60 % of
       // the step's time in this phase).
       I2LQR_PHASE_FENCE();
+      if constexpr (I2LQR_W_PAIRS && m % 2 == 0) {
+        // two rows of Y per sweep over Kc: every word of [W | w] is updated twice per sweep —
+        // half the register <-> accumulation-register traffic for the part of V that does not fit
+        // the vector registers — and Kc is read m / 2 times instead of m.  Same operations on every
+        // word in the same order: bit-identical to one row per sweep.
+        static_for<0, m / 2>([&](auto p_) {
+          constexpr int b0 = 2 * decltype(p_)::value, b1 = b0 + 1;
+          T y0[n], y1[n], k0[n + 1], k1[n + 1];
+          asm volatile("" : "+v"(lrd));  // this sweep reads its words again (no reuse across sweeps)
+#pragma unroll
+          for (int i = 0; i < n; i++) y0[i] = y1[i] = T(0);
+          static_for<0, m / 2>([&](auto h_) {
+            constexpr int a0 = 2 * decltype(h_)::value;
+            T r0[n], r1[n];
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+              r0[i] = kcs[(a0 * (n + 1) + i) * 64 + lrd];
+              r1[i] = kcs[((a0 + 1) * (n + 1) + i) * 64 + lrd];
+            }
+            I2LQR_PHASE_FENCE();
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+              y0[i] = t_fma(Quu[b0 * m + a0], r0[i], y0[i]);
+              y0[i] = t_fma(Quu[b0 * m + a0 + 1], r1[i], y0[i]);
+              y1[i] = t_fma(Quu[b1 * m + a0], r0[i], y1[i]);
+              y1[i] = t_fma(Quu[b1 * m + a0 + 1], r1[i], y1[i]);
+              if constexpr (a0 == b0) {
+                k0[i] = r0[i];
+                k1[i] = r1[i];
+              }
+            }
+            I2LQR_PHASE_FENCE();
+          });
+          k0[n] = kcs[(b0 * (n + 1) + n) * 64 + lrd];
+          k1[n] = kcs[(b1 * (n + 1) + n) * 64 + lrd];
+#pragma unroll
+          for (int i = 0; i < n; i++) {
+#pragma unroll
+            for (int j = i; j < n; j++) {
+              V[i][j] = t_fma(-y0[i], k0[j], V[i][j]);
+              V[i][j] = t_fma(-y1[i], k1[j], V[i][j]);
+            }
+            vx[i] = t_fma(-y0[i], k0[n], vx[i]);
+            vx[i] = t_fma(-y1[i], k1[n], vx[i]);
+          }
+        });
+      } else {
       static_for<0, m>([&](auto b_) {
         constexpr int bb = decltype(b_)::value;
         T y[n], kb[n + 1];
@@ -1245,6 +1295,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           vx[i] = t_fma(-y[i], kb[n], vx[i]);
         }
       });
+      }
       // K = Kc A row by row, then straight to HBM
       I2LQR_PHASE_FENCE();
       STAMP_END(1);
