@@ -129,7 +129,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // last (k0_out) and never read back.  Steps 1..lds_steps keep [K | k]: word (t, q) of lane l
   // sits at lds[((t - 1) m (n+1) + q) * 64 + l], k_0[a] behind them: consecutive lanes on
   // consecutive words, conflict-free.
-  T* lds = nullptr;  // null (the one-pass kernels): every gain goes through HBM
+  // (typed as LDS: through a generic pointer some of these accesses were flat_load / flat_store)
+  typedef __attribute__((address_space(3))) T lds_t;
+  lds_t* lds = nullptr;  // null (the one-pass kernels): every gain goes through HBM
   int lds_steps = 0;
 #ifdef I2LQR_STAMPS
   mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
@@ -238,12 +240,12 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, a, m);
     return (t * m + a) * n + j;
   }
-  __device__ __forceinline__ T& lds_gain(int t, int q) const {  // 1 <= t <= lds_steps
+  __device__ __forceinline__ lds_t& lds_gain(int t, int q) const {  // 1 <= t <= lds_steps
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, t - 1, lds_steps);
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, q, m * (n + 1));
     return lds[((t - 1) * (m * (n + 1)) + q) * 64 + (threadIdx.x & 63)];
   }
-  __device__ __forceinline__ T& lds_k0(int a) const {
+  __device__ __forceinline__ lds_t& lds_k0(int a) const {
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, a, m);
     return lds[(lds_steps * (m * (n + 1)) + a) * 64 + (threadIdx.x & 63)];
   }
@@ -562,7 +564,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   template <bool FASTBAR = false, bool CK = false>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
-                                           T* seg = nullptr) const {
+                                           lds_t* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
@@ -573,7 +575,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
     const unsigned l64 = threadIdx.x & 63;
     // state k of the current segment (k = 0: the checkpoint), component i: conflict-free LDS words
-    auto seg_at = [&](int k, int i) -> T& {
+    auto seg_at = [&](int k, int i) -> lds_t& {
       I2LQR_DBG_CHECK(c.trap, TAG_LANE_LDS, k * n + i, (kSeg + 1) * n);
       return seg[(k * n + i) * 64 + l64];
     };
@@ -1621,7 +1623,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const LaneView<TILED> v(a.B);
   LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   extern __shared__ __align__(16) unsigned char lane_smem[];
-  w.lds = reinterpret_cast<T*>(lane_smem);
+  typedef __attribute__((address_space(3))) T lds_t;
+  w.lds = (lds_t*)lane_smem;
   w.lds_steps = a.lds_steps;
   const T* gxt = v.rebase(a.x_term, n);
   const T* gob = v.rebase(a.obs, 6);
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
   int it = 0, status = a.early_exit ? 2 : 0;
   T cost_ret = cost;
-  T* const seg = reinterpret_cast<T*>(lane_smem) + (size_t)a.lds_steps * 64 * m * (n + 1) + 64 * m;
+  lds_t* const seg = (lds_t*)lane_smem + (size_t)a.lds_steps * 64 * m * (n + 1) + 64 * m;
   while (it < a.n_iters && it0 + it < a.max_total) {
     // K_0 goes to HBM from the passes that can be this launch's last one for the problem
     const bool k0_out = a.early_exit || it + 1 >= a.n_iters || it0 + it + 1 >= a.max_total;
