@@ -131,7 +131,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // consecutive words, conflict-free.
   // (typed as LDS: through a generic pointer some of these accesses were flat_load / flat_store)
   typedef __attribute__((address_space(3))) T lds_t;
-  lds_t* lds = nullptr;  // null (the one-pass kernels): every gain goes through HBM
+  lds_t* lds = nullptr;
+  bool has_lds = false;  // false (the one-pass kernels): every gain goes through HBM.  (Not the
+                         // pointer's nullness: the dynamic LDS of a kernel starts at LDS address 0.)
   int lds_steps = 0;
 #ifdef I2LQR_STAMPS
   mutable unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
@@ -772,7 +774,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           for (int bb = 0; bb < m; bb++) acc = t_fma(Qinv[a * m + bb], G[bb][j], acc);
           Kk[a][j] = -acc;
         }
-      if (t == 0 && lds) {
+      if (t == 0 && has_lds) {
 #pragma unroll
         for (int a = 0; a < m; a++) lds_k0(a) = Kk[a][n];
         if (k0_out) {
@@ -1406,7 +1408,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       }
 #pragma unroll
       for (int a = 0; a < m; a++) ul[a] = at(U, ru(a, t));
-      if (t == 0 && lds) {  // x_0 is common to the nominal and the candidate: K_0 multiplies zeros
+      if (t == 0 && has_lds) {  // x_0 is common to the nominal and the candidate: K_0 multiplies zeros
 #pragma unroll
         for (int a = 0; a < m; a++) {
 #pragma unroll
@@ -1625,6 +1627,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   extern __shared__ __align__(16) unsigned char lane_smem[];
   typedef __attribute__((address_space(3))) T lds_t;
   w.lds = (lds_t*)lane_smem;
+  w.has_lds = true;
   w.lds_steps = a.lds_steps;
   const T* gxt = v.rebase(a.x_term, n);
   const T* gob = v.rebase(a.obs, 6);
