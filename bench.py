@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
+    ap.add_argument("--test-hooks", action="store_true",
+                    help="tests only: honour I2LQR_BENCH_TEST_HANG (an attempt that never returns)")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="--gpus N > 1 without a launcher: seconds one attempt of the N ranks may "
                          "take before its process group is ended")
@@ -92,6 +94,7 @@ def _run_ranks(args, extra_argv, timeout_s):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["I2LQR_BENCH_LAUNCHER"] = "1"  # the ranks may leave (exit 75) and count on a fresh start
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -169,33 +172,59 @@ def spawn_ranks(args) -> int:
 # they are 5 % of it (rocprofv3's kernel duration, profiles/, is the check).  Secondary workloads:
 # EXTRA_LAUNCHES individually bracketed launches after EXTRA_WARMUP, median and spread reported.
 KERNEL_SAMPLES = 10
+LONG_RUN_STEPS = 200  # --gpus N > 1: a second timed loop of this many steps ("long_run")
 EXTRA_LAUNCHES = 20
 EXTRA_WARMUP = 3
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec; = 1024 SIMDs x 16 lanes x 2 x 2.4 GHz)
-LANE_THRESHOLD = 10240
-LANE_THRESHOLD_SOLVE = 16384
-QUAD_LANE_THRESHOLD = 8192
 LAYOUT_ID = {"wave": 0, "lane": 1, "tiled": 2}
-LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",  # eight from 1024 problems
+LAYOUT_NAME = {"wave": "problem-major (one problem per wavefront)",  # 4 / 8 per wavefront from 1024
                "lane": "batch-minor (one problem per lane)",
                "tiled": "batch-tiled x64 (one problem per lane)"}
 
 
 def pick_layout(args, B, solve=False, cfg=None):
-    """wave: problem-major (one problem per wavefront below 1024 problems, eight per wavefront from
-    there: the library's automatic choice); lane / tiled: one problem per lane over batch-minor
-    rows / tiles of 64 problems.  Measured with tools/ab_bench.py (interleaved)."""
+    """wave: problem-major (one problem per wavefront below 1024 problems, four / eight per
+    wavefront from there: the library's per-call choice); lane / tiled: one problem per lane over
+    batch-minor rows / tiles of 64 problems.  The crossover between the layouts is the LIBRARY's
+    (i2lqr_recommended_layout: measured thresholds live behind the C-ABI, not here)."""
     if args.layout != "auto":
         return args.layout
-    if cfg is not None and cfg.system_id == 2:
-        # quad12: one problem per lane (k_lane_iterate_rows) from 8192 problems, the sixteen-lane
-        # kernel of the problem-major layout below (tools/ab_bench.py --workload config5)
-        if B < QUAD_LANE_THRESHOLD or cfg.dtype != 0:
-            return "wave"
-        return "lane" if B % 64 else "tiled"
-    if B < (LANE_THRESHOLD_SOLVE if solve else LANE_THRESHOLD):
-        return "wave"
-    return "lane" if B % 64 else "tiled"
+    from ilqr_iterative_tasks_amd import _abi
+    rc = _abi.load_library().i2lqr_recommended_layout(cfg, int(B), 1 if solve else 0)
+    if rc < 0:
+        raise RuntimeError(f"i2lqr_recommended_layout failed ({rc})")
+    return {0: "wave", 1: "lane", 2: "tiled"}[rc]
+
+
+def kernel_label(kernel, layout):
+    if kernel.startswith("k_group_iterate (sixteen"):
+        return "problem-major (four problems per wavefront, sixteen lanes each)"
+    if kernel.startswith("k_group_iterate"):
+        return "problem-major (eight problems per wavefront)"
+    if kernel == "k_quad_iterate":
+        return "problem-major (four problems per wavefront)"
+    return LAYOUT_NAME[layout]
+
+
+def waves_of(kernel, B):
+    """Main wavefronts of a launch (helper wavefronts not counted)."""
+    if kernel == "k_iterate":
+        return B
+    if kernel.startswith("k_group_iterate (sixteen") or kernel == "k_quad_iterate":
+        return (B + 3) // 4
+    if kernel.startswith("k_group_iterate") or kernel == "k_group_spec":
+        return (B + 7) // 8
+    return (B + 63) // 64
+
+
+def accepted_fraction(lamb, lamb0, iters, factor):
+    """Share of the `iters` fixed-count iterations that were accepted steps: every accept divides
+    lamb by `factor`, every reject multiplies it (control/iterative_ilqr.py:76, :82), so
+    accepts - rejects = log(lamb0 / lamb) / log(factor)."""
+    import torch
+    d = torch.log(lamb0.double() / lamb.double()) / torch.log(torch.tensor(float(factor), dtype=torch.float64))
+    acc = (iters + torch.round(d)) / 2.0
+    return float((acc / iters).mean())
 
 
 def make_step_buffers(solver, host, n_sets, torch):
@@ -265,6 +294,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     host = workloads.make_batch(cfg, B, offset=rank * B)
     sets = make_step_buffers(solver, host, steps + warmup, torch)
+    l0_first = sets[-1]["lamb"].clone()
     qfun = torch.zeros(B, dtype=torch.int32, device=solver.device)
     # one cost vector per step: the exchange of step i (all-gather + arg-min) runs on a side
     # stream and overlaps the solve of step i+1 (the steps are independent candidate batches)
@@ -279,15 +309,25 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             # the communicator behind i2lqr_allgather_costs is created here by every rank at once;
             # if RCCL cannot be bound or bootstrapped that way on this node, all ranks fall back
             # to torch.distributed's all-gather together and the JSON line says so
+            poisoned = False
             try:  # (raises on every rank or on none: CostExchange agrees on each bring-up step)
                 exchange = dist_mod.CostExchange(solver)
                 ok = 1
+            except dist_mod.CostExchangePoisoned as e:
+                native_error, ok, poisoned = f"{type(e).__name__}: {e}", 0, True
             except Exception as e:  # noqa: BLE001
                 native_error, ok = f"{type(e).__name__}: {e}", 0
-            flag = torch.tensor([ok], dtype=torch.int32,
-                                device=solver.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+            # agreement over the HOST-side channel (no device collective next to a bootstrap that
+            # may still be running in an abandoned thread)
+            all_ok, none_poisoned = dist_mod._agree([ok == 1, not poisoned], dist_mod.host_group())
+            if not none_poisoned and os.environ.get("I2LQR_BENCH_LAUNCHER") == "1":
+                # some rank's ncclCommInitRank never returned: this set of processes is not to be
+                # trusted with the device any more.  Under bench.py's own launcher every rank
+                # leaves (non-zero) and the launcher starts FRESH ranks on the torch exchange.
+                sys.stderr.write(f"bench.py rank {rank}: {native_error}; leaving for a fresh start\n")
+                sys.stderr.flush()
+                os._exit(75)
+            if not all_ok:
                 if exchange != "torch" and not isinstance(exchange, str):
                     exchange.close()
                 exchange = "torch"
@@ -301,32 +341,49 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     xv1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     picks = []
 
+    fused = solver.iterate_kernel(B).startswith("k_group_iterate")
+    bests = [(torch.zeros(1, dtype=torch.int64, device=solver.device),
+              torch.zeros(1, dtype=solver.dtype, device=solver.device))
+             for _ in range(steps + warmup)] if with_tail and exchange is None else None
+
     def step(i_set, i_timed=None):
         buf, cost_it = sets[i_set], cost_its[i_set]
         bracket = i_timed is not None and i_timed % event_stride == 0
         if bracket:
             ev0[i_timed].record()
-        solver.iterate(buf, args.iters)
+        # One call per control round (i2lqr_iterate_pick).  On the eight- / sixteen-lane kernels it
+        # is ONE launch — relaxed cost in the kernel's exit block, the pick a last-workgroup-done
+        # reduction — and the bracket holds that launch; the other families run iterate,
+        # relax_cost and argmin as launches and the bracket holds the dominant one.
+        if not with_tail:
+            solver.iterate(buf, args.iters)
+        elif fused and exchange is None:
+            picks.append(solver.iterate_pick(buf, args.iters, qfun, 0, 55, cost_it,
+                                             best=bests[i_set])[1])
+        elif fused:
+            solver.iterate_pick(buf, args.iters, qfun, 0, 55, cost_it, pick=False)
+        else:
+            solver.iterate(buf, args.iters)
         if bracket:
             ev1[i_timed].record()
-        if with_tail:
+        if with_tail and not fused:
             solver.relax_cost(buf["X"], buf["x_term"], qfun, 0, 55, cost_it)
             if exchange is None:
                 picks.append(solver.argmin(cost_it))
-            else:
-                ready = torch.cuda.Event()
-                ready.record(main_stream)
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ready)
-                    if bracket:
-                        xv0[i_timed].record()
-                    if exchange == "torch":
-                        cost_all = dist_mod.allgather_costs(cost_it)
-                    else:
-                        cost_all = exchange.allgather(cost_it, cost_alls[i_set])
-                    picks.append(solver.argmin(cost_all))
-                    if bracket:
-                        xv1[i_timed].record()
+        if with_tail and exchange is not None:
+            ready = torch.cuda.Event()
+            ready.record(main_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready)
+                if bracket:
+                    xv0[i_timed].record()
+                if exchange == "torch":
+                    cost_all = dist_mod.allgather_costs(cost_it)
+                else:
+                    cost_all = exchange.allgather(cost_it, cost_alls[i_set])
+                picks.append(solver.argmin(cost_all))
+                if bracket:
+                    xv1[i_timed].record()
 
     for i in range(warmup):
         step(i)
@@ -361,9 +418,17 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
     res = dict(seconds=seconds, kernel_ms=kern_ms, kernel_ms_stats=kstat,
                kernel_ms_raw_median=spread(raw)["median"], event_pair_overhead_ms=overhead,
                iterations=world * B * args.iters * steps,
-               rank_seconds=rank_seconds, kernel=kernel,
-               layout=(LAYOUT_NAME[layout] if not kernel.startswith("k_group_iterate") else
-                       "problem-major (eight problems per wavefront)"))
+               rank_seconds=rank_seconds, kernel=kernel, layout=kernel_label(kernel, layout),
+               launches_per_step=1 if (fused and with_tail) else (3 if with_tail else 1),
+               # share of the fixed-count iterations that were accepted steps (a rejected step of
+               # the one-problem-per-lane kernels stores no states: "defer_states")
+               accepted_fraction=accepted_fraction(sets[-1]["lamb"], l0_first, args.iters,
+                                                   cfg.lamb_factor))
+    if with_tail and exchange is None:
+        # the pick of the last step is the first-index arg-min of its relaxed costs
+        idx, val = picks[-1]
+        first, best = dist_mod.select_best_flat(cost_its[warmup + steps - 1])
+        assert int(idx.item()) == first and float(val.item()) == best, "fused pick mismatch"
     if exchange is not None:
         res["exchange_ms"] = sum(xv0[i].elapsed_time(xv1[i]) for i in timed) / len(timed)
         # the pick is the same on every rank and is the arg-min of the gathered vector
@@ -380,6 +445,10 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             res["exchange_path"] = "torch"
             if native_error:
                 res["native_exchange_error"] = native_error
+            if dist_mod.abandoned_bring_ups() or (native_error and "Poisoned" in native_error):
+                # foreign launcher: nobody can restart the ranks, the run goes on over torch's
+                # exchange and the process leaves through os._exit at the end
+                res["poisoned_bring_up"] = True
     solver.close()
     return res
 
@@ -396,6 +465,7 @@ def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EX
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     host = workloads.make_batch(cfg, B)
     sets = make_step_buffers(solver, host, warmup + launches, torch)
+    l0 = sets[-1]["lamb"].clone()
     overhead = empty_bracket_ms(torch)
     vals = []
     for i in range(warmup + launches):
@@ -409,16 +479,16 @@ def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EX
             vals.append(max(e0.elapsed_time(e1) - overhead, 0.0))
     assert int(sets[-1]["iters"].min()) == iters == int(sets[-1]["iters"].max())
     kernel = solver.iterate_kernel(B)
-    name = ("problem-major (eight problems per wavefront)" if kernel.startswith("k_group_iterate")
-            else "problem-major (four problems per wavefront)" if kernel == "k_quad_iterate"
-            else LAYOUT_NAME[layout])
+    name = kernel_label(kernel, layout)
+    acc = accepted_fraction(sets[-1]["lamb"], l0, iters, cfg.lamb_factor)
     solver.close()
     st = spread(vals)
     return {"kernel": kernel, "layout": name, "kernel_ms": st["median"],
             "kernel_ms_mean": st["mean"],  # (what a kernel-trace summary's AverageNs compares with)
             "kernel_ms_min": st["min"],
             "kernel_ms_max": st["max"], "kernel_ms_rel_spread": st["rel_spread"],
-            "launches": st["samples"], "warmup": warmup,
+            "launches": st["samples"], "warmup": warmup, "accepted_fraction": acc,
+            "waves_per_simd": waves_of(kernel, B) / SIMDS,
             "iterations_per_s": B * iters / (st["median"] * 1e-3)}
 
 
@@ -441,7 +511,7 @@ def roofline_entry(cfg, B, iters, r, traffic):
 def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
-    layout = pick_layout(args, B, solve=True)
+    layout = pick_layout(args, B, solve=True, cfg=cfg)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
     if single_launch:
@@ -609,7 +679,7 @@ def cpu_baseline(cfg, B, iters, budget_s):
 def run_exchange_only(args, rank, world, torch, dist_mod):
     # test hook of the launcher's timeout / fresh-process fallback (tests/test_dist_gloo.py): a
     # "native" attempt that never returns, as a rank stuck in a communicator bootstrap would
-    if os.environ.get("I2LQR_BENCH_TEST_HANG") == args.exchange:
+    if args.test_hooks and os.environ.get("I2LQR_BENCH_TEST_HANG") == args.exchange:
         time.sleep(3600)
     """The multi-rank harness without the solve (CPU tensors, gloo): per step every rank
     contributes a synthetic cost shard, all-gathers, and picks; the pick is checked against the
@@ -704,8 +774,7 @@ def run_rank(args) -> int:
     alg_bytes = workloads.algorithmic_bytes_per_iteration(cfg)
     achieved = alg_bytes * B * args.iters / (res["kernel_ms"] * 1e-3) / 1e9
     key = f"{args.workload}:{dtype}:B{B}:it{args.iters}"
-    waves = (B if res["kernel"] == "k_iterate" else (B + 7) // 8
-             if res["kernel"].startswith("k_group_iterate") else (B + 63) // 64)
+    waves = waves_of(res["kernel"], B)
 
     out = {
         "metric": "batched iLQR iterations/s (n=6,m=2,N=20)" if wl["system"] == "bicycle6"
@@ -725,8 +794,38 @@ def run_rank(args) -> int:
                                f"{wl['system']} n={cfg.n} m={cfg.m} N={cfg.N} dt={cfg.dt}",
                    "batch_per_gpu": B, "global_batch": B * world, "layout": res["layout"],
                    "iterations_per_step": args.iters,
-                   "step": "i2lqr_iterate + relax_cost + all-gather(costs) + argmin",
+                   "step": ("i2lqr_iterate_pick: ONE launch (iterations + relaxed cost + pick)"
+                            if res["launches_per_step"] == 1 and world == 1 else
+                            "i2lqr_iterate_pick (iterations + relaxed cost) + all-gather(costs) + "
+                            "i2lqr_argmin"),
+                   "launches_per_step": res["launches_per_step"],
                    "parallelism": f"batch-sharded x{world}, one all-gather of terminal costs"},
+    }
+    # (the driver keeps the head of the line: the multi-rank facts come before the long objects)
+    out["per_rank_iterations_per_s"] = [B * args.iters * args.steps / s for s in res["rank_seconds"]]
+    if "exchange_ms" in res:
+        out["exchange"] = {"path": res["exchange_path"], "nccl_world": res["nccl_world"],
+                           "ms_per_step": res["exchange_ms"],
+                           "what": "i2lqr_allgather_costs (RCCL ncclAllGather via the C-ABI) + "
+                                   "i2lqr_argmin on a side stream" if res["exchange_path"] == "native"
+                           else "torch.distributed.all_gather_into_tensor + i2lqr_argmin on a "
+                                "side stream",
+                           "bytes_per_rank": B * (8 if dtype == "f64" else 4)}
+        for k in ("native_exchange_error", "poisoned_bring_up"):
+            if k in res:
+                out["exchange"][k] = res[k]
+    if world > 1 and args.steps < LONG_RUN_STEPS:
+        # the contract's K timed steps may be a few milliseconds, of which the two barriers are a
+        # visible share: the same loop once more over LONG_RUN_STEPS steps, reported beside it
+        lr = run_gpu(args, cfg, B, rank, world, torch, dist_mod, LONG_RUN_STEPS, args.warmup,
+                     event_stride=event_stride_for(LONG_RUN_STEPS))
+        out["long_run"] = {"steps": LONG_RUN_STEPS, "value": lr["iterations"] / lr["seconds"],
+                           "ms_per_step": lr["seconds"] / LONG_RUN_STEPS * 1e3,
+                           "per_rank_iterations_per_s": [B * args.iters * LONG_RUN_STEPS / s
+                                                         for s in lr["rank_seconds"]],
+                           "exchange_path": lr.get("exchange_path"),
+                           "exchange_ms_per_step": lr.get("exchange_ms")}
+    out.update({
         "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc.get(key), "algorithmic_bytes_per_iteration": alg_bytes,
@@ -738,22 +837,15 @@ def run_rank(args) -> int:
                      "kernel_ms_min": res["kernel_ms_stats"]["min"],
                      "kernel_ms_max": res["kernel_ms_stats"]["max"],
                      "kernel_ms_raw_median": res["kernel_ms_raw_median"],
-                     "event_pair_overhead_ms": res["event_pair_overhead_ms"], **pmc.stamp(),
+                     "event_pair_overhead_ms": res["event_pair_overhead_ms"],
+                     "step_ms_outside_kernel": res["seconds"] / args.steps * 1e3 - res["kernel_ms"],
+                     "accepted_fraction": res["accepted_fraction"],
+                     "waves_per_simd": waves / SIMDS, **pmc.stamp(),
                      # SQ counters of the same kernel (separate --pmc pass): shares of the
                      # wavefronts' lifetime spent issuing (any / VALU), parked on s_waitcnt, stalled
                      "sq_shares_of_wave_cycles": pmc.get(key, "sq_shares_of_wave_cycles")},
         "roofline_issue": issue_roofline(pmc, key, res["kernel_ms"], waves),
-        "per_rank_iterations_per_s": [B * args.iters * args.steps / s for s in res["rank_seconds"]],
-    }
-    if "exchange_ms" in res:
-        out["exchange"] = {"ms_per_step": res["exchange_ms"], "nccl_world": res["nccl_world"],
-                           "path": "i2lqr_allgather_costs (RCCL ncclAllGather via the C-ABI) + "
-                                   "i2lqr_argmin on a side stream" if res["exchange_path"] == "native"
-                           else "torch.distributed.all_gather_into_tensor + i2lqr_argmin on a "
-                                "side stream",
-                           "bytes_per_rank": B * (8 if dtype == "f64" else 4)}
-        if "native_exchange_error" in res:
-            out["exchange"]["native_exchange_error"] = res["native_exchange_error"]
+    })
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B, args.iters, args.cpu_seconds)

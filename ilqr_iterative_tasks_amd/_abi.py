@@ -143,6 +143,7 @@ EXPORTS = {
     "i2lqr_config_default": (C.c_int, [C.POINTER(I2lqrConfig), C.c_int, C.c_int]),
     "i2lqr_create": (C.c_int, [C.POINTER(I2lqrConfig), C.POINTER(_P)]),
     "i2lqr_destroy": (C.c_int, [_P]),
+    "i2lqr_recommended_layout": (C.c_int, [C.POINTER(I2lqrConfig), C.c_int64, C.c_int32]),
     "i2lqr_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
     "i2lqr_set_workspace": (C.c_int, [_P, _P, C.c_int64]),
     "i2lqr_set_compaction": (C.c_int, [_P, C.c_int64]),
@@ -158,6 +159,8 @@ EXPORTS = {
     "i2lqr_relax_cost": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "i2lqr_argmin_workspace_bytes": (C.c_int64, [C.c_int64]),
     "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "i2lqr_iterate_pick": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "i2lqr_select_candidates": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
                                           C.c_int32, _P, _P, _P, _P]),
     "i2lqr_init_candidates": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P, _P, _P]),
@@ -166,6 +169,7 @@ EXPORTS = {
     "i2lqr_comm_unique_id": (C.c_int, [_P]),
     "i2lqr_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "i2lqr_comm_destroy": (C.c_int, [_P]),
+    "i2lqr_comm_abort": (C.c_int, [_P]),
     "i2lqr_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "i2lqr_allgather_costs": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
 }

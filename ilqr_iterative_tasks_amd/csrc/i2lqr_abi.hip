@@ -125,13 +125,25 @@ struct i2lqr_handle {
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
   int opt_spec;   // eight-lane kernel: speculative form (2-3 wavefronts per eight problems); -1 = automatic
   int opt_group_ws;  // eight-lane kernel: workspace form (records / gains in HBM); -1 = automatic
+  // i2lqr_iterate_pick: the epilogue the call asks for (null outside such a call); `fused` is set
+  // by the launcher that folded it into its kernel, otherwise the call runs the separate kernels
+  struct Epilogue {
+    const int32_t* qfun;
+    int outer_iter, max_relax_iter;
+    void* cost_it;
+    void* part;
+    int64_t* best_idx;
+    void* best_cost;
+    bool fused;
+  }* epi;
+  unsigned* ticket;  // device word of the last-workgroup-done reduction (wraps to 0 by itself)
 };
 
 namespace {
 
 // Which fused kernel a problem-major call runs on: ONE function, used by the launchers and by
 // i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
-enum FusedKernel { K_WAVE, K_GROUP, K_GROUP_WS, K_SPEC, K_QUAD, K_INVALID };
+enum FusedKernel { K_WAVE, K_GROUP, K_GROUP16, K_GROUP_WS, K_SPEC, K_QUAD, K_INVALID };
 constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
 constexpr int64_t kAutoSpecBatch = 8192;   // speculative form for solves up to here (automatic)
 
@@ -170,6 +182,19 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
         (h->opt_spec == 1 ||
          (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
       return K_SPEC;
+    // Sixteen lanes per problem (one problem per DPP row; GroupWorker::backward_row): the backward
+    // step exchanges its columns by row broadcasts, no LDS round trip in the serial chain.  Four
+    // problems per wavefront: automatic while that still leaves every wavefront a SIMD of its own
+    // (kAutoGroupBatch ... kGroup16Batch problems); "group_lanes" 16 / 8 pins the choice.
+    const bool can16 = group16_supported(h->cfg);  // (four slices: longer horizons than `can`)
+    if (h->opt_group == 16 && !can16) {
+      *why = "\"group_lanes\" = 16 needs a bicycle plant with Q = R = 0 and a horizon whose four "
+             "problem slices fit the 160 KiB of LDS";
+      return K_INVALID;
+    }
+    if (h->opt_group == 16 ||
+        (h->opt_group < 0 && can16 && B >= kAutoGroupBatch && B <= kGroup16Batch))
+      return K_GROUP16;
     if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
       // more than 4096 problems (two wavefronts per CU are full): the workspace form, four
       // wavefronts per CU, whenever the caller's workspace is registered ("group_workspace" 0 / 1
@@ -200,8 +225,8 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
       return K_INVALID;
     }
     if ((h->opt_group == 16 || h->opt_group < 0) && can && have_ws) return K_QUAD;
-  } else if (h->opt_group == 16) {
-    *why = "\"group_lanes\" = 16 is built for the n + m = 16 plant only";
+  } else if (h->opt_group == 16 && !m2) {
+    *why = "\"group_lanes\" = 16 is built for the bicycles (DPP row form) and the n + m = 16 plant";
     return K_INVALID;
   }
   return K_WAVE;
@@ -272,7 +297,21 @@ template <class T, class Sys> struct Launch {
     a.dbg = (unsigned long long*)h->ws;  // diagnostic build: caller registers [B][8] u64 here
 #endif
     const char* why = "";
-    switch (select_fused(h, B, early_exit != 0, &why)) {
+    const FusedKernel fk = select_fused(h, B, early_exit != 0, &why);
+    if (h->epi && (fk == K_GROUP || fk == K_GROUP16 || fk == K_GROUP_WS)) {  // the eight-lane kernels carry the epilogue
+      a.qfun = h->epi->qfun;
+      a.outer_iter = h->epi->outer_iter;
+      a.max_relax_iter = h->epi->max_relax_iter;
+      a.cost_it = (T*)h->epi->cost_it;
+      if (h->epi->best_idx) {
+        a.pick_part = (MinPair<T>*)h->epi->part;
+        a.pick_ticket = h->ticket;
+        a.best_idx = h->epi->best_idx;
+        a.best_cost = (T*)h->epi->best_cost;
+      }
+      h->epi->fused = true;
+    }
+    switch (fk) {
       case K_INVALID:
         return fail(I2LQR_ERR_UNSUPPORTED, "%s", why);
       case K_SPEC:
@@ -284,6 +323,12 @@ template <class T, class Sys> struct Launch {
       case K_GROUP:
         if constexpr (m == 2 && n + m <= 8) {
           HIP_TRY(group_iterate<T>(h->cfg, a, s));
+          return I2LQR_OK;
+        }
+        break;
+      case K_GROUP16:
+        if constexpr (m == 2 && n + m <= 8) {
+          HIP_TRY(group16_iterate<T>(h->cfg, a, s));
           return I2LQR_OK;
         }
         break;
@@ -825,15 +870,6 @@ int check_common(const i2lqr_handle* h, int64_t B) {
 }
 
 // ---- arg-min kernels (flat, first index wins ties) -------------------------------------------
-template <class T> struct MinPair { T v; int64_t i; };
-
-template <class T> __device__ __forceinline__ bool better(T v, int64_t i, T bv, int64_t bi) {
-  // NaN never wins; ties resolve to the lower index (Python list.index(min(list)))
-  if (v != v) return false;
-  if (bi < 0) return true;
-  return v < bv || (v == bv && i < bi);
-}
-
 // FINAL: a single workgroup scans the whole vector and writes the result itself (small batches:
 // one launch instead of two)
 template <class T, bool FINAL = false>
@@ -916,12 +952,14 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "";  // the loader's message, captured once (dlerror() is cleared by reading it)
 };
 
 const RcclApi& rccl_api() {
@@ -932,17 +970,23 @@ const RcclApi& rccl_api() {
     if (!a.lib)
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!a.lib) return a;
+    if (!a.lib) {
+      const char* e = dlerror();
+      snprintf(a.why, sizeof(a.why), "%s", e ? e : "librccl.so not found by the dynamic loader");
+      return a;
+    }
     auto sym = [&](const char* n) { return dlsym(a.lib, n); };
     a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))sym("ncclCommAbort");
     a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
     a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
     a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
-    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommCount && a.CommUserRank &&
-           a.AllGather && a.GetErrorString;
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommAbort && a.CommCount &&
+           a.CommUserRank && a.AllGather && a.GetErrorString;
+    if (!a.ok) snprintf(a.why, sizeof(a.why), "the loaded librccl lacks a symbol this library binds");
     return a;
   }();
   return api;
@@ -1072,9 +1116,18 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
   h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = h->opt_group_ws = -1;
   h->wave_tail = -1;
-  HIP_TRY(hipGetDevice(&h->device));
+  h->epi = nullptr;
+  h->ticket = nullptr;
+  if (hipGetDevice(&h->device) != hipSuccess || hipMalloc((void**)&h->ticket, 64) != hipSuccess ||
+      hipMemset(h->ticket, 0, 64) != hipSuccess) {
+    if (h->ticket) (void)hipFree(h->ticket);
+    delete h;
+    return fail(I2LQR_ERR_LAUNCH, "could not set up the handle's device state: %s",
+                hipGetErrorString(hipGetLastError()));
+  }
   const int rc = prepare_dispatch(h);
   if (rc != I2LQR_OK) {
+    (void)hipFree(h->ticket);
     delete h;
     return rc;
   }
@@ -1095,6 +1148,7 @@ int i2lqr_destroy(i2lqr_handle* h) {
       return fail(I2LQR_ERR_INVALID, "i2lqr_destroy: %p is not a live handle (destroyed twice?)",
                   (void*)h);
   }
+  if (h->ticket) (void)hipFree(h->ticket);
   delete h;
   return I2LQR_OK;
 }
@@ -1127,6 +1181,46 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
       return 0;
     default: return 0;
   }
+}
+
+// Batch sizes from which the one-problem-per-lane layouts win over the problem-major kernels
+// (tools/ab_bench.py, tools/solve_bench.py, interleaved on one device; fp64, n=6, N=20):
+//   iterate: 8192: 260 (eight-lane workspace form) vs 146 M it/s (lane), 12288: 216 vs 223,
+//            16384: 285 lane;   solve: 8192: 1.17 vs 1.68 ms, 16384: 1.80 vs 1.30 ms;
+//   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
+//   8192 and 73 M at 65536.
+constexpr int64_t kLaneBatchIterate = 10240;
+constexpr int64_t kLaneBatchSolve = 16384;
+constexpr int64_t kLaneBatchQuad = 8192;
+
+int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit) {
+  if (!cfg) return fail(I2LQR_ERR_INVALID, "null config");
+  if (cfg->struct_size != (int32_t)sizeof(i2lqr_config))
+    return fail(I2LQR_ERR_INVALID, "config struct_size %d, library expects %zu", cfg->struct_size,
+                sizeof(i2lqr_config));
+  if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
+  // what the lane layouts cannot run stays problem-major: stage weights, non-symmetric weights,
+  // quad12 in fp32
+  bool lane_ok = true;
+  for (int i = 0; i < cfg->n && lane_ok; i++)
+    for (int j = 0; j < cfg->n; j++)
+      if (cfg->Q[i * I2LQR_MAX_N + j] != 0.0 ||
+          cfg->Qt[i * I2LQR_MAX_N + j] != cfg->Qt[j * I2LQR_MAX_N + i]) { lane_ok = false; break; }
+  for (int a = 0; a < cfg->m && lane_ok; a++)
+    for (int b = 0; b < cfg->m; b++)
+      if (cfg->R[a * I2LQR_MAX_M + b] != 0.0) { lane_ok = false; break; }
+  int64_t from;
+  switch (cfg->system_id) {
+    case I2LQR_SYS_BICYCLE4:
+    case I2LQR_SYS_BICYCLE6: from = early_exit ? kLaneBatchSolve : kLaneBatchIterate; break;
+    case I2LQR_SYS_QUAD12:
+      from = kLaneBatchQuad;
+      if (cfg->dtype != I2LQR_F64) lane_ok = false;
+      break;
+    default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
+  }
+  if (!lane_ok || B < from) return I2LQR_LAYOUT_PROBLEM_MAJOR;
+  return B % 64 == 0 ? I2LQR_LAYOUT_BATCH_TILED : I2LQR_LAYOUT_BATCH_MINOR;
 }
 
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch) {
@@ -1183,6 +1277,7 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
   switch (select_fused(h, B, early_exit, nullptr)) {
     case K_SPEC: return "k_group_spec";
     case K_GROUP: return "k_group_iterate";
+    case K_GROUP16: return "k_group_iterate (sixteen lanes)";
     case K_GROUP_WS: return "k_group_iterate (workspace form)";
     case K_QUAD: return "k_quad_iterate";
     case K_WAVE: return "k_iterate";
@@ -1278,8 +1373,10 @@ int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_te
 }
 
 int64_t i2lqr_argmin_workspace_bytes(int64_t B) {
-  (void)B;
-  return (int64_t)kArgminBlocks * 16;
+  // one (value, index) pair per workgroup: 256 for i2lqr_argmin, one per eight problems for the
+  // pick that i2lqr_iterate_pick folds into the eight-lane kernels
+  const int64_t rows = B > 0 ? (B + 3) / 4 : 0;  // ... one per four on the sixteen-lane form
+  return (rows > kArgminBlocks ? rows : (int64_t)kArgminBlocks) * 16;
 }
 
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
@@ -1314,6 +1411,40 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
   }
   HIP_TRY(hipGetLastError());
   return I2LQR_OK;
+}
+
+int i2lqr_iterate_pick(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
+                       const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                       int32_t* iters, int32_t* status, const int32_t* qfun, int32_t outer_iter,
+                       int32_t max_relax_iter, void* cost_it, int64_t* best_idx, void* best_cost,
+                       void* workspace, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (n_iters < 0) return fail(I2LQR_ERR_INVALID, "negative n_iters");
+  if (outer_iter < 0 || max_relax_iter < 1)
+    return fail(I2LQR_ERR_INVALID, "need outer_iter >= 0 and max_relax_iter >= 1");
+  if (best_idx && (!best_cost || !workspace))
+    return fail(I2LQR_ERR_INVALID, "best_idx needs best_cost and a workspace of "
+                "i2lqr_argmin_workspace_bytes(B)");
+  if (B == 0)  // nothing to solve; an empty pick is (-1, +inf) as in i2lqr_argmin
+    return best_idx ? i2lqr_argmin(h, 0, nullptr, best_idx, best_cost, workspace, stream) : I2LQR_OK;
+  if (!X || !U || !x_term || !lamb || !cost || !qfun || !cost_it)
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  if ((K == nullptr) != (k == nullptr))
+    return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
+  i2lqr_handle::Epilogue epi{qfun, outer_iter, max_relax_iter, cost_it, workspace, best_idx,
+                             best_cost, false};
+  h->epi = &epi;
+  const int rc = dispatch_iterate(h, B, n_iters, 0, X, U, x_term, lamb, obs, cost, K, k, iters,
+                                  status, stream);
+  h->epi = nullptr;
+  if (rc != I2LQR_OK) return rc;
+  if (!epi.fused) {  // kernel families without the epilogue: the same three steps as launches
+    if (int r2 = i2lqr_relax_cost(h, B, X, x_term, qfun, outer_iter, max_relax_iter, cost_it, stream))
+      return r2;
+    if (best_idx)
+      if (int r3 = i2lqr_argmin(h, B, cost_it, best_idx, best_cost, workspace, stream)) return r3;
+  }
+  return debug_check(I2LQR_OK, stream);
 }
 
 int i2lqr_select_candidates(i2lqr_handle* h, int32_t L, int32_t Tmax, const void* ss,
@@ -1384,14 +1515,14 @@ int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, 
 
 int i2lqr_comm_available(void) {
   const RcclApi& api = rccl_api();
-  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", api.why);
   return I2LQR_OK;
 }
 
 int i2lqr_comm_unique_id(void* id) {
   if (!id) return fail(I2LQR_ERR_INVALID, "null id buffer");
   const RcclApi& api = rccl_api();
-  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", api.why);
   static_assert(sizeof(ncclUniqueId) == I2LQR_COMM_ID_BYTES, "unique id size");
   ncclUniqueId uid;
   RCCL_TRY(api, api.GetUniqueId(&uid));
@@ -1405,7 +1536,7 @@ int i2lqr_comm_create(const void* id, int32_t world, int32_t rank, void** comm) 
   if (world < 1 || rank < 0 || rank >= world)
     return fail(I2LQR_ERR_INVALID, "need 0 <= rank < world (got rank %d, world %d)", rank, world);
   const RcclApi& api = rccl_api();
-  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror());
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded: %s", api.why);
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof(uid));
   ncclComm_t c = nullptr;
@@ -1419,6 +1550,14 @@ int i2lqr_comm_destroy(void* comm) {
   const RcclApi& api = rccl_api();
   if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
   RCCL_TRY(api, api.CommDestroy((ncclComm_t)comm));
+  return I2LQR_OK;
+}
+
+int i2lqr_comm_abort(void* comm) {
+  if (!comm) return I2LQR_OK;
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  RCCL_TRY(api, api.CommAbort((ncclComm_t)comm));
   return I2LQR_OK;
 }
 

@@ -15,6 +15,15 @@ bool group_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                             hipStream_t stream);
 
+// The same column scheme with SIXTEEN lanes per problem — one problem per 16-lane DPP row, four per
+// wavefront — whose backward step exchanges columns by DPP row broadcasts instead of LDS round trips
+// (i2lqr_group.hpp: GroupWorker::backward_row): the latency form, for batches that leave every
+// wavefront a SIMD of its own (up to kGroup16Batch problems).
+constexpr int64_t kGroup16Batch = 4096;
+bool group16_supported(const i2lqr_config& cfg);
+template <class T> hipError_t group16_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
+                                              hipStream_t stream);
+
 // Workspace form of the same kernel (records and gains in a caller-provided HBM workspace of
 // group_workspace_bytes() for B problems: 4 KB of LDS per problem, four wavefronts per CU): the
 // choice above kGroupWsBatch problems.  0 bytes if the configuration is not supported.

@@ -8,8 +8,8 @@ namespace i2lqr {
 
 namespace {
 
-template <class T, class Sys> size_t group_lds_bytes(int N) {
-  return (size_t)GLayout<Sys>(N).wave_words() * sizeof(T);
+template <class T, class Sys, int G = kGroup> size_t group_lds_bytes(int N) {
+  return (size_t)GLayout<Sys, G>(N).wave_words() * sizeof(T);
 }
 
 bool has_stage_weights(const i2lqr_config& cfg) {
@@ -41,14 +41,29 @@ template <auto Kernel> hipError_t raise_lds_limit(size_t lds) {
   return hipSuccess;
 }
 
-template <class T, class Sys, int H>
+template <class T, class Sys, int H, int G = kGroup>
 hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
-  const size_t lds = group_lds_bytes<T, Sys>(cfg.N);
-  if (hipError_t e = raise_lds_limit<k_group_iterate<T, Sys, H>>(lds); e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((a.B + kGroupsPerWave - 1) / kGroupsPerWave);
-  hipLaunchKernelGGL((k_group_iterate<T, Sys, H>), dim3(grid), dim3(64 * H), lds, s, c, a);
+  const size_t lds = group_lds_bytes<T, Sys, G>(cfg.N);
+  if (hipError_t e = raise_lds_limit<k_group_iterate<T, Sys, H, false, G>>(lds); e != hipSuccess)
+    return e;
+  constexpr int PW = 64 / G;
+  const unsigned grid = (unsigned)((a.B + PW - 1) / PW);
+  hipLaunchKernelGGL((k_group_iterate<T, Sys, H, false, G>), dim3(grid), dim3(64 * H), lds, s, c, a,
+                     (T*)nullptr);
   return hipGetLastError();
+}
+// Sixteen lanes per problem (one problem per DPP row, four per wavefront): the backward step
+// exchanges nothing through LDS (GroupWorker::backward_row).  One helper wavefront for the record
+// phase (2 x 16 lanes >= the 21 records of a problem: one round) while that leaves every wavefront
+// a SIMD of its own (<= 512 workgroups = 2048 problems).
+template <class T, class Sys>
+hipError_t launch16(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  constexpr int64_t kCUs = 256;
+#ifndef I2LQR_STAMPS
+  if ((a.B + 3) / 4 <= 2 * kCUs) return launch_h<T, Sys, 2, 16>(cfg, a, s);
+#endif
+  return launch_h<T, Sys, 1, 16>(cfg, a, s);
 }
 // Two helper wavefronts for the record phase (k_group_iterate<.., 3>) while every workgroup has
 // a CU to itself (<= 256 workgroups = 2048 problems): 0.2216 -> 0.2107 ms per 10 iterations at
@@ -147,6 +162,27 @@ template <> hipError_t group_spec_tail<float>(const i2lqr_config& cfg, const Ite
   if (cfg.system_id == I2LQR_SYS_BICYCLE4)
     return launch_spec<float, Bicycle4<float>, true>(cfg, a, s);
   return launch_spec<float, Bicycle6<float>, true>(cfg, a, s);
+}
+
+bool group16_supported(const i2lqr_config& cfg) {
+  if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
+  if (cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR || has_stage_weights(cfg)) return false;
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<double, Bicycle4<double>, 16>(cfg.N)
+                                             : group_lds_bytes<double, Bicycle6<double>, 16>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<float, Bicycle4<float>, 16>(cfg.N)
+                                             : group_lds_bytes<float, Bicycle6<float>, 16>(cfg.N));
+  return lds <= 160 * 1024;
+}
+template <> hipError_t group16_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                               hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch16<double, Bicycle4<double>>(cfg, a, s);
+  return launch16<double, Bicycle6<double>>(cfg, a, s);
+}
+template <> hipError_t group16_iterate<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                              hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch16<float, Bicycle4<float>>(cfg, a, s);
+  return launch16<float, Bicycle6<float>>(cfg, a, s);
 }
 
 bool group_supported(const i2lqr_config& cfg) {

@@ -101,8 +101,9 @@ template <class Sys> struct GroupPattern {
 #ifndef I2LQR_GROUP_UNROLL
 #define I2LQR_GROUP_UNROLL 4
 #endif
-template <class Sys> struct GLayout {
+template <class Sys, int G = kGroup> struct GLayout {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
+  static constexpr int PW = 64 / G;            // problems per wavefront
   static constexpr int KW = (n + 1 + 1) & ~1;  // gain row [K[a][0..n-1], k[a]] padded to 16 bytes (fp64)
   static constexpr int R_JV = 0, R_ZERO = NV, R_ONE = NV + 1, R_LU = NV + 2, R_LUU = NV + 2 + m,
                        R_OB = NV + 2 + 2 * m, RW = (NV + 2 + 2 * m + 5 + 1) & ~1;
@@ -127,8 +128,9 @@ template <class Sys> struct GLayout {
     if (((o / 4) & 1) == 0) o += 4;
     total = o;
   }
-  __host__ __device__ int t1_base() const { return kGroupsPerWave * total; }
-  __host__ __device__ int qt_base() const { return t1_base() + kGroupsPerWave * kT1Stride; }
+  __host__ __device__ int t1_base() const { return PW * total; }
+  // (the sixteen-lane form exchanges columns by DPP row broadcasts: no T1 buffers)
+  __host__ __device__ int qt_base() const { return t1_base() + (G == kGroup ? PW * kT1Stride : 0); }
   // control words of the helper wavefronts (k_group_iterate<.., H > 1>): int[8] nominal buffer of
   // each problem, int flags
   __host__ __device__ int ctl_base() const { return (qt_base() + n * n + 3) & ~3; }
@@ -139,11 +141,47 @@ template <class Sys> struct GLayout {
   __host__ __device__ int ws_words() const { return (RW * (N + 1) + m * KW * N + 15) & ~15; }
 };
 
-template <class T, class Sys, bool WS = false> struct GroupWorker {
+
+// ---------------------------------------------------------------------------------------------
+// DPP row broadcasts: the exchange primitive of the sixteen-lane form (G = 16: one problem per
+// 16-lane DPP row).  acc += bcast_L(src) * coef, where bcast_L is the value lane L of the row
+// holds: v_fmac_f64_dpp / v_fmac_f32_dpp with row_newbcast — the one DPP mode the fp64 ALU of
+// gfx90a+ has — costs what a plain multiply-add costs (tools/ubench_dpp.hip: 5.3 cycles
+// independent, 8.3 dependent for a wavefront alone on its SIMD) and replaces an LDS write -> wait
+// -> read round trip (108 cycles + 5 per 16-byte read).
+// Hazard: the hardware needs two wait states between a VALU write of a register and a DPP read of
+// it, and inline asm is invisible to the compiler's hazard recogniser.  One statement per
+// instruction (so that the scheduler can fill the latency of the step's dependent chain with
+// them); dpp_ready() is the fence a producer passes its values through (s_nop 1 tied to the
+// registers), and tests/test_isa_hygiene.py checks on the compiled ISA that no *_dpp instruction
+// reads a register one of the two instructions in front of it wrote.
+// ---------------------------------------------------------------------------------------------
+template <int L> __device__ __forceinline__ void bcast_fmac1(double& a, double s, double c) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(s), "v"(c), "n"(L));
+}
+template <int L> __device__ __forceinline__ void bcast_fmac1(float& a, float s, float c) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(s), "v"(c), "n"(L));
+}
+template <int L, class T, int R>
+__device__ __forceinline__ void bcast_fmac(T (&a)[R], const T (&s)[R], T c) {
+#pragma unroll
+  for (int r = 0; r < R; r++) bcast_fmac1<L>(a[r], s[r], c);
+}
+template <class T, int R> __device__ __forceinline__ void dpp_ready(T (&v)[R]) {
+  if constexpr (R == 8)
+    asm("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+  else if constexpr (R == 6)
+    asm("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+  else static_assert(R == 6 || R == 8, "dpp_ready: n + m of the bicycles");
+}
+
+template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorker {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NV = Sys::NVAR, NT = Sys::NTRIG;
   static constexpr int NA = n + 1;
   using Cfg = DevCfg<T, n, m>;
-  using GL = GLayout<Sys>;
+  using GL = GLayout<Sys, G>;
+  static_assert(G == kGroup || G == 16, "eight lanes per problem, or one 16-lane DPP row");
+  static_assert(G == kGroup || !WS, "the workspace form is built for eight lanes per problem");
   using GP = GroupPattern<Sys>;
   static_assert(GP::ok(), "plant does not have the column structure this kernel is written for");
   const Cfg& c;
@@ -169,11 +207,11 @@ template <class T, class Sys, bool WS = false> struct GroupWorker {
 #endif
 
   __device__ GroupWorker(const Cfg& c_, T* smem, int lane)
-      : GroupWorker(c_, smem + (lane / kGroup) * GLayout<Sys>(c_.N, WS).total,
-                    smem + GLayout<Sys>(c_.N, WS).qt_base(), lane % kGroup,
-                    GLayout<Sys>(c_.N, WS).total) {
-    const int p = lane / kGroup;
-    T1c = smem + L.t1_base() + p * GL::kT1Stride;
+      : GroupWorker(c_, smem + (lane / G) * GL(c_.N, WS).total,
+                    smem + GL(c_.N, WS).qt_base(), lane % G,
+                    GL(c_.N, WS).total) {
+    const int p = lane / G;
+    if constexpr (G == kGroup) T1c = smem + L.t1_base() + p * GL::kT1Stride;
     rho = (p >> 1) & 1;
   }
   // record t / gains of step t (LDS slice, or the HBM workspace in the WS form); gain_x: where the
@@ -387,6 +425,7 @@ template <class T, class Sys, bool WS = false> struct GroupWorker {
   //    run): the gains in LDS are left as the problem's last iteration wrote them.
   template <bool GENERAL>
   __device__ __forceinline__ bool backward(int XUo, const T (&xT)[n], T lamb, bool commit) const {
+    if constexpr (G == 16) return backward_row<GENERAL>(XUo, xT, lamb, commit);
     bool bad = false;
     // terminal value function, get_cost_final(): control/ilqr_helper.py:106-150.
     // va[i] = column g of [Vxx | Vx]
@@ -569,6 +608,209 @@ template <class T, class Sys, bool WS = false> struct GroupWorker {
     return bad;
   }
 
+
+  // -- backward pass, sixteen lanes per problem (G = 16): the same column ownership — lane j < n
+  //    holds column j of [Vxx | Vx] and forms column j of H, lane n the gradient column, lanes
+  //    above n idle along — but NO LDS exchange in the step: a problem is one 16-lane DPP row, and
+  //    every foreign operand of the step is a T1 entry of a lane whose index is known at compile
+  //    time, so it arrives as the broadcast operand of a multiply-add (bcast_fmac):
+  //      H[a][g]  = own T1[a][g] + F[0][g] T1[a][0] + F[1][g] T1[a][1] + dt T1[a][r(g)]   (P2)
+  //      Quu[a][b] = l_uu + sum_k B[k][b] T1[n+a][k]
+  //      Va'[i][g] = H[i][g] - (K^T Quu [K|k][:, g])[i]
+  //               = H[i][g] + sum_b Qux[b][i] z_g[b],  z_g = Quu_reg^-T Quu kc_g,
+  //        Qux[b][i] = sum_k B[k][b] T1[i][k]  — the transpose entry of what lane i formed as
+  //        H[n+b][i]; equal by the symmetry of Vxx, which the one-problem-per-lane kernels rely on
+  //        as well (round-off level; documented in DESIGN.md) —
+  //    so the gains are not exchanged at all: every lane stores its column for the forward pass
+  //    and nothing waits for the store.  ~135 instructions per step in chains the ALU latency
+  //    bounds, against 175 and two LDS round trips (2 x 108 cycles + 20 16-byte reads).
+  template <bool GENERAL>
+  __device__ __forceinline__ bool backward_row(int XUo, const T (&xT)[n], T lamb, bool commit) const {
+    static_assert(GL::KW > n + 1, "the padding word of a gain row takes the stores of idle lanes");
+    bool bad = false;
+    T va[n];
+    {
+      const T* Rn = rec(N);
+      T dx[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        T vxx = T(0), vx = T(0);
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+          const T q = T(2) * Qt[i * n + r];
+          vxx = (g == r) ? q : vxx;
+          vx += q * dx[r];
+        }
+        va[i] = (g == n) ? vx : vxx;
+      }
+      va[0] += Rn[off_l0];
+      va[1] += Rn[off_l1];
+    }
+    // lanes past the gain row and problems that no longer commit store into the row's padding word
+    const int gcol = (commit && g <= n) ? g : GL::KW - 1;
+    // dt entry of column g of A in row r: per-lane coefficient of the broadcast from lane r
+    T cdr[n];
+#pragma unroll
+    for (int r = 0; r < n; r++) cdr[r] = (rsrc == r) ? cdt : T(0);
+    struct Rec { T jv[NV], luu[m], c0, c1, l0, l1, lrow[m]; };
+    Rec ra, rb;
+    auto load_record = [&](int t, Rec& r) __attribute__((always_inline)) {
+      const T* R = rec(t);
+#pragma unroll
+      for (int q = 0; q < NV; q++) r.jv[q] = R[GL::R_JV + q];
+#pragma unroll
+      for (int a = 0; a < m; a++) r.luu[a] = R[GL::R_LUU + a];
+      r.c0 = R[off_c0];
+      r.c1 = R[off_c1];
+      r.l0 = R[off_l0];
+      r.l1 = R[off_l1];
+#pragma unroll
+      for (int a = 0; a < m; a++) r.lrow[a] = R[off_lu[a]];
+    };
+    // F[k][n + b] as a register operand
+    auto f_entry = [&](auto k_, auto b_, const T (&jv)[NV]) __attribute__((always_inline)) {
+      constexpr int code = Sys::pat(decltype(k_)::value, n + decltype(b_)::value);
+      if constexpr (code == 1) return T(1);
+      else if constexpr (code == 2) return c.dt;
+      else return jv[code >= 3 ? code - 3 : 0];
+    };
+    load_record(N - 1, ra);
+    auto step = [&](const int t, Rec& rc, Rec& rn) __attribute__((always_inline)) {
+      const T (&jv)[NV] = rc.jv;
+      STAMP_BEGIN();
+      // P1: own column of T1 = F^T [Vxx | Vx]
+      T t1[W];
+      static_for_i<0, W>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        T acc = T(0);
+        bool first = true;
+        static_for_i<0, n>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          f_acc<i, a>(acc, first, va[i], jv);
+        });
+        t1[a] = acc;
+      });
+      dpp_ready(t1);
+      load_record(t > 0 ? t - 1 : 0, rn);  // lands under the broadcast block
+      STAMP_END(1);
+      // Source order = the order that keeps the serial chain short: Quu and the input rows of the
+      // H column first (the inverse and the gain column wait for them), the state rows of the
+      // column — 4 n independent multiply-adds nothing waits for until the value update — behind
+      // them, where they fill the latency of the chain Quu -> inverse -> gain column.
+      // Quu (every lane) = l_uu + sum_k B[k][b] T1[n+a][k]
+      T Quu[m * m], Qinv[m * m];
+      {
+        T t1u[m];
+#pragma unroll
+        for (int a = 0; a < m; a++) t1u[a] = t1[n + a];
+        static_for_i<0, m>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          T col[m];
+#pragma unroll
+          for (int a = 0; a < m; a++) col[a] = (a == b) ? rc.luu[a] : T(0);
+          static_for_i<0, n>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            if constexpr (Sys::pat(k, n + b) != 0) bcast_fmac<k>(col, t1u, f_entry(k_, b_, jv));
+          });
+#pragma unroll
+          for (int a = 0; a < m; a++) Quu[a * m + b] = col[a];
+        });
+      }
+      // P2: column g of H (lanes < n) / the gradient column (lane n), rows [r0, r0 + R)
+      auto h_rows = [&](auto r0_, auto& hr) __attribute__((always_inline)) {
+        constexpr int r0 = decltype(r0_)::value;
+        constexpr int R = sizeof(hr) / sizeof(T);
+        T src[R];
+#pragma unroll
+        for (int a = 0; a < R; a++) { src[a] = t1[r0 + a]; hr[a] = own * t1[r0 + a]; }
+        bcast_fmac<0>(hr, src, rc.c0);
+        bcast_fmac<1>(hr, src, rc.c1);
+        static_for_i<2, n>([&](auto r_) {
+          constexpr int r = decltype(r_)::value;
+          constexpr bool used = [] {
+            for (int b = 0; b < n; b++)
+              if (GP::dt_row(b) == r) return true;
+            return false;
+          }();
+          if constexpr (used) bcast_fmac<r>(hr, src, cdr[r]);
+        });
+      };
+      T hu[m], hx[n];
+      h_rows(std::integral_constant<int, n>{}, hu);
+#pragma unroll
+      for (int a = 0; a < m; a++) hu[a] += rc.lrow[a];
+      STAMP_END(2);
+      if constexpr (GENERAL) quu_inverse(Quu, lamb, Qinv);
+      else t_quu_inverse2_pd(Quu, lamb, Qinv, &bad);
+      h_rows(std::integral_constant<int, 0>{}, hx);
+      hx[0] += rc.l0;
+      hx[1] += rc.l1;
+      STAMP_END(3);
+      // own column of [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
+      T kc[m];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], hu[b], acc);
+        kc[a] = -acc;
+      }
+      T* Kt = gain_x(t);
+#pragma unroll
+      for (int a = 0; a < m; a++) Kt[a * GL::KW + gcol] = kc[a];
+      STAMP_END(4);
+      // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
+      T qk[m], z[m];
+#pragma unroll
+      for (int a = 0; a < m; a++) {
+        T acc = T(0);
+#pragma unroll
+        for (int b = 0; b < m; b++) acc = t_fma(Quu[a * m + b], kc[b], acc);
+        qk[a] = acc;
+      }
+#pragma unroll
+      for (int b = 0; b < m; b++) {
+        T acc = T(0);
+#pragma unroll
+        for (int a = 0; a < m; a++) acc = t_fma(Qinv[a * m + b], qk[a], acc);
+        z[b] = acc;
+      }
+      T t1x[n], vn[n];
+#pragma unroll
+      for (int i = 0; i < n; i++) { t1x[i] = t1[i]; vn[i] = hx[i]; }
+      static_for_i<0, m>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        static_for_i<0, n>([&](auto k_) {
+          constexpr int k = decltype(k_)::value;
+          constexpr int code = Sys::pat(k, n + b);
+          if constexpr (code == 1) bcast_fmac<k>(vn, t1x, z[b]);
+          else if constexpr (code != 0) bcast_fmac<k>(vn, t1x, f_entry(k_, b_, jv) * z[b]);
+        });
+      });
+#pragma unroll
+      for (int i = 0; i < n; i++) va[i] = vn[i];
+      STAMP_END(5);
+    };
+    int t = N - 1;
+    if constexpr (I2LQR_GROUP_UNROLL >= 4) {
+      for (; t >= 3; t -= 4) {
+        step(t, ra, rb);
+        step(t - 1, rb, ra);
+        step(t - 2, ra, rb);
+        step(t - 3, rb, ra);
+      }
+    }
+    for (; t >= 1; t -= 2) {
+      step(t, ra, rb);
+      step(t - 1, rb, ra);
+    }
+    if (t == 0) step(0, ra, rb);
+    wave_sync();  // the forward pass reads the gain columns the other lanes stored
+    return bad;
+  }
+
   // -- forward pass: control/iterative_ilqr.py:133-160; all lanes of the group redundantly ------
   //    GENERAL = false: short sincos kernel only, *bad set if an angle left its range (the caller
   //    repeats the pass with GENERAL = true); see t_sincos_fast.
@@ -668,21 +910,21 @@ template <class T, class Sys, bool WS = false> struct GroupWorker {
 // WS: records and gains in the HBM workspace `ws` (GLayout::ws_words() words per problem, sized for
 // whole wavefronts: ceil(B / 8) * 8 problems), four wavefronts per CU instead of two — the form
 // for more than 4096 problems on the problem-major layout.  Same arithmetic, bit-identical.
-template <class T, class Sys, int H = 1, bool WS = false>
+template <class T, class Sys, int H = 1, bool WS = false, int G = kGroup>
 __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n, Sys::m> c,
                                                           const IterArgs<T> a, T* ws = nullptr) {
   static_assert(!(WS && H > 1), "the workspace form runs without helper wavefronts");
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
-  using GL = GLayout<Sys>;
+  using GL = GLayout<Sys, G>;
   extern __shared__ __align__(16) unsigned char gsmem_raw[];
   T* smem = reinterpret_cast<T*>(gsmem_raw);
   const int lane = threadIdx.x & 63, hv = threadIdx.x >> 6;
-  const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + lane / kGroup;
+  const int64_t prob0 = (int64_t)blockIdx.x * GL::PW + lane / G;
   // groups past the end of the batch work on a copy of the last problem and store nothing, so
   // that every lane of the wavefront runs the same control flow
   const bool real = prob0 < a.B;
   const int64_t prob = real ? prob0 : a.B - 1;
-  GroupWorker<T, Sys, WS> w(c, smem, lane);
+  GroupWorker<T, Sys, WS, G> w(c, smem, lane);
   const int N = c.N, g = w.g;
   const GL& L = w.L;
   const auto S = w.S;
@@ -696,7 +938,7 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
     const T* gX = a.X + prob * (int64_t)(n * (N + 1));
     if (g < n) S[L.XU0 + g] = gX[g * (N + 1)];
     const T* gU = a.U + prob * (int64_t)(m * N);
-    for (int e = g; e < m * N; e += kGroup) {
+    for (int e = g; e < m * N; e += G) {
       const int aa = e / N, t = e - aa * N;
       S[L.XU0 + t * W + n + aa] = gU[e];
     }
@@ -720,9 +962,9 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
         const int flags = ctl[8];
         if (!(flags & 1)) break;
         if (flags & 2) {
-          const int pc = ctl[lane / kGroup];
-          w.prep(pc ? L.XU1 : L.XU0, pc ? L.TR1 : L.TR0, ob, ob_pa, ob_pb, hv * kGroup + g,
-                 H * kGroup);
+          const int pc = ctl[lane / G];
+          w.prep(pc ? L.XU1 : L.XU0, pc ? L.TR1 : L.TR0, ob, ob_pa, ob_pb, hv * G + g,
+                 H * G);
         }
         __syncthreads();  // B2: the records are complete
       }
@@ -743,19 +985,19 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
     {
       auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
       STAMP_BEGIN();
-      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
+      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, G);
       STAMP_END(0);
     }
 #else
     if constexpr (H > 1) {
       const bool do_prep = __any(fresh);
-      if (g == 0) ctl[lane / kGroup] = cur;
+      if (g == 0) ctl[lane / G] = cur;
       if (lane == 0) ctl[8] = 1 | (do_prep ? 2 : 0);
       __syncthreads();  // B1
-      if (do_prep) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, H * kGroup);
+      if (do_prep) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, H * G);
       __syncthreads();  // B2
     } else {
-      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, kGroup);
+      if (__any(fresh)) w.prep(XUo, TRo, ob, ob_pa, ob_pb, g, G);
     }
 #endif
     // optimistic, branch-free passes first; the general forms only if a lane asked for them
@@ -811,23 +1053,23 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   if (real) {
     const int XUo = cur ? L.XU1 : L.XU0;
     T* gX = a.X + prob * (int64_t)(n * (N + 1));
-    for (int e = g; e < n * (N + 1); e += kGroup) {
+    for (int e = g; e < n * (N + 1); e += G) {
       const int i = e / (N + 1), t = e - i * (N + 1);
       gX[e] = S[XUo + t * W + i];
     }
     T* gU = a.U + prob * (int64_t)(m * N);
-    for (int e = g; e < m * N; e += kGroup) {
+    for (int e = g; e < m * N; e += G) {
       const int aa = e / N, t = e - aa * N;
       gU[e] = S[XUo + t * W + n + aa];
     }
     if (a.K) {
       T* gK = a.K + prob * (int64_t)(m * n * N);
-      for (int e = g; e < m * n * N; e += kGroup) {
+      for (int e = g; e < m * n * N; e += G) {
         const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
         gK[e] = w.gain(t)[aa * GL::KW + j];
       }
       T* gk = a.k + prob * (int64_t)(m * N);
-      for (int e = g; e < m * N; e += kGroup) {
+      for (int e = g; e < m * N; e += G) {
         const int aa = e / N, t = e - aa * N;
         gk[e] = w.gain(t)[aa * GL::KW + n];
       }
@@ -842,6 +1084,25 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
       if (a.iters) a.iters[prob] = it;
       if (a.status) a.status[prob] = status;
     }
+  }
+  // epilogue (i2lqr_iterate_pick): relaxed terminal cost of utils/base.py:427-437 from the x_N
+  // still in LDS — the words just stored to X, so i2lqr_relax_cost on the returned X gives the
+  // same bits — and the flat pick of :462-465 over the launch
+  if (a.qfun) {
+    const bool cand = real && g == 0;
+    T ci = T(0);
+    if (cand) {
+      const int XUo = cur ? L.XU1 : L.XU0;
+      double ss = 0.0;
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        const double d = (double)S[XUo + N * W + i] - (double)xT[i];
+        ss += d * d;
+      }
+      ci = (T)relax_cost_value(ss, a.qfun[prob], N, a.outer_iter, a.max_relax_iter);
+      a.cost_it[prob] = ci;
+    }
+    if (a.pick_part) pick_epilogue(a, cand, prob, ci);
   }
 }
 

@@ -23,7 +23,17 @@
 #include "i2lqr_systems.hpp"
 #include "i2lqr_wave.hpp"
 
+// This file encodes s_waitcnt fields by hand (gfx9 layout) and is written for gfx950; another
+// target's encoding (gfx10+ lgkmcnt width, gfx12 split counters) would turn the literal into a
+// silent race: refuse to compile device code for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "i2lqr_lane.hpp hard-codes the gfx9 s_waitcnt encoding: build with --offload-arch=gfx950"
+#endif
+
 namespace i2lqr {
+
+constexpr bool kGfx9Waitcnt = true;  // see the target guard above
+
 
 template <int Begin, int End, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (Begin < End) {
@@ -1161,7 +1171,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           bool first = true;
           static_for<0, n>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            const T vij = j == n ? vx[i] : (i <= j ? V[i][j] : V[j][i]);
+            T vij;
+            if constexpr (j == n) vij = vx[i];
+            else vij = i <= j ? V[i][j] : V[j][i];
             f_acc<i, n + a>(acc, first, vij, jv);
           });
           g[a] = acc;
@@ -1341,7 +1353,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         static_for<0, Sys::NBLK>([&](auto b_) { block_gain_row<decltype(b_)::value>(g, jv); });
         if constexpr (a == 0) {
           I2LQR_PHASE_FENCE();
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the inputs of step t-1 have landed
+          // vmcnt(0) in the gfx9 s_waitcnt encoding (vmcnt = bits 3:0 and 15:14, expcnt 6:4 and
+          // lgkmcnt 11:8 left at their maxima): the inputs of step t-1 have landed
+          static_assert(kGfx9Waitcnt, "s_waitcnt literal below is the gfx9 field layout");
+          __builtin_amdgcn_s_waitcnt(0x0F70);
           I2LQR_PHASE_FENCE();
         }
         for_rows<n>(gK, rK(a, 0, t), [&](auto j_, T& w) { w = g[decltype(j_)::value]; });

@@ -51,6 +51,16 @@ template <class T, int n, int m> struct DevCfg {
   unsigned long long* trap;  // debug build: the handle's violation record (i2lqr_debug.hpp); null otherwise
 };
 
+// (value, index) pair of the arg-min kernels and of the fused pick epilogue
+template <class T> struct MinPair { T v; int64_t i; };
+
+template <class T> __device__ __forceinline__ bool better(T v, int64_t i, T bv, int64_t bi) {
+  // NaN never wins; ties resolve to the lower index (Python list.index(min(list)))
+  if (v != v) return false;
+  if (bi < 0) return true;
+  return v < bv || (v == bv && i < bi);
+}
+
 template <class T> struct IterArgs {
   int64_t B;
   int n_iters;    // iterations to run (iterate) / max iterations (solve)
@@ -73,7 +83,81 @@ template <class T> struct IterArgs {
   const int32_t* count;
   int count_max, max_total;
   int64_t set_stride;
+  // Optional epilogue of the eight-lane kernels (i2lqr_iterate_pick): the relaxed terminal cost of
+  // every candidate (utils/base.py:427-437) from the x_N the kernel still holds, and the flat
+  // first-index arg-min over them (:462-465) by a last-workgroup-done reduction — one launch per
+  // control round instead of four.  qfun null: no epilogue; pick_part null: costs only.
+  const int32_t* qfun = nullptr;       // [B] cost-to-go in steps (I2LQR_QF_NONE: empty slot)
+  int outer_iter = 0, max_relax_iter = 0;
+  T* cost_it = nullptr;                // [B] out
+  MinPair<T>* pick_part = nullptr;     // [gridDim.x] partial minima (caller's arg-min workspace)
+  unsigned* pick_ticket = nullptr;     // the handle's ticket word (wraps to 0 by itself)
+  int64_t* best_idx = nullptr;         // [1] out
+  T* best_cost = nullptr;              // [1] out
 };
+
+// relaxed terminal cost of one candidate, utils/base.py:427-437: ss = ||x_N - x_term||_2^2 summed in
+// double in component order (k_relax_cost and the fused epilogue share this: bit-identical)
+__device__ __forceinline__ double relax_cost_value(double ss, int32_t qf, int N, int outer_iter,
+                                                   int max_relax_iter) {
+  const double nrm = sqrt(ss);
+  double scale = 1.0;
+  for (int q = 0; q < outer_iter; q++) scale *= 10.0;
+  double out = INFINITY;
+  if (qf == 0x7fffffff) return out;  // I2LQR_QF_NONE: an empty candidate slot (i2lqr_select_candidates)
+  for (int i = 1; i <= max_relax_iter; i++) {
+    if (nrm <= 80.0 * i / scale) { out = (double)qf + N + 100 * i; break; }
+    if (nrm > 80.0 * max_relax_iter / scale) break;
+  }
+  return out;
+}
+
+// The pick part of the epilogue.  `cand`: this lane carries candidate `prob` with cost `v`.
+// Wavefront minimum -> part[workgroup]; the workgroup that draws the last ticket reduces the
+// partial minima and writes the result.  better() is a total order on (value, index) with NaN
+// excluded, so the result does not depend on the order of the reduction: it is the flat arg-min
+// with first-index tie-break of k_argmin_partial / k_argmin_final.  Called by ONE wavefront per
+// workgroup, all 64 lanes.
+template <class T>
+__device__ __forceinline__ void pick_epilogue(const IterArgs<T>& a, bool cand, int64_t prob, T v) {
+  T bv = cand ? v : T(0);
+  int64_t bi = (cand && v == v) ? prob : -1;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const T ov = __shfl_xor(bv, s);
+    const int64_t oi = __shfl_xor(bi, s);
+    if (oi >= 0 && better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63;
+  unsigned ticket = 0;
+  if (lane == 0) {
+    __hip_atomic_store(&a.pick_part[blockIdx.x].v, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.pick_part[blockIdx.x].i, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    // wraps to 0 at gridDim.x - 1: the word is ready for the next launch without a reset
+    ticket = atomicInc(a.pick_ticket, gridDim.x - 1);
+  }
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != gridDim.x - 1) return;
+  __threadfence();
+  bv = T(0);
+  bi = -1;
+  for (unsigned p = lane; p < gridDim.x; p += 64) {
+    const T ov = __hip_atomic_load(&a.pick_part[p].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t oi = __hip_atomic_load(&a.pick_part[p].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (oi >= 0 && better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const T ov = __shfl_xor(bv, s);
+    const int64_t oi = __shfl_xor(bi, s);
+    if (oi >= 0 && better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    *a.best_idx = bi;
+    *a.best_cost = bi >= 0 ? bv : (T)INFINITY;
+  }
+}
 
 // Diagnostic build only (-DI2LQR_STAMPS, tools/stamp_build.sh): per-phase cycle shares of one
 // wave, accumulated in scalar registers and written to a debug buffer no other code reads.
@@ -941,18 +1025,7 @@ __global__ void k_relax_cost(int64_t B, int n, int N, int batch_minor, const T* 
     const double d = xN - xt;
     ss += d * d;
   }
-  const double nrm = sqrt(ss);
-  double scale = 1.0;
-  for (int q = 0; q < outer_iter; q++) scale *= 10.0;
-  double out = INFINITY;
-  if (qfun[b] == 0x7fffffff) {  // I2LQR_QF_NONE: an empty candidate slot (i2lqr_select_candidates)
-    cost_it[b] = (T)out;
-    return;
-  }
-  for (int i = 1; i <= max_relax_iter; i++) {
-    if (nrm <= 80.0 * i / scale) { out = (double)qfun[b] + N + 100 * i; break; }
-    if (nrm > 80.0 * max_relax_iter / scale) break;
-  }
+  const double out = relax_cost_value(ss, qfun[b], N, outer_iter, max_relax_iter);
   cost_it[b] = (T)out;
 }
 

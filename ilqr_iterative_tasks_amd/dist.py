@@ -71,21 +71,52 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
     return torch.cat([gathered[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)])
 
 
-def _agree(ok: bool, device, group=None) -> bool:
-    """True on every rank iff `ok` is true on every rank (one all-reduce; a world of one agrees
-    with itself)."""
+# Host-side side channel of a process group: the group itself if it runs on gloo, otherwise ONE gloo
+# group made next to it (every rank of the group calls this at the same point: dist.new_group is a
+# collective).  The bring-up below agrees on its outcomes over this channel only, so that no device
+# collective is issued by a rank whose helper thread may still sit inside ncclCommInitRank.
+_host_groups: dict = {}
+
+
+def host_group(group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return bool(ok)
-    dev = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(int(flag.item()))
+        return None
+    if dist.get_backend(group) == "gloo":
+        return group if group is not None else dist.group.WORLD
+    key = id(group) if group is not None else None
+    if key not in _host_groups:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _host_groups[key]
+
+
+def _agree(flags, hgroup) -> list[bool]:
+    """For every flag: true on every rank iff it is true on every rank (ONE all-reduce of host
+    integers over the host-side group; a world of one agrees with itself)."""
+    flags = [bool(f) for f in flags]
+    if hgroup is None:
+        return flags
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hgroup)
+    return [bool(int(v)) for v in t]
 
 
 class CostExchangeUnavailable(RuntimeError):
     """The native communicator could not be brought up — raised on EVERY rank of the group (the
     ranks agree on the outcome before and after the bootstrap), so the callers' fallbacks stay in
     step."""
+
+
+class CostExchangePoisoned(CostExchangeUnavailable):
+    """... because some rank's ncclCommInitRank did not return within its timeout (raised on every
+    rank; `self.here` tells whether THIS process holds the abandoned helper thread).  Such a
+    process group should not go on sharing a device with the abandoned bootstrap: a launcher that
+    can (bench.py's own) ends the ranks and starts fresh ones on the torch exchange; a rank started
+    by a foreign launcher carries on with the torch exchange and leaves through os._exit."""
+
+    def __init__(self, msg, here: bool):
+        super().__init__(msg)
+        self.here = here
 
 
 # Bring-ups whose ncclCommInitRank never returned: the daemon thread that made the call is still
@@ -110,22 +141,24 @@ class CostExchange:
     """The all-gather of the candidates' terminal costs through the C-ABI (i2lqr_allgather_costs:
     one RCCL ncclAllGather on a communicator the library creates itself).
 
-    The ranks agree on the communicator's unique id through the torch.distributed group that is
-    already up (any backend: the id is 128 bytes of host data, sent with broadcast_object_list);
-    without a process group this is a world of one.  A host language other than Python does the
-    same with i2lqr_comm_available / i2lqr_comm_unique_id / i2lqr_comm_create and its own side
-    channel.
+    The ranks agree on the communicator's unique id and on every step of the bring-up over a
+    HOST-side channel (host_group(): gloo; the id is 128 bytes of host data); without a process
+    group this is a world of one.  A host language other than Python does the same with
+    i2lqr_comm_available / i2lqr_comm_unique_id / i2lqr_comm_create and its own side channel.
 
     Bring-up never leaves the ranks in different collectives: (1) every rank checks that RCCL can
     be bound and the ranks agree on that; (2) rank 0 makes the id and broadcasts it — an EMPTY id
     if it failed, so the others do not sit in the broadcast; (3) every rank joins
-    ncclCommInitRank; (4) the ranks agree on the outcome.  Any failure raises
-    CostExchangeUnavailable on all ranks.  Step (3) blocks inside RCCL until every rank has
-    arrived; it runs in a helper thread and a rank that has waited `timeout` seconds (default
-    I2LQR_COMM_TIMEOUT = 180) gives up, reports failure in step (4) — where the other ranks, which
-    are waiting for the same bootstrap, arrive the same way — and leaves the thread behind
-    (abandoned_bring_ups()): under a launcher that is not bench.py's own (torchrun started by
-    someone else) nothing outside the rank could end a hung bootstrap."""
+    ncclCommInitRank; (4) the ranks agree on the outcome — a rank whose communicator came up while
+    another's did not frees it with i2lqr_comm_abort (ncclCommAbort: a destroy would wait for
+    peers that never arrived).  Any failure raises CostExchangeUnavailable on all ranks.  Step (3)
+    blocks inside RCCL until every rank has arrived; it runs in a helper thread and a rank that
+    has waited `timeout` seconds (default I2LQR_COMM_TIMEOUT = 180) gives up and reports that in
+    step (4) — where the other ranks, which are waiting for the same bootstrap, arrive the same
+    way —; every rank then raises CostExchangePoisoned.  No device collective is issued between
+    (1) and (4).  After a successful bring-up the device is synchronised and the ranks pass a
+    host-side barrier, so the first collective of the library's communicator and the next one of
+    torch's are ordered the same way on every rank."""
 
     def __init__(self, solver, group=None, timeout: float | None = None):
         import ctypes as C
@@ -136,13 +169,14 @@ class CostExchange:
         self.world = dist.get_world_size(group) if grouped else 1
         self.rank = dist.get_rank(group) if grouped else 0
         self._group = group
+        hg = self._hgroup = host_group(group)
         # (1) can every rank bind RCCL?
         err = None
         try:
             solver._check(self.lib.i2lqr_comm_available())
         except Exception as e:  # noqa: BLE001
             err = e
-        if not _agree(err is None, solver.device, group):
+        if not _agree([err is None], hg)[0]:
             raise CostExchangeUnavailable(f"RCCL cannot be bound on every rank ({err or 'another rank'})")
         # (2) the unique id, or an empty marker
         uid = C.create_string_buffer(_abi.COMM_ID_BYTES)
@@ -154,21 +188,33 @@ class CostExchange:
             except Exception as e:  # noqa: BLE001
                 err = e
         box = [payload]
-        if grouped and self.world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
+        if hg is not None:
+            dist.broadcast_object_list(box, src=dist.get_process_group_ranks(hg)[0], group=hg)
         if not box[0]:
             raise CostExchangeUnavailable(f"rank 0 could not create the RCCL unique id ({err or 'see rank 0'})")
-        # (3) the bootstrap, (4) agreement on its outcome
+        # (3) the bootstrap, (4) agreement on its outcome (host side)
         comm = C.c_void_p()
         err = self._create(box[0], comm, _bring_up_timeout() if timeout is None else timeout)
-        if not _agree(err is None, solver.device, group):
+        timed_out = isinstance(err, TimeoutError)
+        all_ok, none_timed_out = _agree([err is None, not timed_out], hg)
+        if not all_ok:
             if err is None and comm.value:
-                self.lib.i2lqr_comm_destroy(comm)
+                self.lib.i2lqr_comm_abort(comm)
+            if not none_timed_out:
+                raise CostExchangePoisoned(
+                    f"ncclCommInitRank timed out ({err if timed_out else 'on another rank'})",
+                    here=timed_out)
             raise CostExchangeUnavailable(f"ncclCommInitRank failed ({err or 'on another rank'})")
         self._comm = comm
         w, r = C.c_int32(), C.c_int32()
         solver._check(self.lib.i2lqr_comm_info(self._comm, C.byref(w), C.byref(r)))
         self.comm_world, self.comm_rank = int(w.value), int(r.value)  # what RCCL itself reports
+        # two communicators in this process from here on (torch's and the library's): start them
+        # from a common point on every rank
+        if torch.device(solver.device).type == "cuda":
+            torch.cuda.synchronize(solver.device)
+        if hg is not None:
+            dist.barrier(group=hg)
 
     def _create(self, uid: bytes, comm, timeout: float):
         """i2lqr_comm_create in a helper thread (the device current there too); returns the error

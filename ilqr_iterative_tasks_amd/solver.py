@@ -304,12 +304,38 @@ class BatchedILQR:
                 self._ptr(x_pred, (self.n, self.N + 1), name="x_pred"),
                 self._ptr(u_pred, (self.m, self.N), name="u_pred"), self._stream()))
 
+    def _argmin_workspace(self, B: int) -> C.c_void_p:
+        need = int(self.lib.i2lqr_argmin_workspace_bytes(B))
+        if self._argmin_ws is None or self._argmin_ws.numel() < need:
+            self._argmin_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return C.c_void_p(self._argmin_ws.data_ptr())
+
+    def iterate_pick(self, buf: dict, n_iters: int, qfun, outer_iter: int, max_relax_iter: int = 55,
+                     cost_it=None, pick: bool = True, best=None):
+        """One control round in one call (i2lqr_iterate_pick): iterate(buf, n_iters), then
+        relax_cost on the returned X, then (pick) the flat arg-min — a single launch on the
+        eight-lane kernels, the same three steps as launches elsewhere; outputs bit-identical to
+        the separate calls.  Returns (cost_it, (best_idx int64[1], best_cost[1]) or None);
+        `best`: preallocated (idx, val) pair to write into."""
+        B = self.batch_of(buf["X"])
+        cost_it = self.empty(B) if cost_it is None else cost_it
+        idx = val = None
+        if pick:
+            idx, val = best if best is not None else (self.empty(1, dtype=torch.int64), self.empty(1))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_iterate_pick(
+                self._handle, B, int(n_iters), *self._iter_args(buf, B),
+                self._ptr(qfun, (B,), torch.int32, name="qfun"), int(outer_iter),
+                int(max_relax_iter), self._ptr(cost_it, (B,), name="cost_it"),
+                C.c_void_p(idx.data_ptr()) if pick else C.c_void_p(None),
+                C.c_void_p(val.data_ptr()) if pick else C.c_void_p(None),
+                self._argmin_workspace(B) if pick else C.c_void_p(None), self._stream()))
+        return cost_it, ((idx, val) if pick else None)
+
     def argmin(self, cost_it):
         """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1])."""
         B = cost_it.shape[0]
-        if self._argmin_ws is None:
-            self._argmin_ws = torch.empty(int(self.lib.i2lqr_argmin_workspace_bytes(B)),
-                                          dtype=torch.uint8, device=self.device)
+        self._argmin_workspace(B)
         idx = self.empty(1, dtype=torch.int64)
         val = self.empty(1)
         with torch.cuda.device(self.device):

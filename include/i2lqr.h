@@ -130,6 +130,21 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
 int i2lqr_destroy(i2lqr_handle* h);
 
 /*
+ * Which cfg.layout to create the handle with for batches of B problems (host only, no GPU needed):
+ * the layouts are different kernel FAMILIES — problem-major runs one problem per 64, 16 or 8 lanes
+ * (latency kernels: up to ~10^4 problems), batch-minor / batch-tiled run one problem per lane (the
+ * HBM-bound throughput kernels) — and the crossover is measured, not derivable by a caller:
+ * bicycles from 10240 problems for fixed iteration counts (early_exit 0: i2lqr_iterate) and from
+ * 16384 for solves to termination (early_exit 1: i2lqr_solve); quad12 (fp64) from 8192.
+ * Returns I2LQR_LAYOUT_BATCH_TILED where B is a multiple of 64, I2LQR_LAYOUT_BATCH_MINOR otherwise,
+ * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for configurations the lane kernels do not
+ * run (stage weights Q, R != 0, non-symmetric terminal weights, quad12 in fp32); < 0 on a bad
+ * argument.  cfg->layout itself is not read.  The reference has no counterpart (one NumPy layout).
+ * Inside the problem-major layout the library picks the kernel per call (i2lqr_iterate_kernel).
+ */
+int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit);
+
+/*
  * Scratch in HBM.  Batch-minor / batch-tiled layouts (one problem per lane): candidate inputs, the
  * gains when the caller does not ask for K/k, the work sets of the chunked solve; a call whose
  * batch needs more than the registered size fails with I2LQR_ERR_INVALID.  Problem-major layout,
@@ -332,6 +347,25 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
                  void* best_cost, void* workspace, void* stream);
 
 /*
+ * One control round in one call — i2lqr_iterate followed by i2lqr_relax_cost on the returned X and
+ * (best_idx != NULL) i2lqr_argmin over cost_it, with exactly their outputs, bit for bit.  Replaces
+ * the body of the candidate loops utils/base.py:414-437 plus the flat form of the pick :462-465.
+ * Where the eight-lane kernels run (problem-major layout, the bicycles with Q = R = 0, from 1024
+ * problems) the relaxed cost is formed in the kernel's exit block from the x_N it still holds in
+ * LDS and the pick is a last-workgroup-done reduction of per-wavefront minima inside the same
+ * launch: ONE launch per round instead of four (at 1024 problems the three small launches and
+ * their dependent launch boundaries cost 10 % of the round).  Every other kernel family runs the
+ * three steps as separate launches behind this call.
+ * best_idx NULL: costs only (the sharded path: the all-gather sits between the costs and the
+ * pick); then best_cost and workspace are not read.  `workspace`: i2lqr_argmin_workspace_bytes(B).
+ */
+int i2lqr_iterate_pick(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
+                       const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                       int32_t* iters, int32_t* status, const int32_t* qfun, int32_t outer_iter,
+                       int32_t max_relax_iter, void* cost_it, int64_t* best_idx, void* best_cost,
+                       void* workspace, void* stream);
+
+/*
  * The one collective of the path (multi-GPU): all-gather of the per-candidate
  * terminal costs, one RCCL ncclAllGather over xGMI.  Rank r owns a contiguous shard of n_local
  * candidates; afterwards every rank holds cost_all[world * n_local] in rank order and evaluates
@@ -359,6 +393,9 @@ int i2lqr_comm_available(void);
 int i2lqr_comm_unique_id(void* id);
 int i2lqr_comm_create(const void* id, int32_t world, int32_t rank, void** comm);
 int i2lqr_comm_destroy(void* comm);
+/* ncclCommAbort: frees the communicator WITHOUT the collective teardown ncclCommDestroy performs —
+ * the call for a communicator whose peers did not all come up (a destroy may wait for them). */
+int i2lqr_comm_abort(void* comm);
 int i2lqr_comm_info(void* comm, int32_t* world, int32_t* rank);
 int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, void* cost_all,
                           int64_t n_local, void* stream);

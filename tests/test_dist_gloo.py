@@ -125,7 +125,7 @@ def test_launcher_ends_a_hung_attempt_and_restarts_fresh_ranks_on_the_torch_exch
     processes with --exchange torch; the JSON line tells the story."""
     import json
     out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--exchange-only", "--batch", "64",
-                 "--launch-timeout", "20", env=dict(I2LQR_BENCH_TEST_HANG="native"))
+                 "--launch-timeout", "20", "--test-hooks", env=dict(I2LQR_BENCH_TEST_HANG="native"))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -139,7 +139,7 @@ def test_launcher_ends_a_hung_attempt_and_restarts_fresh_ranks_on_the_torch_exch
 
 def test_launcher_exits_nonzero_when_the_fallback_fails_too():
     out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--exchange-only", "--batch", "64",
-                 "--exchange", "torch", "--launch-timeout", "12",
+                 "--exchange", "torch", "--launch-timeout", "12", "--test-hooks",
                  env=dict(I2LQR_BENCH_TEST_HANG="torch"))
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -148,10 +148,10 @@ def test_launcher_exits_nonzero_when_the_fallback_fails_too():
 # -- bring-up of the native communicator: all ranks fall back together ---------------------------------
 
 class _FakeLib:
-    """The five i2lqr_comm_* entry points with injectable failures (return codes as the C-ABI)."""
+    """The six i2lqr_comm_* entry points with injectable failures (return codes as the C-ABI)."""
 
     def __init__(self, rank, fail):
-        self.rank, self.fail, self.calls, self.destroyed = rank, fail, [], 0
+        self.rank, self.fail, self.calls, self.destroyed, self.aborted = rank, fail, [], 0, 0
 
     def _rc(self, name):
         self.calls.append(name)
@@ -180,6 +180,10 @@ class _FakeLib:
         self.destroyed += 1
         return 0
 
+    def i2lqr_comm_abort(self, comm):
+        self.aborted += 1
+        return 0
+
     def i2lqr_comm_info(self, comm, w, r):
         w._obj.value, r._obj.value = 2, self.rank
         return 0
@@ -203,6 +207,8 @@ def _exchange_worker(rank, world, port, fail, out_dir):
     try:
         ex = idist.CostExchange(_FakeSolver(lib), timeout=3.0)
         assert (ex.comm_world, ex.comm_rank) == (2, rank)
+    except idist.CostExchangePoisoned as e:
+        outcome = f"unavailable: poisoned here={e.here}: " + str(e)
     except idist.CostExchangeUnavailable as e:
         outcome = "unavailable: " + str(e)
     # the ranks are still in step: a collective right after the bring-up completes
@@ -210,7 +216,8 @@ def _exchange_worker(rank, world, port, fail, out_dir):
     dist.all_reduce(t)
     assert float(t.item()) == 1.0
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(f"{outcome}|{','.join(lib.calls)}|{lib.destroyed}|{idist.abandoned_bring_ups()}")
+        f.write(f"{outcome}|{','.join(lib.calls)}|{lib.aborted}|{idist.abandoned_bring_ups()}|"
+                f"{lib.destroyed}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -234,7 +241,22 @@ def test_native_exchange_bring_up_fails_on_all_ranks_or_none(tmp_path, fail, exp
     assert res[0][1].split(",") == expect_calls                     # rank 0 made the id if it got there
     assert res[1][1].split(",") == [c for c in expect_calls if c != "unique_id"]
     if fail.get("create") == 1 or fail.get("create_hangs") == 1:
-        assert res[0][2] == "1"  # rank 0's communicator was created, then destroyed again
+        # rank 0's communicator came up; it is ABORTED (ncclCommAbort), never destroyed: a destroy
+        # may wait for the peer that did not arrive
+        assert (res[0][2], res[0][4]) == ("1", "0")
+    if fail.get("create") == 1:
+        assert not any("poisoned" in o for o in outcomes)
     if fail.get("create_hangs") == 1:  # rank 1 gave up after its timeout and left the thread behind
-        assert "did not return within 3 s" in outcomes[1] or "another rank" in outcomes[1]
+        assert "poisoned here=False" in outcomes[0] and "poisoned here=True" in outcomes[1], outcomes
+        assert "did not return within 3 s" in outcomes[1]
         assert (res[0][3], res[1][3]) == ("0", "1")
+
+
+def test_the_hang_hook_is_inert_without_the_test_flag():
+    """I2LQR_BENCH_TEST_HANG alone (no --test-hooks) must not turn a production run into a hang."""
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--exchange-only", "--batch", "64",
+                 "--launch-timeout", "120", env=dict(I2LQR_BENCH_TEST_HANG="native"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert len(d["launcher"]["attempts"]) == 1 and not d["launcher"]["attempts"][0]["timed_out"]

@@ -35,14 +35,18 @@ def test_bench_json_line_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["traffic_stale"] in (True, False) and (r["traffic"] is None or not r["traffic_stale"])
     ri = d["roofline_issue"]
-    # 1024 problems on the eight-problems-per-wavefront kernel: 128 main wavefronts, one SIMD each
-    # (+ 256 helper wavefronts when the counter file of this library knows about them: their
-    # instructions are in the numerator, so their SIMDs are in the denominator)
-    assert ri["bound"] == "issue" and ri["simds_occupied"] in (128, 384)
+    # 1024 problems on the sixteen-lane form (four problems per wavefront): 256 main wavefronts,
+    # one SIMD each (+ 256 helper wavefronts when the counter file of this library knows about
+    # them: their instructions are in the numerator, so their SIMDs are in the denominator)
+    assert ri["bound"] == "issue" and ri["simds_occupied"] in (256, 512)
     assert abs(ri["peak"] - ri["simds_occupied"] * 2.4 / 4) < 1e-9
     assert r["kernel_ms_samples"] >= 3 and r["kernel_ms_avg"] <= d["ms_per_step"]
     assert r["kernel_ms_min"] <= r["kernel_ms_avg"] <= r["kernel_ms_max"]
-    assert r["kernel"] == "k_group_iterate"
+    assert r["kernel"] == "k_group_iterate (sixteen lanes)"
+    # the control round is ONE launch: iterations, relaxed cost and pick
+    assert d["config"]["launches_per_step"] == 1 and "ONE launch" in d["config"]["step"]
+    assert 0.0 < r["accepted_fraction"] <= 1.0 and r["waves_per_simd"] == 0.25
+    assert r["step_ms_outside_kernel"] >= 0.0
     assert ri["frac"] is None or 0 < ri["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
@@ -67,7 +71,12 @@ def test_bench_under_torchrun_world_of_one_uses_the_native_rccl_exchange():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["exchange"]["nccl_world"] == 1
-    assert "i2lqr_allgather_costs" in d["exchange"]["path"] and d["exchange"]["ms_per_step"] > 0
+    assert d["exchange"]["path"] == "native" and "i2lqr_allgather_costs" in d["exchange"]["what"]
+    assert d["exchange"]["ms_per_step"] > 0
+    # the driver keeps the head of the line: the multi-rank facts come before the long objects
+    head = lines[0][:2000]
+    assert '"exchange"' in head and '"per_rank_iterations_per_s"' in head and '"nccl_world"' in head
+    assert lines[0].index('"exchange"') < lines[0].index('"roofline"') < lines[0].index('"extra"')
     assert d["exchange"]["bytes_per_rank"] == 8192
     assert len(d["per_rank_iterations_per_s"]) == 1
     s4 = d["extra"]["config4_strong"]
@@ -105,7 +114,10 @@ def test_two_ranks_sharing_the_gpu_solve_their_shards_and_fall_back_together():
     assert len(d["per_rank_iterations_per_s"]) == 2
     ex, att = d["exchange"], d["launcher"]["attempts"]
     print("exchange:", ex, "launcher:", d["launcher"])
-    assert "torch.distributed" in ex["path"]
+    assert ex["path"] == "torch" and "torch.distributed" in ex["what"]
+    # two ranks: the contract's 6 steps and the 200-step loop beside them
+    assert d["long_run"]["steps"] == 200 and d["long_run"]["value"] > 1e6
+    assert len(d["long_run"]["per_rank_iterations_per_s"]) == 2
     # either the ranks agreed on the failure inside one attempt, or the launcher restarted them
     assert ("native_exchange_error" in ex and len(att) == 1) or \
         (len(att) == 2 and att[1]["argv"] == ["--exchange", "torch"])

@@ -25,13 +25,15 @@ def torch_mod():
     return torch
 
 
-# problem-major with one problem per wavefront ("wave") or eight problems per wavefront ("group":
-# the automatic choice for the bicycles with Q = R = 0); batch-minor / batch-tiled: one per lane
-LAYOUTS = {"wave": 0, "group": 0, "spec": 0, "lane": 1, "tiled": 2}
-GROUP_LANES = {"wave": 64, "group": 8, "spec": 8}
+# problem-major with one problem per wavefront ("wave"), eight problems per wavefront ("group": the
+# automatic choice for the bicycles with Q = R = 0 above 4096 problems) or four ("row16": sixteen
+# lanes per problem, DPP row broadcasts instead of LDS exchanges; automatic from 1024 to 4096
+# problems); batch-minor / batch-tiled: one per lane
+LAYOUTS = {"wave": 0, "group": 0, "row16": 0, "spec": 0, "lane": 1, "tiled": 2}
+GROUP_LANES = {"wave": 64, "group": 8, "row16": 16, "spec": 8}
 
 
-@pytest.fixture(params=["wave", "group", "spec", "lane"])
+@pytest.fixture(params=["wave", "group", "row16", "spec", "lane"])
 def layout(request):
     return request.param
 
@@ -47,8 +49,8 @@ def pin_kernel(solver, layout):
 
 def make_solver(system, N, dtype="f64", dt=1.0, layout="wave", **over):
     from ilqr_iterative_tasks_amd import BatchedILQR, default_config
-    if layout in ("group", "spec") and system == "quad12":
-        pytest.skip("the eight-lane kernels are built for the m = 2 plants")
+    if layout in ("group", "row16", "spec") and system == "quad12":
+        pytest.skip("the eight-lane kernels and their sixteen-lane DPP form are built for the m = 2 plants")
     if layout == "spec" and N > 20:
         pytest.skip("the speculative kernel's buffers fit the LDS up to N = 20 for the bicycles")
     cfg = default_config(system, N, dtype, dt=dt, layout=LAYOUTS[layout])
@@ -285,7 +287,7 @@ def _fp32_vs_oracle(solver, cfg, buf, ref, counts):
         assert (st == ref["status"]).mean() >= FP32_AGREE
 
 
-@pytest.mark.parametrize("lay", ["wave", "group", "lane", "tiled"])
+@pytest.mark.parametrize("lay", ["wave", "group", "row16", "lane", "tiled"])
 def test_fp32_tracks_fp64_oracle(torch_mod, lay):
     """BASELINE configs[2] (n=6, m=2, N=20, fp32) inputs: one backward pass, 10 fused iterations
     and the solve to termination in fp32 against the fp64 oracle, tolerances above."""
@@ -335,6 +337,48 @@ def test_relax_cost_and_argmin_vs_oracle(torch_mod, layout):
         assert float(val.item()) == float(np.min(want))
 
 
+@pytest.mark.parametrize("B", [1, 7, 1027, 4099, 8200])
+def test_iterate_pick_equals_iterate_relax_argmin(torch_mod, layout, B):
+    """i2lqr_iterate_pick — one launch on the eight- / sixteen-lane kernels (relaxed cost in the
+    kernel's exit block, pick by a last-workgroup-done reduction), the three steps as launches on
+    the other families — against i2lqr_iterate + i2lqr_relax_cost + i2lqr_argmin and the oracle's
+    relaxed cost (utils/base.py:427-437, :462-465): every output bit for bit, empty slots
+    (I2LQR_QF_NONE) and non-finite candidates included, repeated launches (the ticket word of the
+    reduction resets itself), costs without the pick."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    orc = oracle()
+    solver, cfg = make_solver("bicycle4", 6, layout=layout)
+    host = workloads.make_batch(cfg, B)
+    rng = np.random.default_rng(B)
+    qfun = rng.integers(0, 120, B).astype(np.int32)
+    qfun[rng.integers(0, B, max(1, B // 9))] = 0x7FFFFFFF
+    if B > 5:
+        host["x_term"][5, 0] = np.nan
+    q = to_dev(solver, qfun)
+    for outer in (0, 1, 2, 0):
+        a = solver.iterate(dev_batch(solver, host), 4)
+        cost_a = solver.relax_cost(a["X"], a["x_term"], q, outer)
+        idx_a, val_a = solver.argmin(cost_a)
+        b = dev_batch(solver, host)
+        cost_b, (idx_b, val_b) = solver.iterate_pick(b, 4, q, outer)
+        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):  # (NaN == NaN here)
+            assert torch.equal(a[key].isnan(), b[key].isnan()), (key, outer)
+            assert torch.equal(a[key].nan_to_num(7.0), b[key].nan_to_num(7.0)), (key, outer)
+        assert torch.equal(cost_a.isnan(), cost_b.isnan())
+        assert torch.equal(cost_a.nan_to_num(-1.0), cost_b.nan_to_num(-1.0)), outer
+        assert int(idx_a.item()) == int(idx_b.item()) and float(val_a.item()) == float(val_b.item())
+        want = orc.relax_cost_batch(cfg, to_host(solver, a["X"]), host["x_term"], qfun, outer)
+        want[qfun == 0x7FFFFFFF] = np.inf  # empty candidate slots (a concept of this build)
+        np.testing.assert_array_equal(cost_b.cpu().numpy(), want)
+        assert int(idx_b.item()) == int(np.argmin(want))
+        c = dev_batch(solver, host)
+        cost_c, none = solver.iterate_pick(c, 4, q, outer, pick=False)
+        assert none is None and torch.equal(cost_c.nan_to_num(-1.0), cost_b.nan_to_num(-1.0))
+    if B >= 1024 and layout in ("group", "row16"):
+        assert solver.iterate_kernel(B).startswith("k_group_iterate")
+
+
 # ------------------------------------------------------------------------------------------------
 # (c) size-independent properties at full batch sizes, edge cases
 # ------------------------------------------------------------------------------------------------
@@ -366,7 +410,8 @@ def test_properties_full_size(torch_mod, dtype, B, layout):
     assert (solver.to_problem_major(a["U"]).abs() <= u_max[None, :, None]).all()
 
 
-@pytest.mark.parametrize("lay,B", [("wave", 131072), ("group", 131072), ("lane", 131072),
+@pytest.mark.parametrize("lay,B", [("wave", 131072), ("group", 131072), ("row16", 131072),
+                                   ("lane", 131072),
                                    ("tiled", 131072), ("lane", 1 << 20), ("tiled", 1 << 20)])
 def test_config4_sizes_properties_and_oracle_sample(torch_mod, lay, B):
     """BASELINE configs[3]: 2^20 problems over 8 GPUs = 131072 per GPU, and the whole 2^20 on one
@@ -644,7 +689,7 @@ def test_edge_cases(torch_mod, layout):
     assert int(b4["status"][2]) == 4 and (b4["status"].cpu().numpy()[[0, 1, 3]] != 4).all()
     # horizon limits: N = 1 and N = 64 (I2LQR_MAX_HORIZON; the eight problem slices of the
     # eight-lane kernel fit the LDS up to N = 50 for this plant)
-    for N in (1, {"group": 50, "spec": 20}.get(layout, 64)):
+    for N in (1, {"group": 50, "spec": 20}.get(layout, 64)):  # (four slices of "row16" fit at 64)
         s2, c2 = make_solver("bicycle4", N, layout=layout)
         h = workloads.make_batch(c2, 33)
         ref = orc.ilqr_batch(c2, h["X"], h["U"], h["x_term"], h["lamb"], h["obs"], max_iter=5,
@@ -686,10 +731,14 @@ def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
         host["lamb"] = 10.0 ** np.random.default_rng(5).integers(-3, 3, B).astype(float)
         out = {}
         solver.set_option("speculate", 0)
-        for lanes in (64, 8, -1):
+        for lanes in (64, 8, 16, -1):
             solver.set_option("group_lanes", lanes)
             out[lanes] = (solver.iterate(dev_batch(solver, host), 7), solver.solve(dev_batch(solver, host)))
-        auto = 8 if B >= 1024 else 64  # the automatic choice: eight lanes from 1024 problems
+        # the automatic choice: sixteen lanes per problem from 1024 to 4096 problems
+        auto = 16 if B >= 1024 else 64
+        if B >= 1024:
+            assert solver.iterate_kernel(B) == "k_group_iterate (sixteen lanes)"
+            assert solver.iterate_kernel(4097) == "k_group_iterate"
         for a, b in zip(out[auto], out[-1]):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, key)
@@ -715,14 +764,17 @@ def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, key, nit)
         solver.set_option("speculate", 0)
-        for a, b in zip(out[8], out[64]):
-            same = (a["iters"] == b["iters"]) & (a["lamb"] == b["lamb"])
-            assert float(same.double().mean()) >= 0.99, system
-            assert torch.equal(a["status"][same], b["status"][same])
-            sm = same.cpu().numpy()
-            for key in ("X", "U"):
-                assert batch_rel_err(to_host(solver, a[key])[sm], to_host(solver, b[key])[sm],
-                                     floor=1e-2) < TOL_SOLVE, (system, key)
+        # eight lanes and sixteen lanes (Qux by the symmetry of Vxx, no gain exchange) against one
+        # problem per wavefront: round-off apart
+        for lanes in (8, 16):
+            for a, b in zip(out[lanes], out[64]):
+                same = (a["iters"] == b["iters"]) & (a["lamb"] == b["lamb"])
+                assert float(same.double().mean()) >= 0.99, (system, lanes)
+                assert torch.equal(a["status"][same], b["status"][same])
+                sm = same.cpu().numpy()
+                for key in ("X", "U"):
+                    assert batch_rel_err(to_host(solver, a[key])[sm], to_host(solver, b[key])[sm],
+                                         floor=1e-2) < TOL_SOLVE, (system, key, lanes)
     # stage weights: the automatic choice falls back, forcing is an error
     cfg = default_config("bicycle4", 6)
     cfg.set_matrix("R", np.diag([0.05, 0.05]))
@@ -813,7 +865,7 @@ def test_solves_to_termination_speculate_automatically(torch_mod):
         host = workloads.make_batch(cfg, B)
         auto = BatchedILQR(cfg)
         assert auto.solve_kernel(B) == "k_group_spec"
-        assert auto.iterate_kernel(B) == ("k_group_iterate" if B >= 1024 else "k_iterate")
+        assert auto.iterate_kernel(B) == ("k_group_iterate (sixteen lanes)" if B >= 1024 else "k_iterate")
         plain = BatchedILQR(cfg)
         plain.set_option("group_lanes", 8)
         plain.set_option("speculate", 0)
@@ -1019,9 +1071,9 @@ def test_nonzero_stage_weights_vs_oracle(torch_mod, layout):
     (nominal cost measured to xtarget, forward cost to x_terminal: iterative_ilqr.py:43 vs :151)."""
     from ilqr_iterative_tasks_amd import workloads
     orc = oracle()
-    if layout in ("group", "spec"):
-        pytest.skip("the eight-lane kernel is built for Q = R = 0 (other weights take the "
-                    "one-problem-per-wavefront kernel automatically)")
+    if layout in ("group", "row16", "spec"):
+        pytest.skip("the eight- / sixteen-lane kernels are built for Q = R = 0 (other weights take "
+                    "the one-problem-per-wavefront kernel automatically)")
     solver, cfg = make_solver("bicycle4", 6, layout=layout)
     cfg.set_matrix("Q", np.diag([0.01, 0.02, 0.1, 0.05]) + 0.001)
     cfg.set_matrix("R", np.array([[0.05, 0.01], [0.01, 0.08]]))
@@ -1197,7 +1249,8 @@ def test_eight_lane_workspace_form_is_bit_identical(torch_mod):
     assert auto.iterate_kernel(8192) == "k_group_iterate"  # no workspace registered yet
     auto.ensure_workspace(8192)
     assert auto.iterate_kernel(8192) == "k_group_iterate (workspace form)"
-    assert auto.iterate_kernel(4096) == "k_group_iterate"
+    assert auto.iterate_kernel(4096) == "k_group_iterate (sixteen lanes)"
+    assert auto.iterate_kernel(4097) == "k_group_iterate (workspace form)"
 
 
 def test_inputs_outside_the_benchmark_distribution_vs_oracle(torch_mod, layout):

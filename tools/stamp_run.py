@@ -26,7 +26,7 @@ for key in ("X", "U", "x_term", "lamb"):
     buf[key].copy_(torch.as_tensor(host[key]).to(solver.device, solver.dtype))
 buf["obs"] = torch.as_tensor(host["obs"]).to(solver.device, solver.dtype)
 dbg = torch.zeros(B, 8, dtype=torch.int64, device=solver.device)
-if lanes == 16:  # the sixteen-lane kernel keeps its real workspace: debug buffer through the env
+if lanes == 16 and cfg.system_id == 2:  # quad12's sixteen-lane kernel keeps its real workspace: debug buffer through the env
     import os
     os.environ["I2LQR_DBG_PTR"] = str(dbg.data_ptr())
     solver.ensure_workspace(B)
@@ -39,7 +39,7 @@ d = dbg.double().mean(0).cpu().numpy() / iters
 names = (["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd refreshF+sync", "forward", "-"]
          if lanes == 64 else ["record phase", "bwd P1 + T1 exchange", "forward", "accept + adopt", "bwd P2 (H column)",
           "bwd record fetch, Quu, inverse, gain column", "bwd gain exchange + value update", "rollout at entry + stores at exit (per launch / iters)"]
-         if lanes == 16 else
+         if lanes == 16 and cfg.system_id == 2 else
          ["prep", "bwd P1 + T1 exchange", "bwd P2 (H column)", "bwd Quu + inverse",
           "bwd gains + exchange", "bwd value update", "forward", "-"])
 tot = d.sum()
