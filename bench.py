@@ -492,6 +492,37 @@ def time_launches(args, cfg, B, torch, iters, launches=EXTRA_LAUNCHES, warmup=EX
             "iterations_per_s": B * iters / (st["median"] * 1e-3)}
 
 
+def time_candidate_round(args, B, torch, rounds=20, warmup=3):
+    """Wall time of whole control rounds through control.iterative_ilqr.HipCandidateSolver (events
+    around `rounds` consecutive calls; inputs resident on the device)."""
+    import numpy as np
+    from ilqr_iterative_tasks_amd import workloads
+    from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+    cfg = workloads.config_for(args.workload, "f64")
+    host = workloads.make_batch(cfg, B)
+    x0 = torch.as_tensor(host["X"][0, :, 0]).cuda()
+    x_terms = torch.as_tensor(host["x_term"]).cuda()
+    qfun = torch.zeros(B, dtype=torch.int32, device="cuda")
+    hs = HipCandidateSolver(device=torch.device("cuda", torch.cuda.current_device()))
+    obs = (31.0, -3.0, 8.0, 6.0, 0.0, 0.0)
+    for _ in range(warmup):
+        out = hs.candidate_round(cfg, x0, x_terms, qfun, 1.0, obs_rec=obs, n_iters=args.iters)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        out = hs.candidate_round(cfg, x0, x_terms, qfun, 1.0, obs_rec=obs, n_iters=args.iters)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / rounds
+    s = out["solver"]
+    return {"iterations_per_s": B * args.iters / (ms * 1e-3), "ms_per_round": ms, "batch": B,
+            "kernel": s.iterate_kernel(B), "layout": LAYOUT_NAME[{0: "wave", 1: "lane", 2: "tiled"}[s.cfg.layout]],
+            "entry": "control.iterative_ilqr.HipCandidateSolver.candidate_round (device tensors in, "
+                     "cost_it / pick / winner's U, X out; layout chosen by i2lqr_recommended_layout)",
+            "round": "initial state in the chosen layout + i2lqr_iterate_pick + winner gather"}
+
+
 def roofline_entry(cfg, B, iters, r, traffic):
     """HBM (and fp64) fractions of one timed workload from its median kernel time."""
     from ilqr_iterative_tasks_amd import workloads
@@ -893,6 +924,11 @@ def run_rank(args) -> int:
         q["note"] = ("flops in the reference's dense form (SURVEY.md 8d); the kernel executes about "
                      "40 % of them: the sparsity of [A | B] is folded into the instruction stream")
         extra["config5_quad12_B65536_f64"] = q
+        # the product surface: HipCandidateSolver.candidate_round — 65536 candidates of one control
+        # round handed over as device tensors (x0, x_term[B, n], qfun[B]); the library picks the
+        # layout (i2lqr_recommended_layout), the round stays on the device: initial state written
+        # in that layout, 10 fused iterations, relaxed costs, flat pick, the winner's trajectory
+        extra["candidate_round_B65536_f64"] = time_candidate_round(args, 65536, torch)
         # solve to termination (reference exits: 1..150 iterations per problem): executed
         # iterations per second — lanes that finish early idle until their wavefront's slowest
         # problem is done, so this is below the fixed-count rate.  Default = chunked solve with

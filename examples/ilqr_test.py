@@ -13,6 +13,16 @@ Scenarios: static_obstacle (default, (31,-3,8,6)), no_obstacle, static_obstacle_
 (35,-16,34,34) spd 1 / left: (50,-1,35,35) spd 0.2, present during lap 5 only).
 `--lamb-mode chained` reproduces the reference's lap lengths exactly; `independent` batches every
 round into one launch; `--device-rounds` keeps the three rounds of a control step on the GPU.
+
+Multi-GPU (the sharded calc_input: every rank drives the same loop and solves its shard of each
+round's candidates; one all-gather of the costs and one hand-off of the winner per round):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29511 examples/ilqr_test.py --sharded --lap-number 3
+
+Every rank prints one JSON line (laps, a digest of the applied inputs, the exchange path); the
+lines must agree.  I2LQR_SHARE_GPU=1 (single-GPU boxes): the ranks share the visible devices and
+the process group runs on gloo.
 """
 import argparse
 import sys
@@ -37,7 +47,29 @@ def main():
     ap.add_argument("--lamb-mode", default="chained", choices=["chained", "independent"])
     ap.add_argument("--device-rounds", action="store_true")
     ap.add_argument("--save-trajectory", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="under torchrun: shard every round's candidates over the ranks")
     args = ap.parse_args()
+
+    rounds, solver, rank, exchange_path = None, None, 0, None
+    if args.sharded:
+        import os
+        import torch
+        from ilqr_iterative_tasks_amd import BatchedILQR, default_config, dist as idist
+        from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+        share = os.environ.get("I2LQR_SHARE_GPU") == "1"
+        rank, world, local = idist.init_from_env("gloo" if share else "nccl")
+        dev = f"cuda:{local % max(1, torch.cuda.device_count())}"
+        torch.cuda.set_device(dev)
+        solver = HipCandidateSolver(device=dev)
+        native = None
+        try:  # RCCL through the C-ABI where it comes up (it refuses two ranks on one device)
+            native = idist.CostExchange(BatchedILQR(default_config("bicycle4", 6), dev))
+        except idist.CostExchangeUnavailable:
+            pass
+        rounds = idist.ShardedRound(native=native)
+        exchange_path = "native" if native is not None else "torch"
+        args.lamb_mode = "independent"
 
     dt = 1
     ego = harness.KineticBicycle(system_param=KineticBicycleParam())
@@ -49,9 +81,9 @@ def main():
                 "static_obstacle_big": Obstacle(100, -5, 20, 40)}.get(args.scenario)
     param = iLqrParam(num_ss_points=args.num_ss_points, num_ss_iter=args.num_ss_iters, timestep=dt,
                       num_horizon=6)
-    ctrl = iLqr(param, obstacle=obstacle, system_param=KineticBicycleParam(),
+    ctrl = iLqr(param, obstacle=obstacle, system_param=KineticBicycleParam(), solver=solver,
                 lamb_mode="independent" if args.device_rounds else args.lamb_mode,
-                device_rounds=args.device_rounds)
+                device_rounds=args.device_rounds, sharded=rounds)
     ctrl.add_trajectory(ego.xcl, ego.ucl)
     ctrl.set_timestep(dt)
     ego.set_ctrl_policy(ctrl)
@@ -68,7 +100,24 @@ def main():
             if it == 6:
                 c.obstacle = None
 
+    applied, calc = [], ctrl.calc_input
+
+    def spy():
+        calc()
+        applied.append(np.array(ctrl.u, float))
+
+    ctrl.calc_input = spy
     laps = harness.run_laps(ego, ctrl, args.lap_number, on_lap=on_lap)
+    if args.sharded:
+        import hashlib
+        import json
+        import torch.distributed as dist
+        print(json.dumps({"rank": rank, "laps": [int(v) for v in laps], "control_steps": len(applied),
+                          "inputs_sha256": hashlib.sha256(np.array(applied).tobytes()).hexdigest(),
+                          "exchange": exchange_path, "exchanges": rounds.collectives}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     print("time at iteration 0 is", laps[0] * dt, " s")
     for lap, steps in enumerate(laps[1:], 1):
         print("time at iteration ", lap, " is ", steps * dt, " s")

@@ -172,6 +172,7 @@ EXPORTS = {
     "i2lqr_comm_abort": (C.c_int, [_P]),
     "i2lqr_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "i2lqr_allgather_costs": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
+    "i2lqr_broadcast_winner": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
 }
 
 _lib = None

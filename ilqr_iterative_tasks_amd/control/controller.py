@@ -13,6 +13,15 @@ batched solves on the GPU.  Two regularisation modes:
                            all (lap, candidate) pairs — the form that shards across GPUs
                            (documented deviation; config-1 laps 121/54/28/23
                            instead of 121/54/29/23).
+
+sharded=ShardedRound(...)  (lamb_mode="independent") the multi-GPU calc_input: every rank runs the
+                           same controller on the same state; in each of the three rounds a rank
+                           solves only its contiguous shard of the round's candidates, the ranks
+                           all-gather the relaxed costs (the ONE collective of the solve path), every
+                           rank evaluates the reference's list-of-lists pick on the full vector, and
+                           the rank that solved the winner hands its (U, X) to the others — the
+                           next round's select_close_ss starts from that x_N on every rank
+                           (utils/base.py:384-478 with the loops :391-455 sharded).
 """
 from __future__ import annotations
 
@@ -66,9 +75,14 @@ class iLqr(ControlBase):
     part of the i2LQR path and is not kept."""
 
     def __init__(self, ilqr_param, obstacle=None, system_param=None, solver=None,
-                 lamb_mode="chained", verbose=False, device_rounds=False):
+                 lamb_mode="chained", verbose=False, device_rounds=False, sharded=None):
         ControlBase.__init__(self)
         assert lamb_mode in ("chained", "independent")
+        # sharded: a dist.ShardedRound (the exchanges of a sharded round); candidates of one lap
+        # cannot chain their lamb across ranks
+        assert sharded is None or (lamb_mode == "independent" and not device_rounds)
+        self.sharded = sharded
+        self._shard = None  # (offsets, total, lo, U_local, X_local) of the round being picked
         # device_rounds: run the three outer rounds (select / solve / relaxed cost / pick) on the
         # GPU with one read-back per control step (control/device_round.py; independent lamb)
         assert not device_rounds or lamb_mode == "independent"
@@ -87,6 +101,7 @@ class iLqr(ControlBase):
         self.x_pred = self.u_pred = self.u_old = None
         self.x_guess = self.x_terminal_guess = None
         self.last_round = None  # diagnostics of the most recent calc_input (tests)
+        self.last_round_info = None  # device rounds: {"graph": replayed?, "graph_error": ...}
 
     # -- safe set ---------------------------------------------------------------------------
     def select_close_ss(self, iter, x0):
@@ -142,6 +157,8 @@ class iLqr(ControlBase):
         width = max(len(idx) for _, idx in candidates)
         U = [[None] * len(idx) for _, idx in candidates]
         X = [[None] * len(idx) for _, idx in candidates]
+        if self.lamb_mode == "independent" and self.sharded is not None:
+            return self._solve_sharded(cfg, solver, x0, candidates, obs, outer_iter, N)
         if self.lamb_mode == "independent":
             x_terms = np.stack([self.ss[lap][:, j] for lap, idx in candidates for j in idx])
             out = solver.solve(cfg, x0, x_terms, np.full(len(x_terms), float(p.lamb)), obs)
@@ -164,6 +181,45 @@ class iLqr(ControlBase):
                  for c, j in enumerate(idx)] for a, (lap, idx) in enumerate(candidates)]
         return cost, U, X
 
+    def _solve_sharded(self, cfg, solver, x0, candidates, obs, outer_iter, N):
+        """One sharded round: this rank solves candidates [lo, hi) of the round's flat candidate
+        list (laps in order, each lap's nearest-first points), computes their relaxed costs, and
+        the ranks all-gather them (dist.ShardedRound.gather_costs).  Returns the FULL cost lists —
+        the pick is evaluated on every rank — and (U, X) lists that hold entries for the local
+        shard only; calc_input fetches the winner's through _winner()."""
+        p = self.ilqr_param
+        flat = [(lap, j) for lap, idx in candidates for j in idx]
+        total = len(flat)
+        lo, hi = self.sharded.shard(total)
+        U_loc, X_loc, cost_loc = [], [], np.zeros(hi - lo)
+        if hi > lo:
+            x_terms = np.stack([self.ss[lap][:, j] for lap, j in flat[lo:hi]])
+            out = solver.solve(cfg, x0, x_terms, np.full(hi - lo, float(p.lamb)), obs)
+            U_loc, X_loc = list(out["U"]), list(out["X"])
+            cost_loc = np.array([self._relax_cost(X_loc[q][:, -1], self.ss[lap][:, j],
+                                                  self.Qfun[lap][j], outer_iter, N)
+                                 for q, (lap, j) in enumerate(flat[lo:hi])], float)
+        cost_all = self.sharded.gather_costs(cost_loc, total)
+        offsets = np.cumsum([0] + [len(idx) for _, idx in candidates])
+        cost = [[float(v) for v in cost_all[offsets[a]:offsets[a + 1]]]
+                for a in range(len(candidates))]
+        U = [[None] * len(idx) for _, idx in candidates]
+        X = [[None] * len(idx) for _, idx in candidates]
+        for q in range(hi - lo):
+            a = int(np.searchsorted(offsets, lo + q, side="right") - 1)
+            U[a][lo + q - offsets[a]], X[a][lo + q - offsets[a]] = U_loc[q], X_loc[q]
+        self._shard = (offsets, total, U_loc, X_loc, (cfg.m, N), (cfg.n, N + 1))
+        return cost, U, X
+
+    def _winner(self, a, c, u_pred, x_pred):
+        """(U, X) of the picked candidate (lap position a, candidate position c): local lists
+        unless the round was sharded — then the owner's hand-off (dist.ShardedRound.winner)."""
+        if self._shard is None:
+            return u_pred[a][c], x_pred[a][c]
+        offsets, total, U_loc, X_loc, us, xs = self._shard
+        self._shard = None
+        return self.sharded.winner(int(offsets[a]) + c, total, U_loc, X_loc, (us, xs))
+
     def _device_rounds_ok(self, min_iter):
         from .device_round import DeviceRounds
         if self._rounds is None:
@@ -185,6 +241,7 @@ class iLqr(ControlBase):
         elif self.device_rounds and self.num_horizon > 1 and self._device_rounds_ok(min_iter):
             laps = list(range(min_iter, self.iter))
             self.u_pred, self.x_pred, (best_loc, best_time), idx = self._rounds.run(self, laps)
+            self.last_round_info = self._rounds.info  # captured graph or eager (and why)
             self.u = self.u_pred[:, 0]
             self.x_terminal_guess = self.x_pred[:, -1]
             self.u_old = self.u_pred[:, 1:]
@@ -223,8 +280,7 @@ class iLqr(ControlBase):
                 cost_vec = cost_list[best_iter_loc_ss]
                 best_time = cost_vec.index(min(cost_vec))
                 best_iter = best_iter_loc_ss + min_iter
-                self.u_pred = u_pred[best_iter_loc_ss][best_time]
-                self.x_pred = x_pred[best_iter_loc_ss][best_time]
+                self.u_pred, self.x_pred = self._winner(best_iter_loc_ss, best_time, u_pred, x_pred)
                 self.u = self.u_pred[:, 0]
                 self.x_terminal_guess = self.x_pred[:, -1]
                 if self.num_horizon > 1:

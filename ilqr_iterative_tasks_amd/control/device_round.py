@@ -25,6 +25,7 @@ class DeviceRounds:
         self._solvers = {}
         self._ss_key = None
         self._plans = {}
+        self.info = None  # how the last run() executed: {"graph", "graph_requested", "graph_error"}
 
     def _solver(self, cfg) -> BatchedILQR:
         import ctypes as C
@@ -103,16 +104,20 @@ class DeviceRounds:
                                  pl["x_pred"], pl["u_pred"])
 
         pl["launches"] = launches
+        pl["graph_error"] = None
         if self.use_graph:
+            launches()  # warm-up outside capture: an error of the launches themselves propagates
+            torch.cuda.synchronize(self.device)
             try:
-                launches()  # warm-up outside capture
-                torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     launches()
                 pl["graph"] = g
-            except Exception:  # capture not possible: stay eager
-                pl["graph"] = None
+            except RuntimeError as e:
+                # HIP / torch refused the capture (both report it as RuntimeError; I2lqrError is
+                # one): the rounds run eagerly and say so (self.info, iLqr.last_round_info) — a
+                # capture regression is a visible state, not a silent latency change
+                pl["graph"], pl["graph_error"] = None, f"{type(e).__name__}: {e}"
                 torch.cuda.synchronize(self.device)
         self._plans[key] = pl
         return pl
@@ -136,5 +141,7 @@ class DeviceRounds:
             pl["graph"].replay()
         else:
             pl["launches"]()
+        self.info = {"graph": pl["graph"] is not None, "graph_requested": self.use_graph,
+                     "graph_error": pl["graph_error"]}
         return (pl["u_pred"].double().cpu().numpy(), pl["x_pred"].double().cpu().numpy(),
                 tuple(int(v) for v in pl["best"].cpu().numpy()), pl["idx"].cpu().numpy())

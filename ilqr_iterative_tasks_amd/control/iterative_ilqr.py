@@ -24,20 +24,68 @@ class HipCandidateSolver:
         self.dtype = dtype
         self._solvers = {}
 
-    def _solver(self, cfg):
+    def _solver(self, cfg, B=None, early_exit=True):
+        """The handle for this configuration; with B given, in the layout the LIBRARY recommends
+        for batches of that size (i2lqr_recommended_layout): a caller who hands 65536 candidates
+        to solve() gets the one-problem-per-lane kernels without knowing that they exist."""
         from ..solver import BatchedILQR
+        if B is not None:
+            lay = BatchedILQR.recommended_layout(cfg, B, early_exit)
+            if lay != cfg.layout:
+                cfg = cfg.copy()
+                cfg.layout = lay
         key = bytes(C.string_at(C.byref(cfg), C.sizeof(cfg)))
         if key not in self._solvers:
             self._solvers[key] = BatchedILQR(cfg, self.device)
         return self._solvers[key]
 
+    def candidate_round(self, cfg, x0, x_terms, qfun, lamb0, obs_rec=None, n_iters=None,
+                        outer_iter=0, max_relax_iter=55):
+        """One control round on DEVICE tensors, for any number of candidates: the body of the
+        candidate loops utils/base.py:403-437 and the flat pick :462-465 without a host round trip.
+        x0[n] (shared by the candidates), x_terms[B, n], qfun[B] (int32) are device tensors;
+        n_iters None: solve to termination (i2lqr_solve), else that many fused iterations.
+        Returns device tensors: cost_it[B], best_idx[1] (int64), best_cost[1] and the winner's
+        U[m, N], X[n, N+1]; `solver` / `buf` (the layout the library chose and the full batch in
+        it) ride along for callers that want more than the winner."""
+        import torch
+        B = int(x_terms.shape[0])
+        solver = self._solver(cfg, B, early_exit=n_iters is None)
+        key = (id(solver), B)
+        if not hasattr(self, "_round_bufs"):
+            self._round_bufs = {}
+        if key not in self._round_bufs:
+            if len(self._round_bufs) > 8:
+                self._round_bufs.clear()
+            self._round_bufs[key] = (solver.alloc(B, want_gains=False),
+                                     torch.zeros(B, dtype=solver.dtype, device=solver.device))
+        buf, cost_it = self._round_bufs[key]
+        solver.set_initial_state(buf, x0, lamb0)
+        buf["x_term"].copy_(solver.to_native(x_terms.to(solver.device, solver.dtype)))
+        if obs_rec is not None:
+            rec = torch.as_tensor(np.asarray(obs_rec, float)).to(solver.device, solver.dtype)
+            buf["obs"] = solver.to_native(rec[None, :].expand(B, -1).contiguous())
+        else:
+            buf["obs"] = None
+        qfun = qfun.to(solver.device, torch.int32)
+        if n_iters is None:
+            solver.solve(buf)
+            solver.relax_cost(buf["X"], buf["x_term"], qfun, outer_iter, max_relax_iter, cost_it)
+            idx, val = solver.argmin(cost_it)
+        else:
+            _, (idx, val) = solver.iterate_pick(buf, int(n_iters), qfun, outer_iter, max_relax_iter,
+                                                cost_it)
+        win = solver.problem(buf, idx)
+        return dict(cost_it=cost_it, best_idx=idx, best_cost=val, U=win["U"], X=win["X"],
+                    solver=solver, buf=buf)
+
     def solve(self, cfg, x0, x_terms, lamb0, obs_rec, U0=None):
         """x0[n] (shared) or [B,n]; x_terms[B,n]; lamb0[B]; obs_rec[6] (shared) or None.
         Returns dict(U[B,m,N], X[B,n,N+1], lamb[B], iters[B], status[B], cost[B]) on the host."""
         import torch
-        solver = self._solver(cfg)
         x_terms = np.atleast_2d(np.asarray(x_terms, float))
         B = x_terms.shape[0]
+        solver = self._solver(cfg, B, early_exit=True)
         buf = solver.alloc(B, want_gains=False)
         X = np.zeros((B, cfg.n, cfg.N + 1))
         X[:, :, 0] = np.asarray(x0, float)

@@ -957,6 +957,8 @@ struct RcclApi {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t,
+                            hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
   char why[256] = "";  // the loader's message, captured once (dlerror() is cleared by reading it)
@@ -983,9 +985,10 @@ const RcclApi& rccl_api() {
     a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
     a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
     a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommAbort && a.CommCount &&
-           a.CommUserRank && a.AllGather && a.GetErrorString;
+           a.CommUserRank && a.AllGather && a.Broadcast && a.GetErrorString;
     if (!a.ok) snprintf(a.why, sizeof(a.why), "the loaded librccl lacks a symbol this library binds");
     return a;
   }();
@@ -1583,6 +1586,21 @@ int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, v
   if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
   const ncclDataType_t dt = h->cfg.dtype == I2LQR_F64 ? ncclDouble : ncclFloat;
   RCCL_TRY(api, api.AllGather(cost_local, cost_all, (size_t)n_local, dt, (ncclComm_t)comm,
+                              (hipStream_t)stream));
+  return I2LQR_OK;
+}
+
+int i2lqr_broadcast_winner(i2lqr_handle* h, void* comm, void* buf, int64_t count, int32_t root,
+                           void* stream) {
+  if (int rc = check_common(h, count)) return rc;
+  if (!comm) return fail(I2LQR_ERR_INVALID, "null communicator");
+  if (root < 0) return fail(I2LQR_ERR_INVALID, "negative root rank");
+  if (count == 0) return I2LQR_OK;
+  if (!buf) return fail(I2LQR_ERR_INVALID, "null buffer");
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  const ncclDataType_t dt = h->cfg.dtype == I2LQR_F64 ? ncclDouble : ncclFloat;
+  RCCL_TRY(api, api.Broadcast(buf, buf, (size_t)count, dt, root, (ncclComm_t)comm,
                               (hipStream_t)stream));
   return I2LQR_OK;
 }

@@ -278,6 +278,18 @@ class CostExchange:
                 C.c_void_p(out.data_ptr()), n, self.solver._stream()))
         return out
 
+    def broadcast(self, buf: torch.Tensor, root: int) -> torch.Tensor:
+        """The winner's hand-off (i2lqr_broadcast_winner: one ncclBroadcast, in place): `buf` on rank
+        `root` reaches every rank's `buf` (same shape and dtype everywhere), on the current stream."""
+        import ctypes as C
+        if not buf.is_contiguous() or buf.dtype != self.solver.dtype:
+            raise ValueError(f"broadcast buffer must be a contiguous {self.solver.dtype} tensor")
+        with _device_ctx(self.solver.device):
+            self.solver._check(self.lib.i2lqr_broadcast_winner(
+                self.solver._handle, self._comm, C.c_void_p(buf.data_ptr()), buf.numel(), int(root),
+                self.solver._stream()))
+        return buf
+
     def close(self):
         if getattr(self, "_comm", None) is not None and self._comm.value:
             if torch.device(self.solver.device).type == "cuda":
@@ -314,3 +326,85 @@ def select_best_lexicographic(cost_rows: list[list[float]]) -> tuple[int, int]:
     best_lap = cost_rows.index(min(cost_rows))
     row = cost_rows[best_lap]
     return best_lap, row.index(min(row))
+
+
+def owner_of(index: int, total: int, world: int) -> tuple[int, int]:
+    """(rank, local index) of candidate `index` under shard_range's contiguous split."""
+    if not 0 <= index < total:
+        raise ValueError(f"candidate {index} outside [0, {total})")
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        if lo <= index < hi:
+            return r, index - lo
+    raise AssertionError("shard_range does not cover the batch")
+
+
+class ShardedRound:
+    """The two exchanges of ONE sharded control round (utils/base.py:391-471): every
+    rank solves its contiguous shard of the candidates, then
+      gather_costs()  the all-gather of cost_it — afterwards every rank evaluates the pick
+                      (utils/base.py:462-465) on the same full vector —, and
+      winner()        the hand-off of the winner's (U, X) from the rank that solved it: the
+                      reference goes on with that trajectory (u_pred[:, 0] is applied,
+                      x_pred[:, -1] seeds the next round: utils/base.py:466-471).  ONE broadcast of
+                      m N + n (N + 1) numbers from the owner; re-solving the winner on every rank
+                      instead would cost a whole solve per round.
+    `native`: a CostExchange (RCCL through the C-ABI: i2lqr_allgather_costs,
+    i2lqr_broadcast_winner; host arrays are staged through the solver's device); otherwise
+    torch.distributed on the process group (gloo in the CPU tests, host tensors).  Without a
+    process group this is a world of one and both calls return their inputs."""
+
+    def __init__(self, group=None, native: "CostExchange | None" = None):
+        self.group, self.native = group, native
+        grouped = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if grouped else 1
+        self.rank = dist.get_rank(group) if grouped else 0
+        self.collectives = 0  # exchanges issued (tests: two per solved round)
+
+    def shard(self, total: int) -> tuple[int, int]:
+        return shard_range(total, self.rank, self.world)
+
+    def gather_costs(self, cost_local, total: int):
+        import numpy as np
+        cost_local = np.ascontiguousarray(cost_local, dtype=np.float64)
+        self.collectives += 1
+        if self.world == 1:
+            return cost_local
+        if self.native is not None:
+            dev, dt = self.native.solver.device, self.native.solver.dtype
+            out = self.native.allgather(torch.as_tensor(cost_local).to(dev, dt), total=total)
+            return out.double().cpu().numpy()
+        t = torch.as_tensor(cost_local)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        return allgather_costs(t, total, self.group).cpu().numpy()
+
+    def winner(self, index: int, total: int, U_local, X_local, shapes):
+        """(U, X) of candidate `index` on every rank.  U_local / X_local: this rank's solved
+        trajectories (lists or arrays over its shard; read on the owner only); shapes = (U.shape,
+        X.shape) so that the other ranks can size their receive buffer."""
+        import numpy as np
+        owner, loc = owner_of(index, total, self.world)
+        (us, xs) = shapes
+        nu, nx = int(np.prod(us)), int(np.prod(xs))
+        self.collectives += 1
+        if self.world == 1:
+            return np.asarray(U_local[loc], float), np.asarray(X_local[loc], float)
+        pack = np.zeros(nu + nx)
+        if self.rank == owner:
+            pack[:nu] = np.asarray(U_local[loc], float).ravel()
+            pack[nu:] = np.asarray(X_local[loc], float).ravel()
+        if self.native is not None:
+            dev, dt = self.native.solver.device, self.native.solver.dtype
+            if dt != torch.float64:
+                raise ValueError("the native hand-off carries the handle's dtype: use an fp64 handle")
+            buf = torch.as_tensor(pack).to(dev, dt)
+            pack = self.native.broadcast(buf, owner).cpu().numpy()
+        else:
+            t = torch.as_tensor(pack)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            src = dist.get_process_group_ranks(self.group)[owner] if self.group is not None else owner
+            dist.broadcast(t, src=src, group=self.group)
+            pack = t.cpu().numpy()
+        return pack[:nu].reshape(us), pack[nu:].reshape(xs)

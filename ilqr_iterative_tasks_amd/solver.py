@@ -176,6 +176,49 @@ class BatchedILQR:
         buf["k"] = z("k") if want_gains else None
         return buf
 
+    @staticmethod
+    def recommended_layout(cfg: I2lqrConfig, B: int, early_exit: bool = False, lib=None) -> int:
+        """cfg.layout to create a solver with for batches of B problems (i2lqr_recommended_layout:
+        the crossover between the problem-major latency kernels and the one-problem-per-lane
+        throughput kernels is measured and lives behind the C-ABI)."""
+        lib = _abi.load_library() if lib is None else lib
+        rc = int(lib.i2lqr_recommended_layout(C.byref(cfg), int(B), 1 if early_exit else 0))
+        if rc < 0:
+            raise I2lqrError(f"i2lqr error {rc}: {lib.i2lqr_last_error().decode()}")
+        return rc
+
+    def set_initial_state(self, buf: dict, x0: torch.Tensor, lamb0: float | None = None) -> None:
+        """Candidates of one control round share the current state: X[:, :, 0] = x0, X elsewhere
+        and U zero (utils/base.py:405-408), lamb = lamb0 (:393) — written in this solver's layout
+        (fills and one strided copy: no arithmetic)."""
+        X = buf["X"]
+        X.zero_()
+        buf["U"].zero_()
+        x0 = x0.to(self.device, self.dtype)
+        if self.batch_tiled:
+            X[:, 0] = x0[None, :, None]      # [B/64, N+1, n, 64]
+        elif self.batch_minor:
+            X[0] = x0[:, None]               # [N+1, n, B]
+        else:
+            X[:, :, 0] = x0[None, :]         # [B, n, N+1]
+        if lamb0 is not None:
+            buf["lamb"].fill_(float(lamb0))
+
+    def problem(self, buf: dict, idx: torch.Tensor) -> dict:
+        """U[m, N] and X[n, N+1] of problem `idx` (a device int64 tensor of one element, e.g. the
+        pick: no host synchronisation) in the reference's orientation, whatever the layout."""
+        i = idx.reshape(()).clamp(min=0)
+        out = {}
+        for key in ("U", "X"):
+            t = buf[key]
+            if self.batch_tiled:
+                out[key] = t[i // 64, :, :, i % 64].transpose(0, 1).contiguous()
+            elif self.batch_minor:
+                out[key] = t[:, :, i].transpose(0, 1).contiguous()
+            else:
+                out[key] = t[i].clone()
+        return out
+
     # -- the path ---------------------------------------------------------------------------
     def rollout(self, X, U, x_term, cost=None):
         """control/iterative_ilqr.py:32-48.  X[:, :, 0] = x0; U is clipped in place."""

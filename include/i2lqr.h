@@ -401,6 +401,18 @@ int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, v
                           int64_t n_local, void* stream);
 
 /*
+ * The hand-off that follows the pick on a sharded batch: after the all-gather every
+ * rank knows WHICH candidate won, only the rank that solved it holds its trajectory — and the
+ * reference goes on with exactly that trajectory: it applies u_pred[:, 0] and feeds x_pred[:, -1] to
+ * the next round (utils/base.py:466-471).  One ncclBroadcast of `count` reals, in place, from the
+ * owning rank `root` (the winner's U[m][N] and X[n][N+1] packed by the caller: <= 6.5 KB at n = 12,
+ * N = 50) on the communicator of i2lqr_allgather_costs.  Every rank calls it with the same count and
+ * root.  (The alternative — every rank re-solves the winner — costs a whole solve per round.)
+ */
+int i2lqr_broadcast_winner(i2lqr_handle* h, void* comm, void* buf, int64_t count, int32_t root,
+                           void* stream);
+
+/*
  * Controller round on the device (problem-major layout).
  *
  * i2lqr_select_candidates — replaces iLqr.select_close_ss (utils/base.py:332-341) and the

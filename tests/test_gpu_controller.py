@@ -71,6 +71,15 @@ def test_closed_loop_device_rounds_match_host_rounds():
     assert laps_d == laps_h == [121, 54, 28, 23]
     for a, b in zip(ego_h.data["input"], ego_d.data["input"]):
         assert np.abs(np.asarray(a) - np.asarray(b)).max() < 1e-9
+    # the rounds were replayed from the captured hipGraph, not silently run launch by launch (the
+    # index-checked debug build synchronises its streams and cannot be captured: it says why)
+    from ilqr_iterative_tasks_amd import _abi
+    info = ctrl_d.last_round_info
+    assert info["graph_requested"] is True
+    if "debug" in str(_abi.LIB_PATH):
+        assert info["graph"] or info["graph_error"]
+    else:
+        assert info["graph"] is True and info["graph_error"] is None, info
 
 
 def test_select_and_pick_kernels_against_host_logic(golden_dir):
@@ -233,3 +242,93 @@ def test_ilqr_dropin_with_moving_obstacles_matches_reference_calls(golden_dir):
         assert batch_rel_err(x[None], g["X"][i][None]) < 1e-8, (i, kind)
         assert batch_rel_err(u[None], g["U"][i][None], floor=1e-2) < 1e-8, (i, kind)
     assert (1.0, 1) in seen and (0.2, 2) in seen  # both moving options were exercised
+
+
+def test_sharded_calc_input_two_ranks_share_the_gpu():
+    """examples/ilqr_test.py --sharded under torchrun with two ranks on this one-GPU box
+    (I2LQR_SHARE_GPU: process group on gloo, both ranks solve their shards with the HIP kernels on
+    device 0): both ranks drive config 1 to laps 121/54/28/23 — the unsharded independent-lamb
+    controller's — applying identical inputs at every control step."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, I2LQR_SHARE_GPU="1", I2LQR_COMM_TIMEOUT="60")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(port), str(root / "examples" / "ilqr_test.py"), "--sharded",
+                          "--lap-number", "3"], capture_output=True, text=True, timeout=900,
+                         cwd=str(root), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import re
+    # (two ranks write to one pipe: their lines may arrive glued together)
+    recs = [json.loads(r) for r in re.findall(r'\{"rank".*?\}', out.stdout)]
+    assert sorted(r["rank"] for r in recs) == [0, 1]
+    assert recs[0]["laps"] == recs[1]["laps"] == [121, 54, 28, 23]
+    assert recs[0]["inputs_sha256"] == recs[1]["inputs_sha256"]
+    assert recs[0]["exchanges"] == recs[1]["exchanges"] > 0
+    # the same inputs as the unsharded controller on this GPU
+    ego, ctrl = build("independent")
+    us, orig = [], ctrl.calc_input
+
+    def spy():
+        orig()
+        us.append(np.array(ctrl.u, float))
+
+    ctrl.calc_input = spy
+    assert harness.run_laps(ego, ctrl, 3) == [121, 54, 28, 23]
+    import hashlib
+    assert len(us) == recs[0]["control_steps"]
+    assert hashlib.sha256(np.array(us).tobytes()).hexdigest() == recs[0]["inputs_sha256"]
+
+
+def test_candidate_solver_reaches_the_lane_kernels_through_the_product_surface():
+    """HipCandidateSolver (the surface calc_input()/solve() batch through) asks the LIBRARY for the
+    layout (i2lqr_recommended_layout): 65536 candidates of one control round run on the
+    one-problem-per-lane kernels, 64 on the latency kernels — no threshold on the caller's side.
+    candidate_round() keeps the round on the device: relaxed costs, flat pick and the winner's
+    trajectory, checked against the same candidates on the problem-major kernels."""
+    import torch
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+    cfg = default_config("bicycle6", 20, "f64", dt=0.25)
+    hs = HipCandidateSolver()
+    for B, kernel, layout in ((65536, "k_lane_iterate", 2), (16385, "k_lane_iterate", 1),
+                              (2048, "k_group_iterate (sixteen lanes)", 0), (64, "k_iterate", 0)):
+        host = workloads.make_batch(cfg, B)
+        x0 = torch.as_tensor(host["X"][0, :, 0]).cuda()
+        x_terms = torch.as_tensor(host["x_term"]).cuda()
+        qfun = torch.as_tensor(np.random.default_rng(B).integers(0, 100, B).astype(np.int32)).cuda()
+        out = hs.candidate_round(cfg, x0, x_terms, qfun, 1.0, obs_rec=(31, -3, 8, 6, 0, 0),
+                                 n_iters=10)
+        s = out["solver"]
+        assert s.iterate_kernel(B) == kernel and s.cfg.layout == layout, (B, s.iterate_kernel(B))
+        cost = out["cost_it"].cpu().numpy()
+        idx = int(out["best_idx"].item())
+        assert idx == int(np.argmin(cost)) and float(out["best_cost"].item()) == cost.min()
+        Xw = s.to_problem_major(out["buf"]["X"])[idx]
+        Uw = s.to_problem_major(out["buf"]["U"])[idx]
+        assert torch.equal(out["X"], Xw) and torch.equal(out["U"], Uw)
+        # the same round on the problem-major kernels
+        ref = BatchedILQR(cfg)
+        rb = ref.alloc(B, want_gains=False)
+        ref.set_initial_state(rb, x0, 1.0)
+        rb["x_term"].copy_(x_terms)
+        rb["obs"] = torch.tensor([31, -3, 8, 6, 0, 0], dtype=torch.float64).cuda().expand(B, -1).contiguous()
+        rc, (ri, rv) = ref.iterate_pick(rb, 10, qfun, 0)
+        same = (rc.cpu().numpy() == cost) | (np.isinf(cost) & np.isinf(rc.cpu().numpy()))
+        assert same.mean() >= 0.995, same.mean()
+        sm = torch.as_tensor(same).cuda() & (s.to_problem_major(out["buf"]["lamb"]) == rb["lamb"])
+        err = (s.to_problem_major(out["buf"]["X"])[sm] - rb["X"][sm]).abs().max()
+        assert float(err) < 1e-6 * float(rb["X"][sm].abs().max())
+    # solve to termination through the same entry
+    out = hs.candidate_round(cfg, x0, x_terms, qfun, 1.0, n_iters=None)
+    assert int(out["best_idx"].item()) == int(np.argmin(out["cost_it"].cpu().numpy()))

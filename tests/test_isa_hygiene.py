@@ -11,6 +11,11 @@ from pathlib import Path
 
 import pytest
 
+# The COUNT thresholds below (loop sizes, lane moves, waits) were calibrated on this compiler; on
+# another one they are reported as expected failures, the hard invariants (no flat_* / scratch_* in
+# hot loops, no DPP read-after-write hazard) are asserted on any.
+CALIBRATED_HIPCC = "7.2.26015"
+
 CSRC = Path(__file__).resolve().parent.parent / "ilqr_iterative_tasks_amd" / "csrc"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
@@ -28,7 +33,9 @@ def _loops(text: str, kernel_prefix: str):
     """{loop header: [instructions]} of the first kernel whose symbol starts with kernel_prefix
     (blocks attributed to the loop the compiler's annotation names, as tools/isa_loops.py does)."""
     lines = text.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith(kernel_prefix) and ":" in l)
+    start = next((i for i, l in enumerate(lines) if l.startswith(kernel_prefix) and ":" in l), None)
+    assert start is not None, (f"no kernel symbol starting with {kernel_prefix} in the ISA listing: "
+                               "the kernel was renamed or its template arguments changed")
     loops, cur = {}, None
     for l in lines[start + 1:]:
         if l.startswith(".Lfunc_end"):
@@ -53,6 +60,24 @@ def isa(tmp_path_factory):
     return {"lane12": a, "group": b}
 
 
+def _counts_apply():
+    """True on the compiler the count thresholds were calibrated on; otherwise the caller turns a
+    threshold miss into an expected failure."""
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:  # noqa: BLE001
+        return False
+    return CALIBRATED_HIPCC in out
+
+
+def _soft(cond, msg):
+    if cond:
+        return
+    if _counts_apply():
+        raise AssertionError(msg)
+    pytest.xfail(f"{msg} (count threshold calibrated on hipcc {CALIBRATED_HIPCC}, another compiler here)")
+
+
 def test_no_flat_memory_operations(isa):
     for tu, text in isa.items():
         n = len(re.findall(r"^\s+flat_(load|store|atomic)", text, flags=re.M))
@@ -68,15 +93,16 @@ def test_hot_loops_of_the_quad12_lane_kernel_do_not_spill_to_scratch(isa):
     assert hot, {k: len(v) for k, v in loops.items()}
     step = min(hot, key=len)
     assert not [i for i in step if i.startswith("scratch_")]
-    assert sum(i.startswith(("v_readlane", "v_writelane")) for i in step) < 150
-    assert sum("f64" in i for i in step) > 1800
+    _soft(sum(i.startswith(("v_readlane", "v_writelane")) for i in step) < 150, "lane moves in the step")
+    _soft(sum("f64" in i for i in step) > 1800, "fp64 operations in the step")
     # one full drain of the vector-memory counter per step at most: the landing of the next step's
     # inputs before the first gain store
-    assert sum(i == "s_waitcnt" for i in step) < 60
+    _soft(sum(i == "s_waitcnt" for i in step) < 60, "s_waitcnt in the step")
 
 
 def test_headline_kernel_loops_are_clean(isa):
-    loops = _loops(isa["group"], "_ZN5i2lqr15k_group_iterateIdNS_8Bicycle6IdEELi3ELb0EEE")
+    # the headline launch: sixteen lanes per problem, one helper wavefront (H = 2, WS = false, G = 16)
+    loops = _loops(isa["group"], "_ZN5i2lqr15k_group_iterateIdNS_8Bicycle6IdEELi2ELb0ELi16EEE")
     assert loops
     checked = 0
     for name, ins in loops.items():
@@ -87,3 +113,43 @@ def test_headline_kernel_loops_are_clean(isa):
         assert not [i for i in ins if i.startswith(("global_", "buffer_"))], name  # state stays in LDS
         checked += 1
     assert checked >= 2  # the backward and the forward horizon loops at least
+
+
+def _vregs(tok):
+    """VGPR numbers an operand token names: v12 -> {12}, v[4:7] -> {4..7}; anything else -> {}."""
+    tok = tok.strip().rstrip(",").lstrip("-|").rstrip("|")
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_no_dpp_read_of_a_register_written_by_the_two_instructions_in_front(isa):
+    """The DPP row broadcasts of the sixteen-lane form are inline asm (the fp64 ALU's only DPP mode,
+    folded into the multiply-add, is not something the compiler emits), so its hazard recogniser
+    does not see them: the hardware needs two wait states between a VALU write of a VGPR and a DPP
+    read of it.  Checked here on the compiled code: for every *_dpp instruction, neither of the two
+    issue slots in front of it (an s_nop N fills N + 1) is a VALU instruction whose destination
+    overlaps the DPP source operand."""
+    lines = [l for l in isa["group"].split("\n")
+             if l.startswith("\t") and not l.startswith(("\t;", "\t.")) and l.strip()]
+    found = 0
+    for i, l in enumerate(lines):
+        parts = l.split()
+        if "_dpp" not in parts[0]:
+            continue
+        found += 1
+        src = _vregs(parts[2])  # v_fmac_*_dpp dst, SRC0 (the DPP operand), src1
+        assert src, l
+        slots, j = 0, i - 1
+        while slots < 2 and j >= 0:
+            p = lines[j].split()
+            if p[0] == "s_nop":
+                slots += int(p[1]) + 1
+            else:
+                slots += 1
+                if p[0].startswith("v_") and len(p) > 1:
+                    assert not (_vregs(p[1]) & src), f"DPP hazard: {lines[j].strip()!r} -> {l.strip()!r}"
+            j -= 1
+    assert found > 100  # the sixteen-lane kernels are in this translation unit
