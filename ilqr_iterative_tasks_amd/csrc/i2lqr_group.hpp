@@ -167,6 +167,18 @@ __device__ __forceinline__ void bcast_fmac(T (&a)[R], const T (&s)[R], T c) {
 #pragma unroll
   for (int r = 0; r < R; r++) bcast_fmac1<L>(a[r], s[r], c);
 }
+// value of lane L of the 16-lane row (v_mov_b64_dpp / v_mov_b32_dpp row_newbcast: emitted by the
+// compiler itself, which also keeps its hazards)
+template <int L> __device__ __forceinline__ double bcast_mov(double v) {
+  long long x = __builtin_bit_cast(long long, v);
+  x = __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, x);
+}
+template <int L> __device__ __forceinline__ float bcast_mov(float v) {
+  int x = __builtin_bit_cast(int, v);
+  x = __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, false);
+  return __builtin_bit_cast(float, x);
+}
 template <class T, int R> __device__ __forceinline__ void dpp_ready(T (&v)[R]) {
   if constexpr (R == 8)
     asm("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
@@ -679,7 +691,6 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
     load_record(N - 1, ra);
     auto step = [&](const int t, Rec& rc, Rec& rn) __attribute__((always_inline)) {
       const T (&jv)[NV] = rc.jv;
-      STAMP_BEGIN();
       // P1: own column of T1 = F^T [Vxx | Vx]
       T t1[W];
       static_for_i<0, W>([&](auto a_) {
@@ -694,7 +705,6 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       });
       dpp_ready(t1);
       load_record(t > 0 ? t - 1 : 0, rn);  // lands under the broadcast block
-      STAMP_END(1);
       // Source order = the order that keeps the serial chain short: Quu and the input rows of the
       // H column first (the inverse and the gain column wait for them), the state rows of the
       // column — 4 n independent multiply-adds nothing waits for until the value update — behind
@@ -741,13 +751,11 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       h_rows(std::integral_constant<int, n>{}, hu);
 #pragma unroll
       for (int a = 0; a < m; a++) hu[a] += rc.lrow[a];
-      STAMP_END(2);
       if constexpr (GENERAL) quu_inverse(Quu, lamb, Qinv);
       else t_quu_inverse2_pd(Quu, lamb, Qinv, &bad);
       h_rows(std::integral_constant<int, 0>{}, hx);
       hx[0] += rc.l0;
       hx[1] += rc.l1;
-      STAMP_END(3);
       // own column of [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
       T kc[m];
 #pragma unroll
@@ -760,7 +768,6 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       T* Kt = gain_x(t);
 #pragma unroll
       for (int a = 0; a < m; a++) Kt[a * GL::KW + gcol] = kc[a];
-      STAMP_END(4);
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
       T qk[m], z[m];
 #pragma unroll
@@ -791,8 +798,8 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       });
 #pragma unroll
       for (int i = 0; i < n; i++) va[i] = vn[i];
-      STAMP_END(5);
     };
+    STAMP_BEGIN();  // (whole pass: per-phase stamps inside the step serialise what they measure)
     int t = N - 1;
     if constexpr (I2LQR_GROUP_UNROLL >= 4) {
       for (; t >= 3; t -= 4) {
@@ -807,8 +814,100 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       step(t - 1, rb, ra);
     }
     if (t == 0) step(0, ra, rb);
+    STAMP_END(1);
     wave_sync();  // the forward pass reads the gain columns the other lanes stored
     return bad;
+  }
+
+  // -- forward pass, sixteen lanes per problem, plants whose heading is known a step ahead
+  //    (Sys::kHeadingAhead).  The rollout is serial and every lane of a problem runs all of it;
+  //    what the two halves of the 16-lane row can share is the work INSIDE a step:
+  //      * the feedback law and the clip of input a run on half a (lanes 0-7: input 0, lanes
+  //        8-15: input 1; each lane reads only its input's gain row), the two inputs are
+  //        exchanged by row broadcasts;
+  //      * sin / cos — 45 of the 117 instructions of a step — are evaluated ONCE PER TWO STEPS:
+  //        after step t the lower half holds the heading of x_{t+1}, the upper half that of
+  //        x_{t+2} (= theta_{t+1} + delta_{t+1} dt: it does not depend on the inputs of step
+  //        t+1), one evaluation serves both and each half stores its pair into the trajectory's
+  //        sin / cos cache itself.
+  //    Same operations on the same operands as forward<false>: bit-identical states and inputs
+  //    (~75 instructions per step against 117).
+  __device__ __forceinline__ T forward_row(int XUo, int XUn, int TRn, const T (&xT)[n],
+                                           bool* bad) const {
+    static_assert(G == 16 && m == 2, "two inputs on the two halves of a 16-lane row");
+    const int half = g >> 3;
+    const T umax = half ? c.u_max[1] : c.u_max[0];
+    T x[n], u[m], xn[n], tr[NT];
+#pragma unroll
+    for (int i = 0; i < n; i++) x[i] = S[XUo + i];
+#pragma unroll
+    for (int i = 0; i < n; i++) S[XUn + i] = x[i];
+    Sys::template trig_g<false>(x, tr, bad);
+#pragma unroll
+    for (int q = 0; q < NT; q++) S[TRn + q] = tr[q];
+    // Running bases, bumped once per pair of steps; every access of a step is a base plus a
+    // compile-time offset (a per-step address is otherwise a vector add per array and step).
+    // The look-ahead loads of the last step read record N of the nominal buffer (its input slot
+    // is unused) and one gain row past the last step's (the record array follows in the slice):
+    // in bounds, never consumed.
+    static_assert(!WS, "gain rows and records are neighbours in the LDS slice");
+    auto pXo = S + XUo;                        // nominal record of step t
+    auto pXn = S + XUn;                        // candidate record of step t
+    auto pG = S + (oKk + half * GL::KW);       // this half's gain row of step t
+    auto pTR = S + (TRn + half * NT);          // this half's sin / cos slot: record t + half
+    T xo[n], uo, kk[NA];
+    auto load_step = [&](auto k_) __attribute__((always_inline)) {
+      constexpr int k = decltype(k_)::value;
+#pragma unroll
+      for (int j = 0; j < n; j++) xo[j] = pXo[k * W + j];
+      uo = pXo[k * W + n + half];
+#pragma unroll
+      for (int j = 0; j < NA; j++) kk[j] = pG[k * (m * GL::KW) + j];
+    };
+    load_step(std::integral_constant<int, 0>{});
+    auto step = [&](auto k_, const T (&trc)[NT]) __attribute__((always_inline)) {
+      constexpr int k = decltype(k_)::value;   // step t + k of the pair that starts at t
+      T acc = T(0);
+#pragma unroll
+      for (int j = 0; j < n; j++) acc = t_fma(kk[j], x[j] - xo[j], acc);
+      const T ua = clip(uo + kk[n] + acc, -umax, umax);
+      load_step(std::integral_constant<int, k + 1>{});
+      pXn[k * W + n + half] = ua;
+      u[0] = bcast_mov<0>(ua);
+      u[1] = bcast_mov<8>(ua);
+      Sys::step_tr(c, x, u, trc, xn);
+#pragma unroll
+      for (int i = 0; i < n; i++) pXn[(k + 1) * W + i] = xn[i];
+#pragma unroll
+      for (int i = 0; i < n; i++) x[i] = xn[i];
+    };
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+      step(std::integral_constant<int, 0>{}, tr);  // x = x_{t+1}
+      T sc[NT], tr1[NT];
+      Sys::trig_heading_fast(half ? Sys::next_heading(c, x) : Sys::heading(x), sc, bad);
+#pragma unroll
+      for (int q = 0; q < NT; q++) pTR[NT + q] = sc[q];   // record t + 1 + half
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+        tr1[q] = bcast_mov<0>(sc[q]);
+        tr[q] = bcast_mov<8>(sc[q]);   // of x_{t+2}: the next pair's first step
+      }
+      step(std::integral_constant<int, 1>{}, tr1);  // x = x_{t+2}
+      pXo = pXo + 2 * W;
+      pXn = pXn + 2 * W;
+      pG = pG + 2 * (m * GL::KW);
+      pTR = pTR + 2 * NT;
+    }
+    if (t < N) {  // odd horizon: the last step, and the sin / cos of x_N for the records
+      step(std::integral_constant<int, 0>{}, tr);
+      Sys::template trig_g<false>(x, tr, bad);
+#pragma unroll
+      for (int q = 0; q < NT; q++) S[TRn + N * NT + q] = tr[q];
+    }
+    const T cost = terminal_cost(x, xT);
+    wave_sync();
+    return cost;
   }
 
   // -- forward pass: control/iterative_ilqr.py:133-160; all lanes of the group redundantly ------
@@ -817,6 +916,8 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
   template <bool GENERAL>
   __device__ __forceinline__ T forward(int XUo, int XUn, int TRn, const T (&xT)[n],
                                        bool* bad) const {
+    if constexpr (G == 16 && !GENERAL && Sys::kHeadingAhead && m == 2)
+      return forward_row(XUo, XUn, TRn, xT, bad);
     T x[n], u[m], xn[n], tr[NT];
 #pragma unroll
     for (int i = 0; i < n; i++) x[i] = S[XUo + i];
@@ -919,6 +1020,10 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   extern __shared__ __align__(16) unsigned char gsmem_raw[];
   T* smem = reinterpret_cast<T*>(gsmem_raw);
   const int lane = threadIdx.x & 63, hv = threadIdx.x >> 6;
+#ifdef I2LQR_STAMPS
+  unsigned long long st_k0, st_k1, st_k2, st_k3;  // kernel start, loop start, loop end, kernel end
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k0)::"memory");
+#endif
   const int64_t prob0 = (int64_t)blockIdx.x * GL::PW + lane / G;
   // groups past the end of the batch work on a copy of the last problem and store nothing, so
   // that every lane of the wavefront runs the same control flow
@@ -977,6 +1082,9 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   bool fresh = true, active = a.n_iters > 0;
   // the problems of a wavefront stop at different iterations (early exits): the loop runs while any
   // of them is active; finished ones keep computing on their (unchanged) state and commit nothing
+#ifdef I2LQR_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k1)::"memory");
+#endif
   while (__any(active)) {
     const int XUo = cur ? L.XU1 : L.XU0, XUn = cur ? L.XU0 : L.XU1;
     const int TRo = cur ? L.TR1 : L.TR0, TRn = cur ? L.TR0 : L.TR1;
@@ -1043,6 +1151,9 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
       fresh = false;
     }
   }
+#ifdef I2LQR_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k2)::"memory");
+#endif
   if constexpr (H > 1) {
     if (lane == 0) ctl[8] = 0;  // release the helpers
     __syncthreads();            // B1 of an iteration that does not happen
@@ -1074,16 +1185,22 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
         gk[e] = w.gain(t)[aa * GL::KW + n];
       }
     }
-#ifdef I2LQR_STAMPS
-    if (a.dbg && g == 0)
-      for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = w.st_acc[q];
-#endif
     if (g == 0) {
       a.lamb[prob] = lamb;
       a.cost[prob] = cost_ret;
       if (a.iters) a.iters[prob] = it;
       if (a.status) a.status[prob] = status;
     }
+#ifdef I2LQR_STAMPS
+    // slots 0 (records), 1 (backward), 6 (forward): sums over the iterations; 2: entry (loads +
+    // nominal rollout), 3: the whole iteration loop, 4: exit stores
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k3)::"memory");
+    w.st_acc[2] = st_k1 - st_k0;
+    w.st_acc[3] = st_k2 - st_k1;
+    w.st_acc[4] = st_k3 - st_k2;
+    if (a.dbg && g == 0)
+      for (int q = 0; q < 8; q++) a.dbg[prob * 8 + q] = w.st_acc[q];
+#endif
   }
   // epilogue (i2lqr_iterate_pick): relaxed terminal cost of utils/base.py:427-437 from the x_N
   // still in LDS — the words just stored to X, so i2lqr_relax_cost on the returned X gives the

@@ -130,6 +130,42 @@ template <> __device__ __forceinline__ void t_sincos_fast<double>(double x, doub
                                                                    bool* big_out) {
   t_sincos_fast_d<false>(x, s, c, big_out);
 }
+// t_sincos_fast with the Horner steps written as THREE-address multiply-adds (v_fma_f64 d, p, z, k).
+// Left to itself the compiler picks the two-address v_fmac_f64 and copies every coefficient — a
+// loop-invariant vector register pair — into the accumulator first: 12 v_mov_b64 per evaluation
+// in the sixteen-lane forward pass (GroupWorker::forward_row).  Same operations, bit for bit.
+__device__ __forceinline__ double t_fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ void t_sincos_fast_h3(double x, double* s, double* c, bool* big_out) {
+  const bool big = !(__builtin_fabs(x) < 1.0e5);
+  *big_out = *big_out || big;
+  const double xs = big ? 0.0 : x;
+  const double kf = __builtin_rint(xs * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-kf, 1.57079632679489655800e+00, xs);
+  r = __builtin_fma(-kf, 6.12323399573676603587e-17, r);
+  r = __builtin_fma(-kf, -1.49738490485916983327e-33, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10, pc = -1.13596475577881948265e-11;
+#define I2LQR_SC_STEP3(ls, lc) \
+  ps = t_fma3(ps, z, ls);      \
+  pc = t_fma3(pc, z, lc);
+  I2LQR_SC_STEP3(-2.50507602534068634195e-08, 2.08757232129817482790e-09)
+  I2LQR_SC_STEP3(2.75573137070700676789e-06, -2.75573143513906633035e-07)
+  I2LQR_SC_STEP3(-1.98412698298579493134e-04, 2.48015872894767294178e-05)
+  I2LQR_SC_STEP3(8.33333333332248946124e-03, -1.38888888888741095749e-03)
+  I2LQR_SC_STEP3(-1.66666666666666324348e-01, 4.16666666666666019037e-02)
+#undef I2LQR_SC_STEP3
+  const int qd = (int)kf;
+  const double sr = __builtin_fma(ps * z, r, r);
+  const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+  const bool swap = qd & 1;
+  const double sv = swap ? cr : sr, cv = swap ? sr : cr;
+  *s = (qd & 2) ? -sv : sv;
+  *c = ((qd + 1) & 2) ? -cv : cv;
+}
 template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) {
   // The short kernel runs unconditionally and the library routine, which only arguments of
   // |x| >= 1e5 (or NaN) need, sits behind a WAVE-UNIFORM unlikely branch: the common case falls
@@ -169,6 +205,9 @@ template <> __device__ __forceinline__ void t_sincos_fast<float>(float x, float*
   const float sv = swap ? cr : sr, cv = swap ? sr : cr;
   *s = (q & 2) ? -sv : sv;
   *c = ((q + 1) & 2) ? -cv : cv;
+}
+__device__ __forceinline__ void t_sincos_fast_h3(float x, float* s, float* c, bool* big_out) {
+  t_sincos_fast<float>(x, s, c, big_out);
 }
 template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) {
   bool big = false;
@@ -588,6 +627,9 @@ template <class T> struct Bicycle4 {
   static constexpr int blk(int) { return 0; }
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 0;
+  // theta' = theta + delta dt with delta an INPUT: the heading two steps ahead is not known before
+  // the next step's feedback law has run
+  static constexpr bool kHeadingAhead = false;
 
   // {cos(theta), sin(theta)}
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
@@ -666,6 +708,20 @@ template <class T> struct Bicycle6 {
   static constexpr int blk(int) { return 0; }
   template <class Cfg> static __device__ __forceinline__ T plant_const(const Cfg&, int) { return T(0); }
   static constexpr int system_id = 1;
+  // theta' = theta + delta dt with delta a STATE: the heading of x_{t+2} follows from x_{t+1} alone,
+  // so a rollout can evaluate the sin / cos of two consecutive steps side by side (the sixteen-lane
+  // forward pass does, on the two halves of a problem's DPP row: GroupWorker::forward_row)
+  static constexpr bool kHeadingAhead = true;
+  static __device__ __forceinline__ T heading(const T (&xe)[n]) { return xe[3]; }
+  // heading of the successor state: the very expression step_tr evaluates for xn[3]
+  template <class Cfg>
+  static __device__ __forceinline__ T next_heading(const Cfg& c, const T (&xe)[n]) {
+    return xe[3] + xe[5] * c.dt;
+  }
+  // trig_g<false> for a heading given as a number
+  static __device__ __forceinline__ void trig_heading_fast(T ang, T (&tr)[NTRIG], bool* bad) {
+    t_sincos_fast_h3(ang, &tr[1], &tr[0], bad);
+  }
 
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {
     t_sincos(xe[3], &tr[1], &tr[0]);
@@ -742,6 +798,7 @@ template <class T> struct Quad12 {
   // 25 state-dependent entries of A and the 3 x 4 thrust-direction entries of B
   static constexpr int NVAR = 37;
   static constexpr int system_id = 2;
+  static constexpr bool kHeadingAhead = false;
 
   // {sin phi, cos phi, sin theta, cos theta, sin psi, cos psi}
   static __device__ __forceinline__ void trig(const T (&xe)[n], T (&tr)[NTRIG]) {

@@ -40,6 +40,9 @@ names = (["prep", "bwd P1", "bwd P2", "bwd quu_inv", "bwd gains+value", "bwd ref
          if lanes == 64 else ["record phase", "bwd P1 + T1 exchange", "forward", "accept + adopt", "bwd P2 (H column)",
           "bwd record fetch, Quu, inverse, gain column", "bwd gain exchange + value update", "rollout at entry + stores at exit (per launch / iters)"]
          if lanes == 16 and cfg.system_id == 2 else
+         ["records (sum / iters)", "backward (sum / iters)", "ENTRY: loads + rollout (per launch / iters)",
+          "LOOP: all iterations (per launch / iters)", "EXIT: stores (per launch / iters)", "-",
+          "forward (sum / iters)", "-"] if lanes == 16 else
          ["prep", "bwd P1 + T1 exchange", "bwd P2 (H column)", "bwd Quu + inverse",
           "bwd gains + exchange", "bwd value update", "forward", "-"])
 tot = d.sum()
