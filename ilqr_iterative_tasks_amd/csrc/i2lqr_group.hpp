@@ -1002,6 +1002,17 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
   }
 };
 
+// e / d for the index arithmetic of the entry / exit copies (0 <= e < 2^22, 1 <= d <= 2^12): a
+// float reciprocal and one correction instead of the ~30-instruction integer division by a
+// run-time divisor (the exit copy of K alone does 30 of them per lane).
+__device__ __forceinline__ int idx_div(int e, int d, float rcp_d) {
+  int q = (int)((float)e * rcp_d);
+  const int r = e - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
 // Grid: ceil(B / 8) workgroups of H wavefronts; dynamic LDS = GLayout::wave_words() * sizeof(T).
 // H > 1: wavefronts 1..H-1 are helpers for the one phase of an iteration that is parallel over the
 // horizon — the per-step records (prep): 21 records of eight problems are three rounds for one
@@ -1031,6 +1042,7 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
   const int64_t prob = real ? prob0 : a.B - 1;
   GroupWorker<T, Sys, WS, G> w(c, smem, lane);
   const int N = c.N, g = w.g;
+  const float rN = 1.0f / (float)N, rN1 = 1.0f / (float)(N + 1), rnN = 1.0f / (float)(n * N);
   const GL& L = w.L;
   const auto S = w.S;
   if constexpr (WS) w.Wp = ws + prob0 * (int64_t)L.ws_words();
@@ -1044,7 +1056,7 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
     if (g < n) S[L.XU0 + g] = gX[g * (N + 1)];
     const T* gU = a.U + prob * (int64_t)(m * N);
     for (int e = g; e < m * N; e += G) {
-      const int aa = e / N, t = e - aa * N;
+      const int aa = idx_div(e, N, rN), t = e - aa * N;
       S[L.XU0 + t * W + n + aa] = gU[e];
     }
     for (int e = lane; e < n * n; e += 64) smem[L.qt_base() + e] = c.Qt[e];
@@ -1124,31 +1136,29 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
       STAMP_END(6);
 #endif
     }
-    if (active) {
-      it++;
-      // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84
-      fresh = cost_new < cost;
-      if (fresh) {
-        cur ^= 1;
-        lamb /= c.lamb_factor;
-        const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
-        cost_ret = cost_new;
-        cost = cost_new;
-        if (conv) {
-          if (a.early_exit) { status = 1; active = false; }
-          if (status == 0) status = 1;
-        }
+    {
+      // accept / reject with the lamb schedule: control/iterative_ilqr.py:74-84 — as selects, not
+      // branches: the problems of a wavefront decide differently, so both arms would run anyway,
+      // and every taken branch costs a wavefront alone on its SIMD ~100 cycles (the two fp64
+      // divisions are straight-line code; their results are dropped where they do not apply)
+      const bool acc = active && cost_new < cost, rej = active && !(cost_new < cost);
+      const T lamb_dn = lamb / c.lamb_factor, lamb_up = lamb * c.lamb_factor;
+      const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
+      it += active ? 1 : 0;
+      fresh = acc;
+      cur ^= acc ? 1 : 0;
+      lamb = acc ? lamb_dn : (rej ? lamb_up : lamb);
+      cost_ret = acc ? cost_new : (rej ? cost : cost_ret);
+      cost = acc ? cost_new : cost;
+      const bool stop_conv = acc && conv, stop_lamb = rej && lamb > c.max_lamb;
+      const int ended = stop_conv ? 1 : 3;
+      if (a.early_exit) {
+        status = (stop_conv || stop_lamb) ? ended : status;
+        active = active && !(stop_conv || stop_lamb);
       } else {
-        lamb *= c.lamb_factor;
-        cost_ret = cost;
-        if (lamb > c.max_lamb) {
-          if (a.early_exit) { status = 3; active = false; }
-          if (status == 0) status = 3;
-        }
+        status = (status == 0 && (stop_conv || stop_lamb)) ? ended : status;
       }
-      if (it >= a.n_iters) active = false;
-    } else {
-      fresh = false;
+      active = active && it < a.n_iters;
     }
   }
 #ifdef I2LQR_STAMPS
@@ -1165,23 +1175,24 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
     const int XUo = cur ? L.XU1 : L.XU0;
     T* gX = a.X + prob * (int64_t)(n * (N + 1));
     for (int e = g; e < n * (N + 1); e += G) {
-      const int i = e / (N + 1), t = e - i * (N + 1);
+      const int i = idx_div(e, N + 1, rN1), t = e - i * (N + 1);
       gX[e] = S[XUo + t * W + i];
     }
     T* gU = a.U + prob * (int64_t)(m * N);
     for (int e = g; e < m * N; e += G) {
-      const int aa = e / N, t = e - aa * N;
+      const int aa = idx_div(e, N, rN), t = e - aa * N;
       gU[e] = S[XUo + t * W + n + aa];
     }
     if (a.K) {
       T* gK = a.K + prob * (int64_t)(m * n * N);
       for (int e = g; e < m * n * N; e += G) {
-        const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
+        const int aa = idx_div(e, n * N, rnN), r = e - aa * (n * N);
+        const int j = idx_div(r, N, rN), t = r - j * N;
         gK[e] = w.gain(t)[aa * GL::KW + j];
       }
       T* gk = a.k + prob * (int64_t)(m * N);
       for (int e = g; e < m * N; e += G) {
-        const int aa = e / N, t = e - aa * N;
+        const int aa = idx_div(e, N, rN), t = e - aa * N;
         gk[e] = w.gain(t)[aa * GL::KW + n];
       }
     }
