@@ -628,13 +628,9 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
   //    time, so it arrives as the broadcast operand of a multiply-add (bcast_fmac):
   //      H[a][g]  = own T1[a][g] + F[0][g] T1[a][0] + F[1][g] T1[a][1] + dt T1[a][r(g)]   (P2)
   //      Quu[a][b] = l_uu + sum_k B[k][b] T1[n+a][k]
-  //      Va'[i][g] = H[i][g] - (K^T Quu [K|k][:, g])[i]
-  //               = H[i][g] + sum_b Qux[b][i] z_g[b],  z_g = Quu_reg^-T Quu kc_g,
-  //        Qux[b][i] = sum_k B[k][b] T1[i][k]  — the transpose entry of what lane i formed as
-  //        H[n+b][i]; equal by the symmetry of Vxx, which the one-problem-per-lane kernels rely on
-  //        as well (round-off level; documented in DESIGN.md) —
-  //    so the gains are not exchanged at all: every lane stores its column for the forward pass
-  //    and nothing waits for the store.  ~135 instructions per step in chains the ALU latency
+  //      Va'[i][g] = H[i][g] - sum_a K[a][i] (Quu [K|k][:, g])[a],  K[:, i] = lane i's gain column
+  //    so the gain columns are not exchanged through LDS either: every lane stores its column for
+  //    the forward pass and nothing waits for the store.  ~135 instructions per step in chains the ALU latency
   //    bounds, against 175 and two LDS round trips (2 x 108 cycles + 20 16-byte reads).
   template <bool GENERAL>
   __device__ __forceinline__ bool backward_row(int XUo, const T (&xT)[n], T lamb, bool commit) const {
@@ -757,19 +753,23 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       hx[0] += rc.l0;
       hx[1] += rc.l1;
       // own column of [K | k] = -Quu_inv [Qux | Qu]: control/iterative_ilqr.py:118-126
-      T kc[m];
+      // (pk = Quu_inv H[n:, g] = -kc: the sign rides in the operands that follow)
+      T pk[m], kc[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
         for (int b = 0; b < m; b++) acc = t_fma(Qinv[a * m + b], hu[b], acc);
+        pk[a] = acc;
         kc[a] = -acc;
       }
       T* Kt = gain_x(t);
 #pragma unroll
       for (int a = 0; a < m; a++) Kt[a * GL::KW + gcol] = kc[a];
       // value update with the UNregularised Quu: control/iterative_ilqr.py:128-129
-      T qk[m], z[m];
+      //   Va'[i][g] = H[i][g] - sum_a K[a][i] (Quu kc_g)[a],  K[a][i] = -pk[a] of LANE i: the
+      //   broadcast operand of the multiply-add — the gain columns are not exchanged through LDS
+      T qk[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
@@ -777,24 +777,13 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
         for (int b = 0; b < m; b++) acc = t_fma(Quu[a * m + b], kc[b], acc);
         qk[a] = acc;
       }
+      T vn[n];
 #pragma unroll
-      for (int b = 0; b < m; b++) {
-        T acc = T(0);
+      for (int i = 0; i < n; i++) vn[i] = hx[i];
+      static_for_i<0, n>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
 #pragma unroll
-        for (int a = 0; a < m; a++) acc = t_fma(Qinv[a * m + b], qk[a], acc);
-        z[b] = acc;
-      }
-      T t1x[n], vn[n];
-#pragma unroll
-      for (int i = 0; i < n; i++) { t1x[i] = t1[i]; vn[i] = hx[i]; }
-      static_for_i<0, m>([&](auto b_) {
-        constexpr int b = decltype(b_)::value;
-        static_for_i<0, n>([&](auto k_) {
-          constexpr int k = decltype(k_)::value;
-          constexpr int code = Sys::pat(k, n + b);
-          if constexpr (code == 1) bcast_fmac<k>(vn, t1x, z[b]);
-          else if constexpr (code != 0) bcast_fmac<k>(vn, t1x, f_entry(k_, b_, jv) * z[b]);
-        });
+        for (int a = 0; a < m; a++) bcast_fmac1<i>(vn[i], pk[a], qk[a]);
       });
 #pragma unroll
       for (int i = 0; i < n; i++) va[i] = vn[i];

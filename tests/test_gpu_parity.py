@@ -1301,7 +1301,7 @@ def test_random_configurations_every_family_against_the_oracle():
     """tools/parity_campaign.py at a size that takes seconds: random horizons, ragged batches,
     regularisation, obstacles and inputs beyond the box, every kernel family against the oracle —
     deviations within the suite's bounds where the oracle itself is insensitive to one ulp on U0,
-    within 100 x that sensitivity elsewhere (profiles/r03_parity_campaign.txt is the long run)."""
+    within 100 x that sensitivity elsewhere (profiles/r04_parity_campaign.txt is the long run)."""
     import subprocess
     import sys
     from pathlib import Path
@@ -1310,4 +1310,5 @@ def test_random_configurations_every_family_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=str(root))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "held everywhere" in out.stdout
-    assert sum(l.startswith(("bicycle4", "bicycle6", "quad12")) for l in out.stdout.splitlines()) == 16
+    # 7 + 7 + 4 (plant, family) lines: the bicycles incl. the sixteen-lane DPP form ("row16")
+    assert sum(l.startswith(("bicycle4", "bicycle6", "quad12")) for l in out.stdout.splitlines()) == 18

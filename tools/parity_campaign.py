@@ -48,12 +48,13 @@ FAMILIES = {
     "group-ws": (0, {"group_lanes": 8, "speculate": 0, "group_workspace": 1}),
     "spec": (0, {"group_lanes": 8, "speculate": 1}),
     "quad16": (0, {"group_lanes": 16}),
+    "row16": (0, {"group_lanes": 16, "speculate": 0}),  # bicycles: sixteen lanes, DPP row broadcasts
     "lane": (1, {}),
     "tiled": (2, {}),
 }
 PLANTS = {
-    "bicycle4": dict(N=[1, 2, 5, 6, 13, 20], dt=[0.25, 1.0], fam=["wave", "group", "group-ws", "spec", "lane", "tiled"]),
-    "bicycle6": dict(N=[2, 7, 20, 31], dt=[0.1, 0.25], fam=["wave", "group", "group-ws", "spec", "lane", "tiled"]),
+    "bicycle4": dict(N=[1, 2, 5, 6, 13, 20], dt=[0.25, 1.0], fam=["wave", "group", "row16", "group-ws", "spec", "lane", "tiled"]),
+    "bicycle6": dict(N=[2, 7, 20, 31], dt=[0.1, 0.25], fam=["wave", "group", "row16", "group-ws", "spec", "lane", "tiled"]),
     "quad12": dict(N=[3, 10, 50], dt=[0.02], fam=["wave", "quad16", "lane", "tiled"]),
 }
 rng = np.random.default_rng(20261003)
