@@ -210,9 +210,9 @@ def waves_of(kernel, B):
     """Main wavefronts of a launch (helper wavefronts not counted)."""
     if kernel == "k_iterate":
         return B
-    if kernel.startswith("k_group_iterate (sixteen") or kernel == "k_quad_iterate":
+    if "(sixteen lanes)" in kernel or kernel == "k_quad_iterate":
         return (B + 3) // 4
-    if kernel.startswith("k_group_iterate") or kernel == "k_group_spec":
+    if kernel.startswith(("k_group_iterate", "k_group_spec")):
         return (B + 7) // 8
     return (B + 63) // 64
 

@@ -143,7 +143,7 @@ namespace {
 
 // Which fused kernel a problem-major call runs on: ONE function, used by the launchers and by
 // i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
-enum FusedKernel { K_WAVE, K_GROUP, K_GROUP16, K_GROUP_WS, K_SPEC, K_QUAD, K_INVALID };
+enum FusedKernel { K_WAVE, K_GROUP, K_GROUP16, K_GROUP_WS, K_SPEC, K_SPEC16, K_QUAD, K_INVALID };
 constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
 constexpr int64_t kAutoSpecBatch = 8192;   // speculative form for solves up to here (automatic)
 
@@ -172,16 +172,20 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     // termination (early_exit) of at most kAutoSpecBatch problems: the launch lasts as long as
     // its slowest problem, and the slowest problems alternate accepts and rejects — i2lqr_solve
     // 0.60 -> 0.44 ms at 16 problems, 1.21 -> 0.71 ms at 1024, 1.23 -> 1.17 at 8192.
-    const bool can_spec = can && group_spec_supported(h->cfg);
+    // (sixteen lanes per problem — the DPP passes, four problems per workgroup — wherever its
+    // buffers fit; "group_lanes" 8 pins the eight-lane form)
+    const bool can_spec16 = group_spec_supported(h->cfg, 16), can_spec8 = group_spec_supported(h->cfg, 8);
+    const bool spec16 = h->opt_group == 16 || (h->opt_group < 0 && can_spec16);
+    const bool can_spec = spec16 ? can_spec16 : can_spec8;
     if (h->opt_spec == 1 && !can_spec) {
-      *why = "\"speculate\" = 1 needs the eight-lane kernel and a horizon whose speculative "
+      *why = "\"speculate\" = 1 needs the eight- / sixteen-lane kernel and a horizon whose speculative "
              "buffers fit the 160 KiB of LDS";
       return K_INVALID;
     }
     if (can_spec && h->opt_group != 64 &&
         (h->opt_spec == 1 ||
          (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
-      return K_SPEC;
+      return spec16 ? K_SPEC16 : K_SPEC;
     // Sixteen lanes per problem (one problem per DPP row; GroupWorker::backward_row): the backward
     // step exchanges its columns by row broadcasts, no LDS round trip in the serial chain.  Four
     // problems per wavefront: automatic while that still leaves every wavefront a SIMD of its own
@@ -315,8 +319,9 @@ template <class T, class Sys> struct Launch {
       case K_INVALID:
         return fail(I2LQR_ERR_UNSUPPORTED, "%s", why);
       case K_SPEC:
+      case K_SPEC16:
         if constexpr (m == 2 && n + m <= 8) {
-          HIP_TRY(group_spec_iterate<T>(h->cfg, a, s));
+          HIP_TRY(group_spec_iterate<T>(h->cfg, a, s, fk == K_SPEC16 ? 16 : 8));
           return I2LQR_OK;
         }
         break;
@@ -1279,6 +1284,7 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
     return h->cfg.system_id == I2LQR_SYS_QUAD12 ? "k_lane_iterate_rows" : "k_lane_iterate";
   switch (select_fused(h, B, early_exit, nullptr)) {
     case K_SPEC: return "k_group_spec";
+    case K_SPEC16: return "k_group_spec (sixteen lanes)";
     case K_GROUP: return "k_group_iterate";
     case K_GROUP16: return "k_group_iterate (sixteen lanes)";
     case K_GROUP_WS: return "k_group_iterate (workspace form)";

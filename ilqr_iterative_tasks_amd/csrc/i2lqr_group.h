@@ -32,15 +32,17 @@ int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B);
 template <class T> hipError_t group_iterate_ws(const i2lqr_config& cfg, const IterArgs<T>& a,
                                                void* ws, hipStream_t stream);
 
-// The speculative form of the eight-lane kernel (k_group_spec: three wavefronts per eight problems,
-// wavefront v runs the iteration that follows v rejects): small batches only.
-bool group_spec_supported(const i2lqr_config& cfg);
+// The speculative form (k_group_spec: V wavefronts per workgroup, wavefront v runs the iteration that
+// follows v rejects): small batches only.  lanes = 8 (eight problems per workgroup, LDS exchanges)
+// or 16 (four problems per workgroup, the DPP passes of the sixteen-lane form: shorter rounds, and
+// three workgroups fit a CU's LDS instead of one).
+bool group_spec_supported(const i2lqr_config& cfg, int lanes);
 template <class T> hipError_t group_spec_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
-                                                 hipStream_t stream);
+                                                 hipStream_t stream, int lanes);
 // The same kernel on the first *a.count (<= a.count_max) columns of a batch-minor work set: the tail
 // of the chunked solves of the one-problem-per-lane layouts (IterArgs::count / set_stride /
 // max_total).  Supported for the plants of the eight-lane kernel with Q = R = 0, whatever the
-// handle's layout is.
+// handle's layout is; sixteen lanes per problem where that fits the LDS.
 bool group_spec_tail_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group_spec_tail(const i2lqr_config& cfg, const IterArgs<T>& a,
                                               hipStream_t stream);

@@ -96,72 +96,80 @@ hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) 
 // 2.34.  Three up to kSpecWideBatch problems where they fit, two above and in the tail.
 constexpr int kSpecWideBatch = 512;
 
-template <class T, class Sys, int V> size_t spec_lds_bytes(int N) {
-  return (size_t)GSpecLayout<Sys, V>(N).group_words() * sizeof(T);
+template <class T, class Sys, int V, int G = kGroup> size_t spec_lds_bytes(int N) {
+  return (size_t)GSpecLayout<Sys, V, G>(N).group_words() * sizeof(T);
 }
 
 // SETIO: a.count_max problems at most (k_group_spec<.., true>, the tail of the chunked solves)
-template <class T, class Sys, int V, bool SETIO>
+template <class T, class Sys, int V, bool SETIO, int G>
 hipError_t launch_spec_v(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
-  const size_t lds = spec_lds_bytes<T, Sys, V>(cfg.N);
-  if (hipError_t e = raise_lds_limit<k_group_spec<T, Sys, V, SETIO>>(lds); e != hipSuccess)
+  const size_t lds = spec_lds_bytes<T, Sys, V, G>(cfg.N);
+  if (hipError_t e = raise_lds_limit<k_group_spec<T, Sys, V, SETIO, G>>(lds); e != hipSuccess)
     return e;
+  constexpr int PW = 64 / G;
   const int64_t problems = SETIO ? (int64_t)a.count_max : a.B;
-  const unsigned grid = (unsigned)((problems + kGroupsPerWave - 1) / kGroupsPerWave);
-  hipLaunchKernelGGL((k_group_spec<T, Sys, V, SETIO>), dim3(grid), dim3(64 * V), lds, s, c, a);
+  const unsigned grid = (unsigned)((problems + PW - 1) / PW);
+  hipLaunchKernelGGL((k_group_spec<T, Sys, V, SETIO, G>), dim3(grid), dim3(64 * V), lds, s, c, a);
   return hipGetLastError();
 }
-template <class T, class Sys, bool SETIO>
+template <class T, class Sys, bool SETIO, int G>
 hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
   const bool wide = !SETIO && a.B <= kSpecWideBatch &&
-                    spec_lds_bytes<T, Sys, 3>(cfg.N) <= 160 * 1024;
-  if (wide) return launch_spec_v<T, Sys, 3, SETIO>(cfg, a, s);
-  return launch_spec_v<T, Sys, 2, SETIO>(cfg, a, s);
+                    spec_lds_bytes<T, Sys, 3, G>(cfg.N) <= 160 * 1024;
+  if (wide) return launch_spec_v<T, Sys, 3, SETIO, G>(cfg, a, s);
+  return launch_spec_v<T, Sys, 2, SETIO, G>(cfg, a, s);
+}
+template <class T, bool SETIO>
+hipError_t launch_spec_any(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s, int lanes) {
+  const bool b4 = cfg.system_id == I2LQR_SYS_BICYCLE4;
+  if (lanes == 16)
+    return b4 ? launch_spec<T, Bicycle4<T>, SETIO, 16>(cfg, a, s)
+              : launch_spec<T, Bicycle6<T>, SETIO, 16>(cfg, a, s);
+  return b4 ? launch_spec<T, Bicycle4<T>, SETIO, kGroup>(cfg, a, s)
+            : launch_spec<T, Bicycle6<T>, SETIO, kGroup>(cfg, a, s);
 }
 
-bool spec_lds_fits(const i2lqr_config& cfg) {  // the two-wavefront form
+template <int G> bool spec_lds_fits(const i2lqr_config& cfg) {  // the two-wavefront form
   const size_t lds = cfg.dtype == I2LQR_F64
-      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>, 2>(cfg.N)
-                                             : spec_lds_bytes<double, Bicycle6<double>, 2>(cfg.N))
-      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>, 2>(cfg.N)
-                                             : spec_lds_bytes<float, Bicycle6<float>, 2>(cfg.N));
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>, 2, G>(cfg.N)
+                                             : spec_lds_bytes<double, Bicycle6<double>, 2, G>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>, 2, G>(cfg.N)
+                                             : spec_lds_bytes<float, Bicycle6<float>, 2, G>(cfg.N));
   return lds <= 160 * 1024;
+}
+bool spec_plant_ok(const i2lqr_config& cfg) {
+  if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
+  return !has_stage_weights(cfg);
 }
 
 }  // namespace
 
-bool group_spec_supported(const i2lqr_config& cfg) {
-  return group_supported(cfg) && spec_lds_fits(cfg);
+bool group_spec_supported(const i2lqr_config& cfg, int lanes) {
+  if (!spec_plant_ok(cfg) || cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return false;
+  return lanes == 16 ? spec_lds_fits<16>(cfg) : (group_supported(cfg) && spec_lds_fits<kGroup>(cfg));
 }
-bool group_spec_tail_supported(const i2lqr_config& cfg) {
-  if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
-  return !has_stage_weights(cfg) && spec_lds_fits(cfg);
+int group_spec_tail_lanes(const i2lqr_config& cfg) {
+  if (!spec_plant_ok(cfg)) return 0;
+  return spec_lds_fits<16>(cfg) ? 16 : (spec_lds_fits<kGroup>(cfg) ? kGroup : 0);
 }
+bool group_spec_tail_supported(const i2lqr_config& cfg) { return group_spec_tail_lanes(cfg) != 0; }
 
 template <> hipError_t group_spec_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
-                                                  hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
-    return launch_spec<double, Bicycle4<double>, false>(cfg, a, s);
-  return launch_spec<double, Bicycle6<double>, false>(cfg, a, s);
+                                                  hipStream_t s, int lanes) {
+  return launch_spec_any<double, false>(cfg, a, s, lanes);
 }
 template <> hipError_t group_spec_iterate<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
-                                                 hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
-    return launch_spec<float, Bicycle4<float>, false>(cfg, a, s);
-  return launch_spec<float, Bicycle6<float>, false>(cfg, a, s);
+                                                 hipStream_t s, int lanes) {
+  return launch_spec_any<float, false>(cfg, a, s, lanes);
 }
 template <> hipError_t group_spec_tail<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
                                                hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
-    return launch_spec<double, Bicycle4<double>, true>(cfg, a, s);
-  return launch_spec<double, Bicycle6<double>, true>(cfg, a, s);
+  return launch_spec_any<double, true>(cfg, a, s, group_spec_tail_lanes(cfg));
 }
 template <> hipError_t group_spec_tail<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
                                               hipStream_t s) {
-  if (cfg.system_id == I2LQR_SYS_BICYCLE4)
-    return launch_spec<float, Bicycle4<float>, true>(cfg, a, s);
-  return launch_spec<float, Bicycle6<float>, true>(cfg, a, s);
+  return launch_spec_any<float, true>(cfg, a, s, group_spec_tail_lanes(cfg));
 }
 
 bool group16_supported(const i2lqr_config& cfg) {

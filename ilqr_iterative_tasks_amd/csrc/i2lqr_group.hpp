@@ -1248,9 +1248,10 @@ __global__ __launch_bounds__(64 * H) void k_group_iterate(const DevCfg<T, Sys::n
 // its gains and exchange buffer.  Workgroup barriers: after the record phase and after the
 // forward pass.
 // ---------------------------------------------------------------------------------------------
-template <class Sys, int V> struct GSpecLayout {
+template <class Sys, int V, int G = kGroup> struct GSpecLayout {
   static constexpr int n = Sys::n, m = Sys::m, W = n + m, NT = Sys::NTRIG;
-  using GL = GLayout<Sys>;
+  static constexpr int PW = 64 / G;  // problems per workgroup
+  using GL = GLayout<Sys, G>;
   int N;
   int traj_words, R, var0, var_words, Kk_in_var, T1c_in_var, total;
   __host__ __device__ explicit GSpecLayout(int N_) : N(N_) {
@@ -1261,7 +1262,11 @@ template <class Sys, int V> struct GSpecLayout {
     var0 = o;
     Kk_in_var = 0;
     T1c_in_var = (m * GL::KW * N + 3) & ~3;
-    var_words = (T1c_in_var + kGroup * 2 * ((W + 1) / 2) + 3) & ~3;  // [row pair][column][2]
+    // eight lanes: the T1 exchange buffer [row pair][column][2] behind the gains; sixteen lanes
+    // (DPP broadcasts, no exchange buffer): one gain row of slack, which the look-ahead load of
+    // the forward pass's last step reads (GroupWorker::forward_row)
+    var_words = G == kGroup ? (T1c_in_var + kGroup * 2 * ((W + 1) / 2) + 3) & ~3
+                            : (T1c_in_var + m * GL::KW + 3) & ~3;
     o += V * var_words;
     if (((o / 4) & 1) == 0) o += 4;
     total = o;
@@ -1269,28 +1274,29 @@ template <class Sys, int V> struct GSpecLayout {
   __host__ __device__ int xu_off(int b) const { return b * traj_words; }
   __host__ __device__ int tr_off(int b) const { return b * traj_words + ((W * (N + 1) + 3) & ~3); }
   // + Q_terminal + the V x 8 candidate costs of a round + the rollout cost
-  __host__ __device__ int group_words() const { return kGroupsPerWave * total + n * n + (V + 1) * kGroupsPerWave; }
+  __host__ __device__ int group_words() const { return PW * total + n * n + (V + 1) * PW; }
 };
 
 // SETIO: the problems are the first *a.count columns of a batch-minor, time-major work set (the
 // tail of the chunked solve of the one-problem-per-lane layouts, see IterArgs and k_iterate): the
 // launch does nothing unless *count <= count_max, the iteration counters continue from iters[] and
 // stop at max_total.
-template <class T, class Sys, int V, bool SETIO = false>
+template <class T, class Sys, int V, bool SETIO = false, int G = kGroup>
 __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, Sys::m> c,
                                                        const IterArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
-  using GL = GLayout<Sys>;
-  using SL = GSpecLayout<Sys, V>;
+  using GL = GLayout<Sys, G>;
+  using SL = GSpecLayout<Sys, V, G>;
+  constexpr int PW = SL::PW;
   extern __shared__ __align__(16) unsigned char gsmem_raw[];
   T* smem = reinterpret_cast<T*>(gsmem_raw);
   const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int p = lane / kGroup, g = lane % kGroup;
-  const int64_t prob0 = (int64_t)blockIdx.x * kGroupsPerWave + p;
+  const int p = lane / G, g = lane % G;
+  const int64_t prob0 = (int64_t)blockIdx.x * PW + p;
   int64_t live = a.B;
   if constexpr (SETIO) {
     live = *a.count;
-    if (live > a.count_max || (int64_t)blockIdx.x * kGroupsPerWave >= live) return;  // block-uniform
+    if (live > a.count_max || (int64_t)blockIdx.x * PW >= live) return;  // block-uniform
   }
   const int64_t Bs = SETIO ? a.set_stride : 0;
   const bool real = prob0 < live;
@@ -1298,18 +1304,18 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   const SL SLay(c.N);
   const int N = c.N;
   T* const S = smem + p * SLay.total;
-  T* const QtL = smem + kGroupsPerWave * SLay.total;
+  T* const QtL = smem + PW * SLay.total;
   T* const CN = QtL + n * n;  // [V + 1][8]: candidate cost of wavefront v / rollout cost at row V
-  GroupWorker<T, Sys> w(c, S, QtL, g, SLay.total);
+  GroupWorker<T, Sys, false, G> w(c, S, QtL, g, SLay.total);
   w.oR = SLay.R;
   w.oKk = SLay.var0 + v * SLay.var_words + SLay.Kk_in_var;
-  w.T1c = S + SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;
+  if constexpr (G == kGroup) w.T1c = S + SLay.var0 + v * SLay.var_words + SLay.T1c_in_var;
 
   // entry (wavefront 0): x0, U into buffer 0, Q_terminal; nominal rollout
   if (v == 0) {
     if constexpr (SETIO) {  // work-set rows: x_t[i] is row t n + i of X, u_t[a] row t m + a of U
       if (g < n) S[SLay.xu_off(0) + g] = a.X[g * Bs + prob];
-      for (int e = g; e < m * N; e += kGroup) {
+      for (int e = g; e < m * N; e += G) {
         const int t = e / m, aa = e - t * m;
         S[SLay.xu_off(0) + t * W + n + aa] = a.U[e * Bs + prob];
       }
@@ -1317,7 +1323,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
       const T* gX = a.X + prob * (int64_t)(n * (N + 1));
       if (g < n) S[SLay.xu_off(0) + g] = gX[g * (N + 1)];
       const T* gU = a.U + prob * (int64_t)(m * N);
-      for (int e = g; e < m * N; e += kGroup) {
+      for (int e = g; e < m * N; e += G) {
         const int aa = e / N, t = e - aa * N;
         S[SLay.xu_off(0) + t * W + n + aa] = gU[e];
       }
@@ -1337,10 +1343,10 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   __syncthreads();
   if (v == 0) {
     const T c0 = w.rollout(SLay.xu_off(0), SLay.tr_off(0), xT);
-    if (g == 0) CN[V * kGroupsPerWave + p] = c0;
+    if (g == 0) CN[V * PW + p] = c0;
   }
   __syncthreads();
-  T cost = CN[V * kGroupsPerWave + p];
+  T cost = CN[V * PW + p];
 
   // which buffer is the nominal, which is wavefront k's candidate (identical in every wavefront)
   int nb = 0, cb[V];
@@ -1351,7 +1357,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   bool fresh = true, active = it_cap > 0;
   while (__any(active)) {
     if (__any(fresh)) {
-      w.prep(SLay.xu_off(nb), SLay.tr_off(nb), ob, ob_pa, ob_pb, v * kGroup + g, V * kGroup);
+      w.prep(SLay.xu_off(nb), SLay.tr_off(nb), ob, ob_pa, ob_pb, v * G + g, V * G);
       __syncthreads();
     }
     // this wavefront's iteration: the one that follows v rejects
@@ -1366,7 +1372,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
     bool big = false;
     T cost_new = w.template forward<false>(XUo, XUn, TRn, xT, &big);
     if (__builtin_expect(__any(big), 0)) cost_new = w.template forward<true>(XUo, XUn, TRn, xT, &big);
-    if (g == 0) CN[v * kGroupsPerWave + p] = cost_new;
+    if (g == 0) CN[v * PW + p] = cost_new;
     __syncthreads();
     // resolve the chain: control/iterative_ilqr.py:74-84 for iteration it, it + 1, ...
     fresh = false;
@@ -1374,7 +1380,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
 #pragma unroll
     for (int k = 0; k < V; k++) {
       if (chain) {
-        const T cn = CN[k * kGroupsPerWave + p];
+        const T cn = CN[k * PW + p];
         it++;
         gsel = k;
         if (cn < cost) {
@@ -1407,17 +1413,17 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   // exit (wavefront 0): X, U from the nominal buffer, the gains of the last executed iteration
   if (real && v == 0 && SETIO) {
     const int XUo = SLay.xu_off(nb);
-    for (int e = g; e < n * (N + 1); e += kGroup) {
+    for (int e = g; e < n * (N + 1); e += G) {
       const int t = e / n, i = e - t * n;
       a.X[e * Bs + prob] = S[XUo + t * W + i];
     }
-    for (int e = g; e < m * N; e += kGroup) {
+    for (int e = g; e < m * N; e += G) {
       const int t = e / m, aa = e - t * m;
       a.U[e * Bs + prob] = S[XUo + t * W + n + aa];
     }
     if (a.K) {  // K rows (t m + a) n + j, k rows t m + a
       const int oK = SLay.var0 + gsel * SLay.var_words + SLay.Kk_in_var;
-      for (int e = g; e < m * N * (n + 1); e += kGroup) {
+      for (int e = g; e < m * N * (n + 1); e += G) {
         const int r = e / (n + 1), j = e - r * (n + 1);
         const T val = S[oK + r * GL::KW + j];
         if (j < n) a.K[((int64_t)r * n + j) * Bs + prob] = val;
@@ -1434,24 +1440,24 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   if (real && v == 0 && !SETIO) {
     const int XUo = SLay.xu_off(nb);
     T* gX = a.X + prob * (int64_t)(n * (N + 1));
-    for (int e = g; e < n * (N + 1); e += kGroup) {
+    for (int e = g; e < n * (N + 1); e += G) {
       const int i = e / (N + 1), t = e - i * (N + 1);
       gX[e] = S[XUo + t * W + i];
     }
     T* gU = a.U + prob * (int64_t)(m * N);
-    for (int e = g; e < m * N; e += kGroup) {
+    for (int e = g; e < m * N; e += G) {
       const int aa = e / N, t = e - aa * N;
       gU[e] = S[XUo + t * W + n + aa];
     }
     if (a.K) {
       const int oK = SLay.var0 + gsel * SLay.var_words + SLay.Kk_in_var;
       T* gK = a.K + prob * (int64_t)(m * n * N);
-      for (int e = g; e < m * n * N; e += kGroup) {
+      for (int e = g; e < m * n * N; e += G) {
         const int aa = e / (n * N), r = e - aa * (n * N), j = r / N, t = r - j * N;
         gK[e] = S[oK + (t * m + aa) * GL::KW + j];
       }
       T* gk = a.k + prob * (int64_t)(m * N);
-      for (int e = g; e < m * N; e += kGroup) {
+      for (int e = g; e < m * N; e += G) {
         const int aa = e / N, t = e - aa * N;
         gk[e] = S[oK + (t * m + aa) * GL::KW + n];
       }

@@ -854,25 +854,36 @@ def test_quad12_sixteen_lane_kernel_vs_oracle_and_wave_kernel(torch_mod, B, iter
 
 
 def test_solves_to_termination_speculate_automatically(torch_mod):
-    """i2lqr_solve of a small batch runs on the speculative eight-lane kernel (three wavefronts per
-    eight problems up to 512 problems, two above) without being asked to, bit for bit the plain
-    eight-lane kernel; the chunked solves of the lane layouts finish their survivors with it and
-    agree with the one-problem-per-wavefront tail to the solve tolerance."""
+    """i2lqr_solve of a small batch runs on the speculative kernel (three wavefronts per workgroup up
+    to 512 problems, two above) without being asked to — in its sixteen-lane form (four problems per
+    workgroup, the DPP passes), bit for bit the plain sixteen-lane kernel; pinned to eight lanes, bit
+    for bit the plain eight-lane kernel; the chunked solves of the lane layouts finish their
+    survivors with it and agree with the one-problem-per-wavefront tail to the solve tolerance."""
     torch = torch_mod
     from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
     cfg = default_config("bicycle6", 20, "f64", dt=0.25)
     for B in (5, 100, 1000, 2500):
         host = workloads.make_batch(cfg, B)
         auto = BatchedILQR(cfg)
-        assert auto.solve_kernel(B) == "k_group_spec"
+        assert auto.solve_kernel(B) == "k_group_spec (sixteen lanes)"
         assert auto.iterate_kernel(B) == ("k_group_iterate (sixteen lanes)" if B >= 1024 else "k_iterate")
-        plain = BatchedILQR(cfg)
-        plain.set_option("group_lanes", 8)
-        plain.set_option("speculate", 0)
-        assert plain.solve_kernel(B) == "k_group_iterate"
-        a, b = auto.solve(dev_batch(auto, host)), plain.solve(dev_batch(plain, host))
-        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
-            assert torch.equal(a[key], b[key]), (B, key)
+        a = auto.solve(dev_batch(auto, host))
+        for lanes, spec_name, plain_name in ((16, "k_group_spec (sixteen lanes)", "k_group_iterate (sixteen lanes)"),
+                                             (8, "k_group_spec", "k_group_iterate")):
+            plain = BatchedILQR(cfg)
+            plain.set_option("group_lanes", lanes)
+            plain.set_option("speculate", 0)
+            assert plain.solve_kernel(B) == plain_name
+            b = plain.solve(dev_batch(plain, host))
+            forced = BatchedILQR(cfg)
+            forced.set_option("group_lanes", lanes)
+            forced.set_option("speculate", 1)
+            assert forced.solve_kernel(B) == spec_name
+            f = forced.solve(dev_batch(forced, host))
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(f[key], b[key]), (B, lanes, key)
+                if lanes == 16:
+                    assert torch.equal(a[key], b[key]), (B, key)
         assert B < 100 or int(a["iters"].max()) > 12  # the batch has stragglers to speculate on
     # tail of the chunked solve (batch-tiled layout): speculative tail against the wave-kernel tail
     cfg = default_config("bicycle6", 20, "f64", dt=0.25, layout=2)
