@@ -1250,7 +1250,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "checkpoint_states")) h->opt_ckpt = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "stagger")) h->opt_stagger = v;
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
-  else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 8192 ? 8192 : v);
+  else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 65536 ? 65536 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "debug_self_test")) {

@@ -205,8 +205,8 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     stays: the forward pass needs only its k_0 (x_0 is common to the nominal
  *                     and the candidate trajectory, K_0 multiplies zeros).
  *   "wave_tail"       chunked solve (i2lqr_set_compaction) only: once a compaction leaves at most
- *                     this many running problems (<= 8192), they are finished by the speculative
- *                     eight-lane kernel ("speculate"; the one-problem-per-wavefront kernel where
+ *                     this many running problems (<= 65536), they are finished by the speculative
+ *                     kernel ("speculate"; the one-problem-per-wavefront kernel where
  *                     that is not built), whose iteration latency is ~2.8x lower.  Same
  *                     algorithm, different summation order: results agree with the single launch
  *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
