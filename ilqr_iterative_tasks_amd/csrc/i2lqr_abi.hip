@@ -186,10 +186,12 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
         (h->opt_spec == 1 ||
          (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
       return spec16 ? K_SPEC16 : K_SPEC;
-    // Sixteen lanes per problem (one problem per DPP row; GroupWorker::backward_row): the backward
-    // step exchanges its columns by row broadcasts, no LDS round trip in the serial chain.  Four
-    // problems per wavefront: automatic while that still leaves every wavefront a SIMD of its own
-    // (kAutoGroupBatch ... kGroup16Batch problems); "group_lanes" 16 / 8 pins the choice.
+    // Sixteen lanes per problem (one problem per DPP row; GroupWorker::backward_row / forward_row):
+    // no LDS round trip in the serial chains.  Four problems per wavefront: automatic for every
+    // batch that still leaves each wavefront a SIMD of its own (up to kGroup16Batch problems) —
+    // its iteration is shorter than the one-problem-per-wavefront kernel's at ANY size (0.145
+    // against 0.188 ms per 10 iterations from 1 to 512 problems, n = 6, N = 20; tools/_diag);
+    // "group_lanes" 16 / 8 / 64 pins the choice.
     const bool can16 = group16_supported(h->cfg);  // (four slices: longer horizons than `can`)
     if (h->opt_group == 16 && !can16) {
       *why = "\"group_lanes\" = 16 needs a bicycle plant with Q = R = 0 and a horizon whose four "
@@ -197,7 +199,7 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
       return K_INVALID;
     }
     if (h->opt_group == 16 ||
-        (h->opt_group < 0 && can16 && B >= kAutoGroupBatch && B <= kGroup16Batch))
+        (h->opt_group < 0 && can16 && B <= kGroup16Batch))
       return K_GROUP16;
     if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
       // more than 4096 problems (two wavefronts per CU are full): the workspace form, four

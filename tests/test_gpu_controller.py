@@ -293,7 +293,7 @@ def test_sharded_calc_input_two_ranks_share_the_gpu():
 def test_candidate_solver_reaches_the_lane_kernels_through_the_product_surface():
     """HipCandidateSolver (the surface calc_input()/solve() batch through) asks the LIBRARY for the
     layout (i2lqr_recommended_layout): 65536 candidates of one control round run on the
-    one-problem-per-lane kernels, 64 on the latency kernels — no threshold on the caller's side.
+    one-problem-per-lane kernels, 2048 or 64 on the sixteen-lane latency kernel — no threshold on the caller's side.
     candidate_round() keeps the round on the device: relaxed costs, flat pick and the winner's
     trajectory, checked against the same candidates on the problem-major kernels."""
     import torch
@@ -302,7 +302,8 @@ def test_candidate_solver_reaches_the_lane_kernels_through_the_product_surface()
     cfg = default_config("bicycle6", 20, "f64", dt=0.25)
     hs = HipCandidateSolver()
     for B, kernel, layout in ((65536, "k_lane_iterate", 2), (16385, "k_lane_iterate", 1),
-                              (2048, "k_group_iterate (sixteen lanes)", 0), (64, "k_iterate", 0)):
+                              (2048, "k_group_iterate (sixteen lanes)", 0),
+                              (64, "k_group_iterate (sixteen lanes)", 0)):
         host = workloads.make_batch(cfg, B)
         x0 = torch.as_tensor(host["X"][0, :, 0]).cuda()
         x_terms = torch.as_tensor(host["x_term"]).cuda()

@@ -734,11 +734,11 @@ def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
         for lanes in (64, 8, 16, -1):
             solver.set_option("group_lanes", lanes)
             out[lanes] = (solver.iterate(dev_batch(solver, host), 7), solver.solve(dev_batch(solver, host)))
-        # the automatic choice: sixteen lanes per problem from 1024 to 4096 problems
-        auto = 16 if B >= 1024 else 64
-        if B >= 1024:
-            assert solver.iterate_kernel(B) == "k_group_iterate (sixteen lanes)"
-            assert solver.iterate_kernel(4097) == "k_group_iterate"
+        # the automatic choice: sixteen lanes per problem up to 4096 problems (where its four slices
+        # fit the LDS: bicycle4 at N = 50 does), eight lanes above
+        auto = 16
+        assert solver.iterate_kernel(B) == "k_group_iterate (sixteen lanes)"
+        assert solver.iterate_kernel(4097) == "k_group_iterate"  # eight lanes above 4096 problems
         for a, b in zip(out[auto], out[-1]):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, key)
@@ -866,7 +866,7 @@ def test_solves_to_termination_speculate_automatically(torch_mod):
         host = workloads.make_batch(cfg, B)
         auto = BatchedILQR(cfg)
         assert auto.solve_kernel(B) == "k_group_spec (sixteen lanes)"
-        assert auto.iterate_kernel(B) == ("k_group_iterate (sixteen lanes)" if B >= 1024 else "k_iterate")
+        assert auto.iterate_kernel(B) == "k_group_iterate (sixteen lanes)"
         a = auto.solve(dev_batch(auto, host))
         for lanes, spec_name, plain_name in ((16, "k_group_spec (sixteen lanes)", "k_group_iterate (sixteen lanes)"),
                                              (8, "k_group_spec", "k_group_iterate")):

@@ -1,16 +1,16 @@
 #!/bin/bash
 # One-shot refresh of profiles/ on the GPU box (run from the repo root through gpurun):
 #   per workload:  rocprofv3 --kernel-trace --stats           -> kstats_<workload>.csv
-#                  rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ cycle counters | SQ instruction counters
-#                  (four SEPARATE passes, never combined with traces: MI355X_MICROARCH.md §HBM)
+#                  rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ cycle counters | SQ instruction counters |
+#                  fp64 instruction counters (five SEPARATE passes, never combined with traces: MI355X_MICROARCH.md §HBM)
 #   then           summarise (tools/summarise_profiles.py) -> pmc_traffic.json stamped with the
 #                  sha256 of the library the counters were collected on
 #                  bench.py JSON line + kernel stats of the bench command itself
 # Results land in gpurun_out/profiles_new/ — copy them into profiles/ afterwards.
-#   bash tools/collect_profiles.sh [round tag, default r03]
+#   bash tools/collect_profiles.sh [round tag, default r04]
 set -u
 ROOT=$(pwd)
-TAG=${1:-r03}
+TAG=${1:-r04}
 NEW=$ROOT/gpurun_out/profiles_new
 RAW=$ROOT/gpurun_out/prof_raw
 rm -rf "$NEW" "$RAW"; mkdir -p "$NEW" "$RAW"
@@ -31,6 +31,7 @@ config5_f64_B65536   config5 f64 65536   tiled 4  16
 "
 SQ_CYC="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES"
 SQ_INS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH"
+SQ_F64="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64"
 target() { echo python3 $ROOT/tools/pmc_target.py --workload $1 --dtype $2 --batch $3 --layout $4 --iters $5 --launches $6; }
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d "$RAW/calib_$ctr" -- python3 $ROOT/tools/pmc_calib.py \
@@ -49,6 +50,8 @@ echo "$WORKLOADS" | while read name wl dt b lay it ln; do
     > "$RAW/${name}_SQCYC.log" 2>&1
   rocprofv3 --pmc $SQ_INS --output-format csv -d "$RAW/${name}_SQINS" -- $(target $wl $dt $b $lay $it $ln) \
     > "$RAW/${name}_SQINS.log" 2>&1
+  rocprofv3 --pmc $SQ_F64 --output-format csv -d "$RAW/${name}_SQF64" -- $(target $wl $dt $b $lay $it $ln) \
+    > "$RAW/${name}_SQF64.log" 2>&1
   echo "collected $name"
 done
 # solves to termination (kernel traces only): the speculative eight-lane kernel at 1024 problems,

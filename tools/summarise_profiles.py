@@ -88,6 +88,18 @@ for d in sorted(glob.glob(f"{raw}/*_kstats")):
         for (kn, c), v in counters(f"{raw}/{name}_{part}/**/*counter_collection.csv").items():
             if "iterate" in kn:
                 sq[c] = avg(v)
+    # fifth pass: fp64 arithmetic instructions by kind -> EXECUTED flops per launch (64 lanes per
+    # wavefront-instruction, a multiply-add counted as two; an upper bound where lanes are masked)
+    f64 = {}
+    for (kn, c), v in counters(f"{raw}/{name}_SQF64/**/*counter_collection.csv").items():
+        if "iterate" in kn:
+            f64[c] = avg(v)
+    if f64:
+        rawrec["sq_f64"] = f64
+        rec["executed_fp64_flops_per_launch"] = 64.0 * (
+            2.0 * f64.get("SQ_INSTS_VALU_FMA_F64", 0) + f64.get("SQ_INSTS_VALU_ADD_F64", 0) +
+            f64.get("SQ_INSTS_VALU_MUL_F64", 0) + f64.get("SQ_INSTS_VALU_TRANS_F64", 0))
+        rec["executed_fp64_flops_per_problem_iteration"] = rec["executed_fp64_flops_per_launch"] / (B * iters)
     rawrec["sq"] = sq
     if sq.get("SQ_WAVE_CYCLES"):
         wc = sq["SQ_WAVE_CYCLES"]
@@ -96,7 +108,7 @@ for d in sorted(glob.glob(f"{raw}/*_kstats")):
             "issuing_valu": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc,
             "parked_on_waitcnt_or_barrier": sq.get("SQ_WAIT_ANY", 0) / wc,
             "issue_stalled": sq.get("SQ_WAIT_INST_ANY", 0) / wc}
-    ins = {k: v for k, v in sq.items() if k.startswith("SQ_INSTS_")}
+    ins = {k: v for k, v in sq.items() if k.startswith("SQ_INSTS_") and "F64" not in k}
     if ins:
         rec["wave_instructions_by_type"] = ins
         rec["wave_instructions_per_launch"] = sum(ins.values())
