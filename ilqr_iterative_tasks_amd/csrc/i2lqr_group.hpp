@@ -288,6 +288,15 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
 #pragma unroll
       for (int a = 0; a < m; a++) off_lu[a] = GL::R_LU + a;
     }
+    if constexpr (G == 16) {
+      // Sixteen-lane form: the lane's own T1 column enters its H column with coefficient ONE on
+      // every lane (columns 0 and 1 included: their identity entry is the "own" term here, not a
+      // broadcast of the column to itself with a coefficient 1 read from the record), so the step
+      // starts from h = t1 without a multiply.  Lanes past the gradient column carry zeros.
+      own = T(1);
+      if (g == 0) off_c0 = GL::R_ZERO;
+      if (g == 1) off_c1 = GL::R_ZERO;
+    }
   }
 
   __device__ __forceinline__ T terminal_cost(const T (&x)[n], const T (&xT)[n]) const {
@@ -730,7 +739,7 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
         constexpr int R = sizeof(hr) / sizeof(T);
         T src[R];
 #pragma unroll
-        for (int a = 0; a < R; a++) { src[a] = t1[r0 + a]; hr[a] = own * t1[r0 + a]; }
+        for (int a = 0; a < R; a++) { src[a] = t1[r0 + a]; hr[a] = t1[r0 + a]; }  // own = 1
         bcast_fmac<0>(hr, src, rc.c0);
         bcast_fmac<1>(hr, src, rc.c1);
         static_for_i<2, n>([&](auto r_) {
