@@ -60,13 +60,16 @@ class HipCandidateSolver:
             self._round_bufs[key] = (solver.alloc(B, want_gains=False),
                                      torch.zeros(B, dtype=solver.dtype, device=solver.device))
         buf, cost_it = self._round_bufs[key]
-        solver.set_initial_state(buf, x0, lamb0)
+        solver.set_initial_state(buf, x0, lamb0, zero_states=False)  # (the buffer starts zeroed)
         buf["x_term"].copy_(solver.to_native(x_terms.to(solver.device, solver.dtype)))
-        if obs_rec is not None:
-            rec = torch.as_tensor(np.asarray(obs_rec, float)).to(solver.device, solver.dtype)
-            buf["obs"] = solver.to_native(rec[None, :].expand(B, -1).contiguous())
-        else:
-            buf["obs"] = None
+        obs_key = None if obs_rec is None else tuple(float(v) for v in obs_rec)
+        if buf.get("_obs_key", ()) != obs_key:  # the round's obstacle record, shared by its candidates
+            if obs_rec is not None:
+                rec = torch.as_tensor(np.asarray(obs_rec, float)).to(solver.device, solver.dtype)
+                buf["obs"] = solver.to_native(rec[None, :].expand(B, -1).contiguous())
+            else:
+                buf["obs"] = None
+            buf["_obs_key"] = obs_key
         qfun = qfun.to(solver.device, torch.int32)
         if n_iters is None:
             solver.solve(buf)

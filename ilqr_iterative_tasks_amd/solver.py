@@ -187,12 +187,17 @@ class BatchedILQR:
             raise I2lqrError(f"i2lqr error {rc}: {lib.i2lqr_last_error().decode()}")
         return rc
 
-    def set_initial_state(self, buf: dict, x0: torch.Tensor, lamb0: float | None = None) -> None:
+    def set_initial_state(self, buf: dict, x0: torch.Tensor, lamb0: float | None = None,
+                          zero_states: bool = True) -> None:
         """Candidates of one control round share the current state: X[:, :, 0] = x0, X elsewhere
         and U zero (utils/base.py:405-408), lamb = lamb0 (:393) — written in this solver's layout
-        (fills and one strided copy: no arithmetic)."""
+        (fills and one strided copy: no arithmetic).  zero_states=False leaves X[:, :, 1:] as it
+        is: every solver entry point rolls the states out from X[:, :, 0] and U before it reads
+        them (control/iterative_ilqr.py:32-42), so a caller that reuses a buffer round after round
+        saves the fill of the largest array."""
         X = buf["X"]
-        X.zero_()
+        if zero_states:
+            X.zero_()
         buf["U"].zero_()
         x0 = x0.to(self.device, self.dtype)
         if self.batch_tiled:
