@@ -166,12 +166,13 @@ def spawn_ranks(args) -> int:
 #   16384: 1.80 vs 1.81 ms, 65536: 5.6 vs 2.5 ms
 # The kernel's launch duration is measured live with HIP events on the launch stream around
 # KERNEL_SAMPLES evenly spaced timed steps (an event pair around EVERY launch costs the timed region
-# 5 us per 220 us step in marker packets): 10 samples at the driver's --steps 20 and at the default
-# 200 alike.  The cost of an EMPTY event pair (measured after the timed region, smallest of 30) is
+# 5 us per step in marker packets, 3 % of a 0.136 ms step): 10 samples at the driver's --steps 20,
+# 20 at the default 200.  The cost of an EMPTY event pair (measured after the timed region, smallest of 30) is
 # subtracted: the two marker packets themselves sit inside the bracket, and at 0.2 ms per launch
 # they are 5 % of it (rocprofv3's kernel duration, profiles/, is the check).  Secondary workloads:
 # EXTRA_LAUNCHES individually bracketed launches after EXTRA_WARMUP, median and spread reported.
-KERNEL_SAMPLES = 10
+KERNEL_SAMPLES = 10       # at fewer than 100 timed steps (the driver's --steps 20: every second step)
+KERNEL_SAMPLES_LONG = 20  # from 100 timed steps
 LONG_RUN_STEPS = 200  # --gpus N > 1: a second timed loop of this many steps ("long_run")
 EXTRA_LAUNCHES = 20
 EXTRA_WARMUP = 3
@@ -252,7 +253,7 @@ def make_step_buffers(solver, host, n_sets, torch):
 
 
 def event_stride_for(steps):
-    return max(1, steps // KERNEL_SAMPLES)
+    return max(1, steps // (KERNEL_SAMPLES_LONG if steps >= 100 else KERNEL_SAMPLES))
 
 
 def empty_bracket_ms(torch, n=30):

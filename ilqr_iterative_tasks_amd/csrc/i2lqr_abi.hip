@@ -1209,23 +1209,31 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
     return fail(I2LQR_ERR_INVALID, "config struct_size %d, library expects %zu", cfg->struct_size,
                 sizeof(i2lqr_config));
   if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
-  // what the lane layouts cannot run stays problem-major: stage weights, non-symmetric weights,
-  // quad12 in fp32
-  bool lane_ok = true;
-  for (int i = 0; i < cfg->n && lane_ok; i++)
-    for (int j = 0; j < cfg->n; j++)
-      if (cfg->Q[i * I2LQR_MAX_N + j] != 0.0 ||
-          cfg->Qt[i * I2LQR_MAX_N + j] != cfg->Qt[j * I2LQR_MAX_N + i]) { lane_ok = false; break; }
-  for (int a = 0; a < cfg->m && lane_ok; a++)
-    for (int b = 0; b < cfg->m; b++)
-      if (cfg->R[a * I2LQR_MAX_M + b] != 0.0) { lane_ok = false; break; }
+  // what the lane layouts cannot run stays problem-major: non-symmetric weights (the kernels keep
+  // the upper triangles), and for quad12 (row-block kernel) stage weights and fp32
+  bool lane_ok = true, weights = false;
+  for (int i = 0; i < cfg->n; i++)
+    for (int j = 0; j < cfg->n; j++) {
+      if (cfg->Q[i * I2LQR_MAX_N + j] != 0.0) weights = true;
+      if (cfg->Q[i * I2LQR_MAX_N + j] != cfg->Q[j * I2LQR_MAX_N + i] ||
+          cfg->Qt[i * I2LQR_MAX_N + j] != cfg->Qt[j * I2LQR_MAX_N + i]) lane_ok = false;
+    }
+  for (int a = 0; a < cfg->m; a++)
+    for (int b = 0; b < cfg->m; b++) {
+      if (cfg->R[a * I2LQR_MAX_M + b] != 0.0) weights = true;
+      if (cfg->R[a * I2LQR_MAX_M + b] != cfg->R[b * I2LQR_MAX_M + a]) lane_ok = false;
+    }
   int64_t from;
   switch (cfg->system_id) {
     case I2LQR_SYS_BICYCLE4:
-    case I2LQR_SYS_BICYCLE6: from = early_exit ? kLaneBatchSolve : kLaneBatchIterate; break;
+    case I2LQR_SYS_BICYCLE6:
+      // with stage weights the problem-major side is the one-problem-per-wavefront kernel (the
+      // column kernels are built for Q = R = 0): 1024 problems already fill the chip's SIMDs
+      from = weights ? 2048 : (early_exit ? kLaneBatchSolve : kLaneBatchIterate);
+      break;
     case I2LQR_SYS_QUAD12:
       from = kLaneBatchQuad;
-      if (cfg->dtype != I2LQR_F64) lane_ok = false;
+      if (cfg->dtype != I2LQR_F64 || weights) lane_ok = false;
       break;
     default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
   }

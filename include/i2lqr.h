@@ -138,8 +138,9 @@ int i2lqr_destroy(i2lqr_handle* h);
  * 16384 for solves to termination (early_exit 1: i2lqr_solve); quad12 (fp64) from 8192.
  * Returns I2LQR_LAYOUT_BATCH_TILED where B is a multiple of 64, I2LQR_LAYOUT_BATCH_MINOR otherwise,
  * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for configurations the lane kernels do not
- * run (stage weights Q, R != 0, non-symmetric terminal weights, quad12 in fp32); < 0 on a bad
- * argument.  cfg->layout itself is not read.  The reference has no counterpart (one NumPy layout).
+ * run (non-symmetric weights; quad12 with stage weights Q, R != 0 or in fp32); the bicycles with
+ * stage weights cross over at 2048 problems (their problem-major side is the
+ * one-problem-per-wavefront kernel); < 0 on a bad argument.  cfg->layout itself is not read.  The reference has no counterpart (one NumPy layout).
  * Inside the problem-major layout the library picks the kernel per call (i2lqr_iterate_kernel).
  */
 int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit);
