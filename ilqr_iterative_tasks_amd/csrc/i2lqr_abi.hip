@@ -198,21 +198,25 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
              "problem slices fit the 160 KiB of LDS";
       return K_INVALID;
     }
+    // Beyond one round of 1024 wavefronts the sixteen-lane kernel runs in rounds (0.168 ms per 4096
+    // problems); the eight-lane workspace form (four wavefronts of eight problems per CU) is the
+    // better choice only between 4096 and kGroupWsTop problems — and only with the caller's
+    // workspace registered.
+    const int64_t need = can ? group_workspace_bytes(h->cfg, B) : 0;
+    const bool have_ws = need > 0 && h->ws && h->ws_bytes >= need;
+    const bool ws_range = B > kGroupWsBatch && B <= kGroupWsTop;
     if (h->opt_group == 16 ||
-        (h->opt_group < 0 && can16 && B <= kGroup16Batch))
+        (h->opt_group < 0 && can16 && h->opt_group_ws != 1 && !(ws_range && can && have_ws)))
       return K_GROUP16;
     if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
-      // more than 4096 problems (two wavefronts per CU are full): the workspace form, four
-      // wavefronts per CU, whenever the caller's workspace is registered ("group_workspace" 0 / 1
-      // pins the choice)
-      const int64_t need = group_workspace_bytes(h->cfg, B);
-      const bool have_ws = need > 0 && h->ws && h->ws_bytes >= need;
+      // "group_workspace" 0 / 1 pins the choice of the eight-lane form
       if (h->opt_group_ws == 1 && !have_ws) {
         *why = "\"group_workspace\" = 1 needs a registered workspace of i2lqr_workspace_bytes() "
                "for this batch";
         return K_INVALID;
       }
-      if (have_ws && (h->opt_group_ws == 1 || (h->opt_group_ws < 0 && B > kGroupWsBatch)))
+      if (have_ws && (h->opt_group_ws == 1 ||
+                      (h->opt_group_ws < 0 && (ws_range || (h->opt_group == 8 && B > kGroupWsBatch)))))
         return K_GROUP_WS;
       return K_GROUP;
     }
@@ -1169,7 +1173,10 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
     if (h->cfg.system_id == I2LQR_SYS_QUAD12) return quad_workspace_bytes(h->cfg, B);
     // the bicycles: the workspace form of the eight-lane kernel, above kGroupWsBatch problems
     // (or whenever it is pinned); nothing below
-    return (B > kGroupWsBatch || h->opt_group_ws == 1) ? group_workspace_bytes(h->cfg, B) : 0;
+    // (only in the range where that form is the automatic choice, or when it is pinned: a
+    // problem-major batch of 2^20 problems does not need 5.9 GB of scratch it would never use)
+    return ((B > kGroupWsBatch && (B <= kGroupWsTop || h->opt_group == 8)) || h->opt_group_ws == 1)
+               ? group_workspace_bytes(h->cfg, B) : 0;
   }
   const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
   const int N = h->cfg.N;
@@ -1195,11 +1202,12 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
 
 // Batch sizes from which the one-problem-per-lane layouts win over the problem-major kernels
 // (tools/ab_bench.py, tools/solve_bench.py, interleaved on one device; fp64, n=6, N=20):
-//   iterate: 8192: 260 (eight-lane workspace form) vs 146 M it/s (lane), 12288: 216 vs 223,
-//            16384: 285 lane;   solve: 8192: 1.17 vs 1.68 ms, 16384: 1.80 vs 1.30 ms;
+//   iterate (round 4): 12288: 245 (sixteen-lane kernel, three rounds of 4096) vs 217 M it/s
+//            (lane), 14336: 223 vs 250, 16384: 249 vs 286;   solve: 8192: 0.73 vs 1.68 ms,
+//            16384: 1.80 vs 1.03 ms;
 //   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
 //   8192 and 73 M at 65536.
-constexpr int64_t kLaneBatchIterate = 10240;
+constexpr int64_t kLaneBatchIterate = 12289;
 constexpr int64_t kLaneBatchSolve = 16384;
 constexpr int64_t kLaneBatchQuad = 8192;
 

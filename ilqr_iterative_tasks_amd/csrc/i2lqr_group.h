@@ -18,7 +18,8 @@ template <class T> hipError_t group_iterate(const i2lqr_config& cfg, const IterA
 // The same column scheme with SIXTEEN lanes per problem — one problem per 16-lane DPP row, four per
 // wavefront — whose backward step exchanges columns by DPP row broadcasts instead of LDS round trips
 // (i2lqr_group.hpp: GroupWorker::backward_row): the latency form, for batches that leave every
-// wavefront a SIMD of its own (up to kGroup16Batch problems).
+// wavefront a SIMD of its own (up to kGroup16Batch problems = one round of 1024 wavefronts), and —
+// in rounds of kGroup16Batch — wherever whole rounds beat the other forms (above kGroupWsTop).
 constexpr int64_t kGroup16Batch = 4096;
 bool group16_supported(const i2lqr_config& cfg);
 template <class T> hipError_t group16_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
@@ -28,6 +29,11 @@ template <class T> hipError_t group16_iterate(const i2lqr_config& cfg, const Ite
 // group_workspace_bytes() for B problems: 4 KB of LDS per problem, four wavefronts per CU): the
 // choice above kGroupWsBatch problems.  0 bytes if the configuration is not supported.
 constexpr int64_t kGroupWsBatch = 4096;
+// ... up to kGroupWsTop problems: the LDS form of the sixteen-lane kernel runs in rounds of 4096
+// problems (0.168 ms each), the workspace form's time grows with the batch (0.25 ms + 25 us per
+// 1024 problems): 5120 problems 0.285 against 0.330 ms, 6144: 0.306 / 0.339, 8192: 0.354 / 0.348,
+// 12288: 0.583 / 0.502, 20480: 0.872 / 0.804 (tools/_diag/mid_check.py).
+constexpr int64_t kGroupWsTop = 7168;
 int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B);
 template <class T> hipError_t group_iterate_ws(const i2lqr_config& cfg, const IterArgs<T>& a,
                                                void* ws, hipStream_t stream);

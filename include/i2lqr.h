@@ -134,7 +134,7 @@ int i2lqr_destroy(i2lqr_handle* h);
  * the layouts are different kernel FAMILIES — problem-major runs one problem per 64, 16 or 8 lanes
  * (latency kernels: up to ~10^4 problems), batch-minor / batch-tiled run one problem per lane (the
  * HBM-bound throughput kernels) — and the crossover is measured, not derivable by a caller:
- * bicycles from 10240 problems for fixed iteration counts (early_exit 0: i2lqr_iterate) and from
+ * bicycles above 12288 problems for fixed iteration counts (early_exit 0: i2lqr_iterate) and from
  * 16384 for solves to termination (early_exit 1: i2lqr_solve); quad12 (fp64) from 8192.
  * Returns I2LQR_LAYOUT_BATCH_TILED where B is a multiple of 64, I2LQR_LAYOUT_BATCH_MINOR otherwise,
  * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for configurations the lane kernels do not

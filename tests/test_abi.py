@@ -109,10 +109,10 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     lib = _abi.load_library()
     ask = lambda cfg, B, ee=0: lib.i2lqr_recommended_layout(C.byref(cfg), B, ee)
     b6 = _abi.default_config("bicycle6", 20)
-    assert [ask(b6, B) for B in (1, 1024, 4096, 10239)] == [0, 0, 0, 0]
-    assert [ask(b6, B) for B in (10240, 65536, 1 << 20)] == [2, 2, 2]      # multiples of 64: tiled
-    assert ask(b6, 10241) == 1 and ask(b6, 65537) == 1                      # ragged: batch-minor
-    assert ask(b6, 10240, 1) == 0 and ask(b6, 16384, 1) == 2                # solves cross over later
+    assert [ask(b6, B) for B in (1, 1024, 4096, 12288)] == [0, 0, 0, 0]
+    assert [ask(b6, B) for B in (12352, 65536, 1 << 20)] == [2, 2, 2]      # multiples of 64: tiled
+    assert ask(b6, 12289) == 1 and ask(b6, 65537) == 1                      # ragged: batch-minor
+    assert ask(b6, 12352, 1) == 0 and ask(b6, 16384, 1) == 2                # solves cross over later
     q = _abi.default_config("quad12", 50)
     assert [ask(q, B) for B in (64, 8191, 8192, 65536)] == [0, 0, 2, 2]
     q32 = _abi.default_config("quad12", 50, "f32")

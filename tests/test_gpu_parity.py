@@ -738,7 +738,7 @@ def test_group_kernel_selection_and_agreement_with_the_wave_kernel(torch_mod):
         # fit the LDS: bicycle4 at N = 50 does), eight lanes above
         auto = 16
         assert solver.iterate_kernel(B) == "k_group_iterate (sixteen lanes)"
-        assert solver.iterate_kernel(4097) == "k_group_iterate"  # eight lanes above 4096 problems
+        assert solver.iterate_kernel(4097) == "k_group_iterate (sixteen lanes)"  # (no workspace registered)
         for a, b in zip(out[auto], out[-1]):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, key)
@@ -1256,12 +1256,16 @@ def test_eight_lane_workspace_form_is_bit_identical(torch_mod):
         for a, b in zip(res[0], res[1]):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, B, key)
+    # automatic: the sixteen-lane kernel (rounds of 4096 problems) except between 4097 and 7168
+    # problems with the workspace registered, where the eight-lane workspace form is ahead
     auto = BatchedILQR(default_config("bicycle6", 20, "f64", dt=0.25))
-    assert auto.iterate_kernel(8192) == "k_group_iterate"  # no workspace registered yet
-    auto.ensure_workspace(8192)
-    assert auto.iterate_kernel(8192) == "k_group_iterate (workspace form)"
+    assert auto.iterate_kernel(6144) == "k_group_iterate (sixteen lanes)"  # no workspace registered yet
+    auto.ensure_workspace(6144)
+    assert auto.iterate_kernel(6144) == "k_group_iterate (workspace form)"
     assert auto.iterate_kernel(4096) == "k_group_iterate (sixteen lanes)"
     assert auto.iterate_kernel(4097) == "k_group_iterate (workspace form)"
+    assert auto.iterate_kernel(8192) == "k_group_iterate (sixteen lanes)"
+    assert int(auto.lib.i2lqr_workspace_bytes(auto._handle, 8192)) == 0  # nothing to allocate there
 
 
 def test_inputs_outside_the_benchmark_distribution_vs_oracle(torch_mod, layout):
