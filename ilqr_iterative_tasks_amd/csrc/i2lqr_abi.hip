@@ -145,7 +145,7 @@ namespace {
 // i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
 enum FusedKernel { K_WAVE, K_GROUP, K_GROUP16, K_GROUP_WS, K_SPEC, K_SPEC16, K_QUAD, K_INVALID };
 constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
-constexpr int64_t kAutoSpecBatch = 8192;   // speculative form for solves up to here (automatic)
+constexpr int64_t kAutoSpecBatch = 12288;  // speculative form for solves up to here (automatic)
 
 // *why: the message of K_INVALID (a forced option the configuration cannot honour)
 FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, const char** why) {
@@ -1203,12 +1203,13 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
 // Batch sizes from which the one-problem-per-lane layouts win over the problem-major kernels
 // (tools/ab_bench.py, tools/solve_bench.py, interleaved on one device; fp64, n=6, N=20):
 //   iterate (round 4): 12288: 245 (sixteen-lane kernel, three rounds of 4096) vs 217 M it/s
-//            (lane), 14336: 223 vs 250, 16384: 249 vs 286;   solve: 8192: 0.73 vs 1.68 ms,
-//            16384: 1.80 vs 1.03 ms;
+//            (lane), 14336: 223 vs 250, 16384: 249 vs 286;   solve (sixteen-lane speculative
+//            kernel vs chunked lane solve): 8192: 0.74 vs 0.97 ms, 12288: 0.95 vs 1.01,
+//            16384: 1.21 vs 1.04 ms;
 //   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
 //   8192 and 73 M at 65536.
 constexpr int64_t kLaneBatchIterate = 12289;
-constexpr int64_t kLaneBatchSolve = 16384;
+constexpr int64_t kLaneBatchSolve = 12289;
 constexpr int64_t kLaneBatchQuad = 8192;
 
 int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit) {

@@ -134,8 +134,8 @@ int i2lqr_destroy(i2lqr_handle* h);
  * the layouts are different kernel FAMILIES — problem-major runs one problem per 64, 16 or 8 lanes
  * (latency kernels: up to ~10^4 problems), batch-minor / batch-tiled run one problem per lane (the
  * HBM-bound throughput kernels) — and the crossover is measured, not derivable by a caller:
- * bicycles above 12288 problems for fixed iteration counts (early_exit 0: i2lqr_iterate) and from
- * 16384 for solves to termination (early_exit 1: i2lqr_solve); quad12 (fp64) from 8192.
+ * bicycles above 12288 problems (fixed iteration counts, early_exit 0: i2lqr_iterate, and solves to
+ * termination, early_exit 1: i2lqr_solve, alike); quad12 (fp64) from 8192.
  * Returns I2LQR_LAYOUT_BATCH_TILED where B is a multiple of 64, I2LQR_LAYOUT_BATCH_MINOR otherwise,
  * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for configurations the lane kernels do not
  * run (non-symmetric weights; quad12 with stage weights Q, R != 0 or in fp32); the bicycles with
@@ -244,7 +244,7 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     nothing is gained as soon as one problem of the batch never rejects (0.275
  *                     vs 0.215 ms per 10 iterations at 1024 problems).  Automatic: on for
  *                     early-exit calls (i2lqr_solve, i2lqr_iterate with early_exit) of at most
- *                     8192 problems where built, and for the <= "wave_tail" survivors of the
+ *                     12288 problems where built, and for the <= "wave_tail" survivors of the
  *                     chunked solves of the lane layouts; off for fixed iteration counts.
  *                     0: never; 1: always (I2LQR_ERR_UNSUPPORTED where not built).
  *   "per_step_jacobians"  ("group_lanes" 64)  1: the [A | B] matrices of all horizon steps (systems/kinetic_bicycle.py:

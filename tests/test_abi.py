@@ -112,7 +112,7 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     assert [ask(b6, B) for B in (1, 1024, 4096, 12288)] == [0, 0, 0, 0]
     assert [ask(b6, B) for B in (12352, 65536, 1 << 20)] == [2, 2, 2]      # multiples of 64: tiled
     assert ask(b6, 12289) == 1 and ask(b6, 65537) == 1                      # ragged: batch-minor
-    assert ask(b6, 12352, 1) == 0 and ask(b6, 16384, 1) == 2                # solves cross over later
+    assert ask(b6, 12288, 1) == 0 and ask(b6, 12352, 1) == 2                # solves: the same crossover
     q = _abi.default_config("quad12", 50)
     assert [ask(q, B) for B in (64, 8191, 8192, 65536)] == [0, 0, 2, 2]
     q32 = _abi.default_config("quad12", 50, "f32")
