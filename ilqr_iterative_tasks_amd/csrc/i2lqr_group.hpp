@@ -651,16 +651,17 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
       T dx[n];
 #pragma unroll
       for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
+      // column g of 2 Qt by a per-lane LDS address (lanes past the columns read column 0 and drop
+      // it) instead of a chain of selects over the whole matrix — the block was 400 instructions
+      // per iteration; the gradient 2 Qt (x_N - x_T) in the same operation order as before
+      const int gq = g < n ? g : 0;
 #pragma unroll
       for (int i = 0; i < n; i++) {
-        T vxx = T(0), vx = T(0);
+        T vx = T(0);
 #pragma unroll
-        for (int r = 0; r < n; r++) {
-          const T q = T(2) * Qt[i * n + r];
-          vxx = (g == r) ? q : vxx;
-          vx += q * dx[r];
-        }
-        va[i] = (g == n) ? vx : vxx;
+        for (int r = 0; r < n; r++) vx += (T(2) * Qt[i * n + r]) * dx[r];
+        const T vxx = T(2) * Qt[i * n + gq];
+        va[i] = (g == n) ? vx : (g < n ? vxx : T(0));
       }
       va[0] += Rn[off_l0];
       va[1] += Rn[off_l1];
