@@ -86,8 +86,16 @@ def host_group(group=None):
     key = id(group) if group is not None else None
     if key not in _host_groups:
         ranks = dist.get_process_group_ranks(group) if group is not None else None
-        _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        try:
+            _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        except Exception:  # noqa: BLE001  (no gloo transport on this node)
+            # every rank fails the same way (the call is collective): the agreement then runs on
+            # the group itself, with device tensors — the pre-round-4 behaviour
+            _host_groups[key] = DEVICE_CHANNEL
     return _host_groups[key]
+
+
+DEVICE_CHANNEL = "device-channel"  # host_group(): no host-side transport, use the group itself
 
 
 def _agree(flags, hgroup) -> list[bool]:
@@ -97,8 +105,12 @@ def _agree(flags, hgroup) -> list[bool]:
     if hgroup is None:
         return flags
     t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hgroup)
-    return [bool(int(v)) for v in t]
+    if hgroup is DEVICE_CHANNEL:
+        t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hgroup)
+    return [bool(int(v)) for v in t.cpu()]
 
 
 class CostExchangeUnavailable(RuntimeError):
@@ -188,7 +200,9 @@ class CostExchange:
             except Exception as e:  # noqa: BLE001
                 err = e
         box = [payload]
-        if hg is not None:
+        if hg is DEVICE_CHANNEL:
+            dist.broadcast_object_list(box, src=0)
+        elif hg is not None:
             dist.broadcast_object_list(box, src=dist.get_process_group_ranks(hg)[0], group=hg)
         if not box[0]:
             raise CostExchangeUnavailable(f"rank 0 could not create the RCCL unique id ({err or 'see rank 0'})")
@@ -213,7 +227,9 @@ class CostExchange:
         # from a common point on every rank
         if torch.device(solver.device).type == "cuda":
             torch.cuda.synchronize(solver.device)
-        if hg is not None:
+        if hg is DEVICE_CHANNEL:
+            dist.barrier()
+        elif hg is not None:
             dist.barrier(group=hg)
 
     def _create(self, uid: bytes, comm, timeout: float):
