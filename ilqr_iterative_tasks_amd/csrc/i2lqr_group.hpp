@@ -629,7 +629,6 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
     return bad;
   }
 
-
   // -- backward pass, sixteen lanes per problem (G = 16): the same column ownership — lane j < n
   //    holds column j of [Vxx | Vx] and forms column j of H, lane n the gradient column, lanes
   //    above n idle along — but NO LDS exchange in the step: a problem is one 16-lane DPP row, and
@@ -639,8 +638,9 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
   //      Quu[a][b] = l_uu + sum_k B[k][b] T1[n+a][k]
   //      Va'[i][g] = H[i][g] - sum_a K[a][i] (Quu [K|k][:, g])[a],  K[:, i] = lane i's gain column
   //    so the gain columns are not exchanged through LDS either: every lane stores its column for
-  //    the forward pass and nothing waits for the store.  ~135 instructions per step in chains the ALU latency
-  //    bounds, against 175 and two LDS round trips (2 x 108 cycles + 20 16-byte reads).
+  //    the forward pass and nothing waits for the store.  130 instructions per step at the issue
+  //    rate of a lone wavefront (683 cycles), against 150 and two LDS round trips (2 x 108 cycles
+  //    + 20 16-byte reads; 1293 cycles) with eight lanes per problem.
   template <bool GENERAL>
   __device__ __forceinline__ bool backward_row(int XUo, const T (&xT)[n], T lamb, bool commit) const {
     static_assert(GL::KW > n + 1, "the padding word of a gain row takes the stores of idle lanes");
@@ -652,8 +652,8 @@ template <class T, class Sys, bool WS = false, int G = kGroup> struct GroupWorke
 #pragma unroll
       for (int i = 0; i < n; i++) dx[i] = S[XUo + N * W + i] - xT[i];
       // column g of 2 Qt by a per-lane LDS address (lanes past the columns read column 0 and drop
-      // it) instead of a chain of selects over the whole matrix — the block was 400 instructions
-      // per iteration; the gradient 2 Qt (x_N - x_T) in the same operation order as before
+      // it) instead of a chain of selects over the whole matrix; the gradient 2 Qt (x_N - x_T) in
+      // the same operation order as the other kernel families
       const int gq = g < n ? g : 0;
 #pragma unroll
       for (int i = 0; i < n; i++) {
