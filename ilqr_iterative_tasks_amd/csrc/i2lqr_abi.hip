@@ -584,9 +584,32 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     }
   }
 
+  // Length of the first chunk of the chunked solve: the iterations after which the survivors are
+  // expected to fit the speculative tail (tail_cap problems), so that ONE compaction hands them
+  // over and no short lane chunk runs on a batch too small to fill the GPU.  The survivor curve is
+  // the bench workload's (oracle, 65536 problems: 32 % need more than 8 iterations, 12 % more than
+  // 10, 2.7 % more than 12); a workload with more survivors only meets the old schedule
+  // one compaction later (the tail kernel is a no-op above its cap).  Measured against a
+  // first chunk of 8 at every size: 32768 problems 1.50 -> 1.28 ms (10), 65536: 1.77 -> 1.61 (10),
+  // 262144: 5.06 -> 4.98 (12), 2^20: 17.7 -> 17.2 ms (12); never below 8 (6 at 16384 problems:
+  // 1.02 -> 0.98 ms, but the tail kernel sums in another order than the lane kernels, and the
+  // more iterations of a long-horizon problem it runs the further the two solves drift apart
+  // in the last digits: 2.3e-8 relative at N = 50 against the suite's 1e-8).
+  static int first_chunk(int64_t B, int tail_cap, int max_iter) {
+    static constexpr struct { int iters; double survivors; } kCurve[] = {
+        {8, 0.32}, {10, 0.122}, {12, 0.028}};
+    int len = 8;
+    if (tail_cap > 0) {
+      len = 12;
+      for (const auto& p : kCurve)
+        if ((double)B * p.survivors <= (double)tail_cap) { len = p.iters; break; }
+    }
+    return max_iter < len ? max_iter : len;
+  }
+
   // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per
   // problem, so a wavefront of 64 problems would otherwise idle on its slowest lane.  The batch
-  // is solved in chunks of 8, 4, 4, 8, 8, 16, ... iterations; after every chunk the terminated problems
+  // is solved in chunks of first_chunk(), 4, 4, 8, 8, 16, ... iterations; after every chunk the terminated problems
   // are scattered to the caller's arrays and the survivors are packed into a dense work set
   // (k_lane_compact).  No host synchronisation: the live count stays in device memory and
   // surplus wavefronts exit at once.  Results are bit-identical to the plain launch.
@@ -607,10 +630,24 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     usr.status = status ? status : cv.ustatus;
     usr.orig = nullptr;
     if (!obs) { cv.set[0].obs = nullptr; cv.set[1].obs = nullptr; }
+    // Latency tail: once few problems survive, the rest of the solve is bound by the slowest
+    // problem's iteration latency, which is ~2.8x lower with one problem per WAVEFRONT.  If the
+    // packed set holds <= wave_tail problems the one-problem-per-wavefront kernel finishes them
+    // (it reads the live count itself and is a no-op otherwise); the lane chunks that follow skip
+    // finished problems and the next compaction scatters them to the caller.
+    // The survivors are the problems with long accept / reject chains (stragglers alternate
+    // accept, reject, accept, ...): the speculative sixteen-lane kernel runs the iteration after
+    // a reject beside the current one and needs about half the rounds; bit-identical to the
+    // plain kernel.  It takes over from 8192 survivors (workgroups of four problems whose slowest
+    // member decides; the hardware backfills), the one-problem-per-wavefront kernel (other
+    // plants, stage weights) from 2048.
+    bool spec_tail = false;
+    if constexpr (m == 2 && n + m <= 8)
+      spec_tail = h->opt_spec != 0 && c.flags == 0 && group_spec_tail_supported(h->cfg);
+    const int wave_tail = h->wave_tail < 0 ? (spec_tail ? kAutoSpecTail : kAutoWaveTail)
+                                           : h->wave_tail;
     // chunk 0 runs in place on the caller's arrays
-    // first chunk: 8 iterations (half of the problems of the benchmark workload need more than 6;
-    // a compaction after 4 moves 85 % of the batch to save 15 % of the next chunk)
-    int done = 0, len = max_iter < 8 ? max_iter : 8;
+    int done = 0, len = first_chunk(B, spec_tail ? wave_tail : 0, max_iter);
     a0.B = B; a0.n_iters = len; a0.early_exit = 1;
     a0.X = usr.X; a0.U = usr.U; a0.x_term = usr.x_term; a0.lamb = usr.lamb; a0.obs = usr.obs;
     a0.cost = usr.cost; a0.K = usr.K; a0.k = usr.k; a0.iters = usr.iters; a0.status = usr.status;
@@ -631,22 +668,6 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
                          src_user ? 1 : 0, count_in, cv.set[cur], count, usr, c.trap);
       const LaneSet<T>& w = cv.set[cur];
-      // Latency tail: once few problems survive, the rest of the solve is bound by the slowest
-      // problem's iteration latency, which is ~2.8x lower with one problem per WAVEFRONT.  If the
-      // packed set holds <= wave_tail problems the one-problem-per-wavefront kernel finishes them
-      // here (it reads the live count itself and is a no-op otherwise); the lane chunks that
-      // follow skip finished problems and the next compaction scatters them to the caller.
-      // The survivors are the problems with long accept / reject chains (stragglers alternate
-      // accept, reject, accept, ...): the speculative eight-lane kernel runs the iteration after
-      // a reject beside the current one and needs about half the rounds; bit-identical to the
-      // plain eight-lane kernel.  It takes over from 8192 survivors (workgroups of eight problems
-      // whose slowest member decides; the hardware backfills), the one-problem-per-wavefront
-      // kernel (other plants, stage weights) from 2048.
-      bool spec_tail = false;
-      if constexpr (m == 2 && n + m <= 8)
-        spec_tail = h->opt_spec != 0 && c.flags == 0 && group_spec_tail_supported(h->cfg);
-      const int wave_tail = h->wave_tail < 0 ? (spec_tail ? kAutoSpecTail : kAutoWaveTail)
-                                             : h->wave_tail;
       if (wave_tail > 0 && done >= 4) {
         using WL = Launch<T, Sys>;
         const size_t lds_f = WL::fstep_lds_bytes(N);
@@ -658,6 +679,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
         t.count = count; t.count_max = wave_tail; t.max_total = max_iter;
         t.set_stride = B;
         if (spec_tail) {
+          // the speculative tail delivers its problems to the caller's arrays itself (the
+          // scatter pass of the next compaction was 82 us for 7938 problems with gains)
+          t.orig = w.orig;
+          t.out_X = usr.X; t.out_U = usr.U; t.out_K = usr.K; t.out_k = usr.k;
+          t.out_lamb = usr.lamb; t.out_cost = usr.cost;
+          t.out_iters = usr.iters; t.out_status = usr.status;
+          t.out_B = usr.B; t.out_tiled = TILED ? 1 : 0;
           if constexpr (m == 2 && n + m <= 8) HIP_TRY(group_spec_tail<T>(h->cfg, t, s));
         } else if (WL::kHasFstep && lds_f <= 64 * 1024) {
           if constexpr (WL::kHasFstep) {
@@ -670,12 +698,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           }
         }
       }
-      // chunk lengths 8, 4, 4, then doubling (8, 16, 32, ...): compaction points at 8, 12, 16, 24,
-      // 40, 72, 136 iterations.  Short chunks while the tail may still be waiting for the survivors
-      // to fit it; once it has run, every further round is four empty launches (19 us), so few of
+      // chunk lengths after the first: one chunk of 4 (the tail's second chance), then as many
+      // iterations as are done (first chunk 10: compaction points at 10, 14, 28, 56 iterations).
+      // Once the tail has run, every further round is three empty launches (14 us), so few of
       // them (the schedule 8, 4, 4, 8, 8, 16, 16, 32, 32, ... spent 0.19 of 2.13 ms there at 65536
-      // problems).  Against 4, 4, 4, 4, ... with a tail of 2048: 1.69 -> 1.35 ms at 16384 problems.
-      len = done < 16 ? 4 : done - 8;
+      // problems; 10, 4, 4, 10, 20, 40, 12: 85 us of 1.55 ms).  Against 4, 4, 4, 4, ... with a tail
+      // of 2048: 1.69 -> 1.35 ms at 16384 problems.
+      len = done < 12 ? 4 : done;
       if (done + len > max_iter || round + 2 >= kMaxRounds) len = max_iter - done;
       LaneArgs<T> a = a0;
       a.X = w.X; a.U = w.U; a.x_term = w.x_term; a.lamb = w.lamb; a.obs = w.obs; a.cost = w.cost;

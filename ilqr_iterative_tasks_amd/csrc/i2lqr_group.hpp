@@ -1422,29 +1422,49 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
 
   // exit (wavefront 0): X, U from the nominal buffer, the gains of the last executed iteration
   if (real && v == 0 && SETIO) {
+    // to the work set (column prob, row stride Bs), or straight to the caller's arrays (a.orig)
+    const bool deliver = a.orig != nullptr;
+    const int64_t o = deliver ? (int64_t)a.orig[prob] : prob;
+    const int64_t ot = (o >> 6) * 64, ol = o & 63;
+    auto at = [&](int rows, int64_t row) -> int64_t {
+      if (!deliver) return row * Bs + prob;
+      return a.out_tiled ? (ot * rows + row * 64 + ol) : (row * a.out_B + o);
+    };
+    T* const dX = deliver ? a.out_X : a.X;
+    T* const dU = deliver ? a.out_U : a.U;
+    T* const dK = deliver ? a.out_K : a.K;
+    T* const dk = deliver ? a.out_k : a.k;
     const int XUo = SLay.xu_off(nb);
     for (int e = g; e < n * (N + 1); e += G) {
       const int t = e / n, i = e - t * n;
-      a.X[e * Bs + prob] = S[XUo + t * W + i];
+      dX[at(n * (N + 1), e)] = S[XUo + t * W + i];
     }
     for (int e = g; e < m * N; e += G) {
       const int t = e / m, aa = e - t * m;
-      a.U[e * Bs + prob] = S[XUo + t * W + n + aa];
+      dU[at(m * N, e)] = S[XUo + t * W + n + aa];
     }
-    if (a.K) {  // K rows (t m + a) n + j, k rows t m + a
+    if (dK) {  // K rows (t m + a) n + j, k rows t m + a
       const int oK = SLay.var0 + gsel * SLay.var_words + SLay.Kk_in_var;
       for (int e = g; e < m * N * (n + 1); e += G) {
         const int r = e / (n + 1), j = e - r * (n + 1);
         const T val = S[oK + r * GL::KW + j];
-        if (j < n) a.K[((int64_t)r * n + j) * Bs + prob] = val;
-        else a.k[(int64_t)r * Bs + prob] = val;
+        if (j < n) dK[at(m * n * N, (int64_t)r * n + j)] = val;
+        else dk[at(m * N, r)] = val;
       }
     }
     if (g == 0) {
-      a.lamb[prob] = lamb;
-      a.cost[prob] = cost_ret;
-      if (a.iters) a.iters[prob] = it0 + it;
-      if (a.status) a.status[prob] = status;
+      if (deliver) {
+        a.out_lamb[o] = lamb;
+        a.out_cost[o] = cost_ret;
+        if (a.out_iters) a.out_iters[o] = it0 + it;
+        if (a.out_status) a.out_status[o] = status;
+        a.status[prob] = status | kStatusDelivered;
+      } else {
+        a.lamb[prob] = lamb;
+        a.cost[prob] = cost_ret;
+        if (a.iters) a.iters[prob] = it0 + it;
+        if (a.status) a.status[prob] = status;
+      }
     }
   }
   if (real && v == 0 && !SETIO) {

@@ -1946,6 +1946,7 @@ __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneS
   const int st = src.status[i];
   if (st != 0) {
     if (src_is_user) return;  // already in place
+    if (st & kStatusDelivered) return;  // the tail kernel wrote it to the caller's arrays itself
     const int64_t o = src.orig[i];
     move_rows(rx, [&](int r, T v) { usr.X[uaddr(rx, r, o)] = v; },
               [&](int r) { return src.X[(int64_t)r * src.B + i]; });

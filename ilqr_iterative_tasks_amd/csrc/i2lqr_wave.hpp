@@ -61,6 +61,9 @@ template <class T> __device__ __forceinline__ bool better(T v, int64_t i, T bv, 
   return v < bv || (v == bv && i < bi);
 }
 
+// flag on a work set's status word: the problem's results are already in the caller's arrays
+constexpr int kStatusDelivered = 0x100;
+
 template <class T> struct IterArgs {
   int64_t B;
   int n_iters;    // iterations to run (iterate) / max iterations (solve)
@@ -83,6 +86,21 @@ template <class T> struct IterArgs {
   const int32_t* count;
   int count_max, max_total;
   int64_t set_stride;
+  // SETIO, optional (orig non-null): a finished problem goes straight to the caller's arrays —
+  // problem orig[prob] of out_B, time-major rows like the work set's, batch-tiled or batch-minor —
+  // and is marked kStatusDelivered in the work set's status: the compaction that follows has
+  // nothing left to move for it (k_lane_compact).
+  const int32_t* orig = nullptr;
+  T* out_X = nullptr;
+  T* out_U = nullptr;
+  T* out_K = nullptr;   // null: the caller did not ask for gains
+  T* out_k = nullptr;
+  T* out_lamb = nullptr;
+  T* out_cost = nullptr;
+  int32_t* out_iters = nullptr;
+  int32_t* out_status = nullptr;
+  int64_t out_B = 0;
+  int out_tiled = 0;
   // Optional epilogue of the eight-lane kernels (i2lqr_iterate_pick): the relaxed terminal cost of
   // every candidate (utils/base.py:427-437) from the x_N the kernel still holds, and the flat
   // first-index arg-min over them (:462-465) by a last-workgroup-done reduction — one launch per
