@@ -914,6 +914,21 @@ def run_rank(args) -> int:
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "dtype": "f64",
             "B65536": timed(args.workload, "f64", 65536, args.iters),
             "B131072": timed(args.workload, "f64", 131072, args.iters)}
+        # ilqr() to termination (1..98 iterations per problem) is what the reference actually
+        # calls (control/iterative_ilqr.py:7-85): executed iterations per second of one solve of
+        # 65536 problems against the fixed-count rate of the same batch; where the solve's time
+        # goes by kernel comes from the kernel trace under profiles/ (same library only)
+        rs = run_solve(args, workloads.config_for(args.workload, "f64"), 65536, torch, reps=5)
+        fixed = out["roofline_large_batch"]["B65536"]["iterations_per_s"]
+        rs.update({"batch": 65536, "dtype": "f64", "fixed_count_iterations_per_s": fixed,
+                   "frac_of_fixed_count_rate": rs["executed_iterations_per_s"] / fixed,
+                   "kernel_time_shares": pmc.get("solve:f64:B65536", "kernel_time_shares"),
+                   "kernels_ms_per_solve": pmc.get("solve:f64:B65536", "kernels_ms_per_solve"),
+                   "note": "kernel_time_shares: rocprofv3 kernel trace of 10 solves "
+                           "(profiles/<round>_kstats_solve_f64_B65536.csv); k_group_spec is the "
+                           "speculative tail that finishes the stragglers, k_lane_iterate the "
+                           "first chunk of the whole batch"})
+        out["roofline_solve"] = rs
         # BASELINE configs[4]: quadrotor-sized n=12, m=4, N=50, B=65536, fp64 (33912 algorithmic
         # bytes and 600 k algorithmic flops per iteration); 4 fused iterations per launch
         q = timed("config5", "f64", 65536, 4)
@@ -943,8 +958,9 @@ def run_rank(args) -> int:
         # problem is done, so this is below the fixed-count rate.  Default = chunked solve with
         # compaction and the one-problem-per-wavefront tail; single launch beside it.
         f64 = workloads.config_for(args.workload, "f64")
-        for sb in (1024, 4096, 16384, 65536):
+        for sb in (1024, 4096, 16384):
             extra[f"solve_to_termination_B{sb}_f64"] = run_solve(args, f64, sb, torch)
+        extra["solve_to_termination_B65536_f64"] = "see roofline_solve"
         extra["solve_to_termination_B65536_f64_single_launch"] = run_solve(
             args, f64, 65536, torch, single_launch=True)
     if extra:

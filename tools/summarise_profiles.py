@@ -54,8 +54,26 @@ out = {"_meta": {"lib_sha256": hashlib.sha256(LIB.read_bytes()).hexdigest(),
 full = {"_meta": out["_meta"]}
 for d in sorted(glob.glob(f"{raw}/*_kstats")):
     name = Path(d).name[: -len("_kstats")]
-    if name == "bench" or name.startswith("solve"):
-        continue  # kernel traces only
+    if name.startswith("solve"):
+        # solves to termination (kernel traces only): where the time of one solve goes, by kernel
+        B = int(name.split("_B")[1])
+        fam = defaultdict(float)
+        launches = 10  # collect_profiles.sh: --launches 10
+        for f in glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "i2lqr::" in r["Name"]:
+                    fam[r["Name"].split("<")[0].replace("void ", "").replace("i2lqr::", "")] += \
+                        float(r["TotalDurationNs"])
+        tot = sum(fam.values())
+        if tot:
+            rec = {"kernels_ms_per_solve": tot / launches / 1e6,
+                   "kernel_time_shares": {k: v / tot for k, v in sorted(fam.items())}}
+            out[f"solve:f64:B{B}"] = rec
+            full[f"solve:f64:B{B}"] = rec
+            print(f"solve:f64:B{B}", json.dumps(rec))
+        continue
+    if name == "bench":
+        continue  # kernel trace only
     wl, dt, bb = name.split("_")
     B = int(bb[1:])
     iters = 4 if wl == "config5" else 10
