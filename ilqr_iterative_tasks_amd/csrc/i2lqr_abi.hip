@@ -497,8 +497,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.defer = 1;  // the forward pass stores no states; accepted steps re-roll them (see i2lqr_lane.hpp)
     // ... and merge the accepted candidate inputs into the one input buffer.  fp64 (HBM-bound):
     // 7.56 -> 7.23 KB per problem-iteration, +4.8 % it/s at 2^20 problems; fp32 (instruction-bound):
-    // the extra row writes cost 6 %, so the per-lane buffer swap stays (tools/ab_bench.py).
-    a.merge = sizeof(T) == 8 ? 1 : 0;
+    // the extra row writes cost 6 %, so the per-lane buffer swap stays (tools/ab_bench.py).  Below
+    // ~40000 problems the fp64 kernel is instruction-bound as well (one or two wavefronts per CU):
+    // 226 -> 237 M it/s at 12800 problems without the merge, 411 -> 426 at 24576, 528 -> 545 at
+    // 32768, +-0 from 40960 to 57344, 811 -> 846 WITH it at 65536.
+    a.merge = sizeof(T) == 8 && B > 32768 ? 1 : 0;
     if (h->opt_merge >= 0) a.merge = h->opt_merge;
     a.ckpt = 0;  // decided in finish_options() once the other options are final
     a.stagger = 0;

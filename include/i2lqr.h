@@ -191,7 +191,8 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     lane rewrites its row entry), so all input rows of a wavefront stay full
  *                     64-lane rows of ONE buffer.  0: per-lane buffer swap (no copy, but after
  *                     mixed decisions every input row access touches two buffers).  Automatic: 1 in
- *                     fp64 (bandwidth-bound), 0 in fp32 (instruction-bound).
+ *                     fp64 above 32768 problems (bandwidth-bound), 0 below and in fp32
+ *                     (instruction-bound).
  *   "checkpoint_states"  (fp64, "defer_states" 1, "merge_inputs" 1, "reroll_nominal" 1, Q = R = 0)
  *                     1: between the passes of an iteration only every fourth state is kept in
  *                     HBM; the backward pass re-rolls the states of four horizon steps at a time
