@@ -161,16 +161,18 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
- * problems the solve runs in chunks of 8, 4, 4, 8, 8, 16, ... iterations and packs the
- * still-running problems into dense work sets between chunks (no host synchronisation); once few
- * problems are left ("wave_tail" option below) they are finished by the speculative eight-lane
- * kernel (the one-problem-per-wavefront kernel where that is not built).
+ * problems the solve runs in chunks — the first 8 to 12 iterations long (as many as leave about
+ * "wave_tail" survivors on the benchmark workload's iteration-count distribution), then 4, then
+ * doubling — and packs the still-running problems into dense work sets between chunks (no host
+ * synchronisation); once few problems are left ("wave_tail" option below) they are finished by the
+ * speculative sixteen-lane kernel, which writes their results straight to the caller's arrays
+ * (the one-problem-per-wavefront kernel where that is not built).
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
  * large solve is bound by the slowest problem's iteration latency.
  *   min_batch  > 0  explicit threshold;  0  never (single launch);  < 0  automatic (default:
  *   from 4096 problems when max_iter > 16).
- * Measured on MI355X, n=6, N=20, 65536 problems, fp64: 6.8 ms single launch, 7.4 ms chunked
- * without the tail kernel, 2.7 ms with it.  The chunks alone are bit-identical to the single
+ * Measured on MI355X, n=6, N=20, 65536 problems, fp64: 6.6-7.5 ms single launch, 7.4 ms chunked
+ * without the tail kernel, 1.5-1.6 ms with it.  The chunks alone are bit-identical to the single
  * launch; with the tail kernel the outputs agree to the solve tolerance (1e-8 rel).
  */
 int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
