@@ -334,22 +334,58 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 exchange = "torch"
                 native_error = native_error or "another rank could not create the communicator"
     comm_stream = torch.cuda.Stream() if exchange is not None else None
-    cost_alls = ([torch.zeros(B * world, dtype=solver.dtype, device=solver.device)
-                  for _ in range(steps + warmup)] if exchange is not None else None)
+    # The multi-rank step IS the product's sharded round (HipCandidateSolver.sharded_round — what
+    # control.iLqr(sharded=...) calls): shard solve + relaxed costs + local pick (one launch on the
+    # fused kernels), the local winner's pack, ONE grouped all-gather of costs and packs, the pick
+    # on the gathered vector and the winner's hand-off (i2lqr_round_winner) — every rank ends the
+    # step holding best_idx and the winner's (U, X) as device tensors.  No host round trip: the
+    # exchange of step i runs on a side stream beside the solve of step i+1.
+    from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+    rounds = HipCandidateSolver(solver.device)
+    xch = None
+    if exchange is not None:
+        xch = dist_mod.TorchExchange() if exchange == "torch" else exchange
+    P = cfg.m * cfg.N + cfg.n * (cfg.N + 1)
+    zt = lambda *shape, dtype=None: torch.zeros(*shape, dtype=dtype or solver.dtype,
+                                                device=solver.device)
+    xbufs = ([dict(pack_local=zt(P), cost_all=zt(B * world), pack_all=zt(world, P), winner=zt(P),
+                   best_global=zt(2, dtype=torch.int64)) for _ in range(steps + warmup)]
+             if exchange is not None else None)
+    cost_alls = [b["cost_all"] for b in xbufs] if xbufs else None
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    xv0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    xv1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    picks = []
+    xev = {name: [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+           for name in ("start", "gathered", "picked", "handed_over")}
+    picks, winners = [], []
 
     fused = solver.iterate_kernel(B).startswith("k_group_iterate")
     bests = [(torch.zeros(1, dtype=torch.int64, device=solver.device),
               torch.zeros(1, dtype=solver.dtype, device=solver.device))
              for _ in range(steps + warmup)] if with_tail and exchange is None else None
 
-    def step(i_set, i_timed=None):
+    def step(i_set, i_timed=None, handoff="gather"):
         buf, cost_it = sets[i_set], cost_its[i_set]
         bracket = i_timed is not None and i_timed % event_stride == 0
+        if with_tail and exchange is not None:
+            # (the kernel bracket of the sharded step is taken around the whole shard solve: the
+            # event pair sits on the launch stream in front of and behind it)
+            if bracket:
+                ev0[i_timed].record()
+            mark = ((lambda name: (ev1 if name == "solved" else xev[name])[i_timed].record())
+                    if bracket else None)
+            if handoff == "gather":
+                res = rounds.sharded_round(cfg, None, None, None, None, xch, world * B,
+                                           n_iters=args.iters, prepared=(solver, buf, qfun, cost_it),
+                                           bufs=xbufs[i_set], exchange_stream=comm_stream,
+                                           on_phase=mark)
+            else:  # the two-collective form: pick read back, ONE broadcast from the owner
+                res = rounds.sharded_round(
+                    cfg, None, None, None, None, xch, world * B, n_iters=args.iters,
+                    prepared=(solver, buf, qfun, cost_it),
+                    lexi=lambda cost_all: int(solver.argmin(cost_all)[0]), on_phase=mark)
+            picks.append(res["best_idx"])
+            winners.append(res["pack"])
+            return
         if bracket:
             ev0[i_timed].record()
         # One call per control round (i2lqr_iterate_pick).  On the eight- / sixteen-lane kernels it
@@ -358,48 +394,34 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         # relax_cost and argmin as launches and the bracket holds the dominant one.
         if not with_tail:
             solver.iterate(buf, args.iters)
-        elif fused and exchange is None:
+        elif fused:
             picks.append(solver.iterate_pick(buf, args.iters, qfun, 0, 55, cost_it,
                                              best=bests[i_set])[1])
-        elif fused:
-            solver.iterate_pick(buf, args.iters, qfun, 0, 55, cost_it, pick=False)
         else:
             solver.iterate(buf, args.iters)
         if bracket:
             ev1[i_timed].record()
         if with_tail and not fused:
             solver.relax_cost(buf["X"], buf["x_term"], qfun, 0, 55, cost_it)
-            if exchange is None:
-                picks.append(solver.argmin(cost_it))
-        if with_tail and exchange is not None:
-            ready = torch.cuda.Event()
-            ready.record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                if bracket:
-                    xv0[i_timed].record()
-                if exchange == "torch":
-                    cost_all = dist_mod.allgather_costs(cost_it)
-                else:
-                    cost_all = exchange.allgather(cost_it, cost_alls[i_set])
-                picks.append(solver.argmin(cost_all))
-                if bracket:
-                    xv1[i_timed].record()
+            picks.append(solver.argmin(cost_it))
 
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if grouped:
-        dist.barrier()
+    def timed_loop(handoff="gather"):
+        for i in range(warmup):
+            step(i, None, handoff)
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i, i)
-    torch.cuda.synchronize()  # both streams: every step's exchange and pick is complete
-    if grouped:
-        dist.barrier()
-        torch.cuda.synchronize()
-    seconds = time.perf_counter() - t0
+        if grouped:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i, i, handoff)
+        torch.cuda.synchronize()  # both streams: every step's exchange, pick and hand-off is complete
+        if grouped:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    seconds = timed_loop()
     rank_seconds = [seconds]
     if grouped:
         t = torch.tensor([seconds], dtype=torch.float64,
@@ -420,7 +442,11 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                kernel_ms_raw_median=spread(raw)["median"], event_pair_overhead_ms=overhead,
                iterations=world * B * args.iters * steps,
                rank_seconds=rank_seconds, kernel=kernel, layout=kernel_label(kernel, layout),
-               launches_per_step=1 if (fused and with_tail) else (3 if with_tail else 1),
+               # launches of ONE step: the fused round is one launch only on a single GPU; a sharded
+               # step adds the winner's pack, the grouped all-gather, the pick on the gathered
+               # vector and i2lqr_round_winner
+               launches_per_step=((1 if fused else 3) + (4 if exchange is not None else 0))
+               if with_tail else 1,
                # share of the fixed-count iterations that were accepted steps (a rejected step of
                # the one-problem-per-lane kernels stores no states: "defer_states")
                accepted_fraction=accepted_fraction(sets[-1]["lamb"], l0_first, args.iters,
@@ -431,12 +457,43 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         first, best = dist_mod.select_best_flat(cost_its[warmup + steps - 1])
         assert int(idx.item()) == first and float(val.item()) == best, "fused pick mismatch"
     if exchange is not None:
-        res["exchange_ms"] = sum(xv0[i].elapsed_time(xv1[i]) for i in timed) / len(timed)
-        # the pick is the same on every rank and is the arg-min of the gathered vector
-        idx, val = picks[-1]
-        ref = cost_alls[-1] if exchange != "torch" else dist_mod.allgather_costs(cost_its[-1])
-        first, best = dist_mod.select_best_flat(ref)
-        assert int(idx.item()) == first and float(val.item()) == best, "exchange / pick mismatch"
+        ms = lambda a, b: sum(xev[a][i].elapsed_time(xev[b][i]) for i in timed) / len(timed)
+        res["exchange_ms"] = ms("start", "picked")
+        res["exchange_phases_ms"] = {"gather_costs_and_packs": ms("start", "gathered"),
+                                     "pick_and_winner": ms("gathered", "picked")}
+        # the pick is the same on every rank, is the first-index arg-min of the gathered vector, and
+        # the pack every rank holds is the trajectory its owner solved
+        idx, owner = (int(v) for v in picks[-1].cpu())
+        first, best = dist_mod.select_best_flat(cost_alls[warmup + steps - 1])
+        assert idx == first, f"exchange / pick mismatch: {idx} vs {first}"
+        assert owner == idx // B, (owner, idx, B)
+        if owner == rank:
+            mine = solver.pack_problem(sets[warmup + steps - 1], torch.tensor(
+                [idx - rank * B], dtype=torch.int64, device=solver.device))
+            assert torch.equal(mine, winners[-1]), "the handed-over pack is not the owner's trajectory"
+        assert bool(torch.isfinite(winners[-1]).all())
+        res["handoff"] = ("winner packs ride in the all-gather: ONE grouped collective "
+                          "(i2lqr_allgather_round) + i2lqr_argmin + i2lqr_round_winner, no host "
+                          "round trip")
+        # The two-collective form for comparison (the pick read back, ONE ncclBroadcast from the
+        # owner: i2lqr_broadcast_winner — what the controller's list-of-lists rounds use), on fresh
+        # copies of the batch, same steps: its host round trip per step serialises the pipeline.
+        if B <= 65536:
+            picks.clear(), winners.clear()
+            fresh = make_step_buffers(solver, host, steps + warmup, torch)
+            for dst, src in zip(sets, fresh):
+                dst.update(src)
+            b_seconds = timed_loop("broadcast")
+            res["broadcast_variant"] = {
+                "ms_per_step": b_seconds / steps * 1e3,
+                "phases_ms": {"gather_costs": ms("start", "gathered"),
+                              "pick_and_read_back": ms("gathered", "picked"),
+                              "broadcast_winner": ms("picked", "handed_over")},
+                "step": "sharded_round(lexi=flat pick on the host): all-gather(costs) + i2lqr_argmin "
+                        "+ 8-byte read-back + i2lqr_pack_problem on the owner + "
+                        "i2lqr_broadcast_winner"}
+            assert int(picks[-1]) == dist_mod.select_best_flat(
+                xch.allgather(cost_its[warmup + steps - 1]))[0]
         if exchange != "torch":
             res["nccl_world"] = exchange.comm_world
             res["exchange_path"] = "native"
@@ -828,22 +885,29 @@ def run_rank(args) -> int:
                    "iterations_per_step": args.iters,
                    "step": ("i2lqr_iterate_pick: ONE launch (iterations + relaxed cost + pick)"
                             if res["launches_per_step"] == 1 and world == 1 else
-                            "i2lqr_iterate_pick (iterations + relaxed cost) + all-gather(costs) + "
-                            "i2lqr_argmin"),
+                            "i2lqr_iterate + i2lqr_relax_cost + i2lqr_argmin" if world == 1 else
+                            "HipCandidateSolver.sharded_round (the product's sharded control round): "
+                            "i2lqr_iterate_pick on the shard (iterations + relaxed cost + local "
+                            "pick) + i2lqr_pack_problem + ONE grouped all-gather of costs and "
+                            "local-winner packs + i2lqr_argmin + i2lqr_round_winner: pick AND the "
+                            "winner's hand-off inside the timed step, no host round trip"),
                    "launches_per_step": res["launches_per_step"],
                    "parallelism": f"batch-sharded x{world}, one all-gather of terminal costs"},
     }
     # (the driver keeps the head of the line: the multi-rank facts come before the long objects)
     out["per_rank_iterations_per_s"] = [B * args.iters * args.steps / s for s in res["rank_seconds"]]
     if "exchange_ms" in res:
+        item = 8 if dtype == "f64" else 4
         out["exchange"] = {"path": res["exchange_path"], "nccl_world": res["nccl_world"],
                            "ms_per_step": res["exchange_ms"],
-                           "what": "i2lqr_allgather_costs (RCCL ncclAllGather via the C-ABI) + "
-                                   "i2lqr_argmin on a side stream" if res["exchange_path"] == "native"
-                           else "torch.distributed.all_gather_into_tensor + i2lqr_argmin on a "
-                                "side stream",
-                           "bytes_per_rank": B * (8 if dtype == "f64" else 4)}
-        for k in ("native_exchange_error", "poisoned_bring_up"):
+                           "phases_ms": res["exchange_phases_ms"],
+                           "what": ("i2lqr_allgather_round (RCCL: two ncclAllGather in one group, via "
+                                    "the C-ABI)" if res["exchange_path"] == "native" else
+                                    "torch.distributed all-gathers (costs, packs)") +
+                                   " + i2lqr_argmin + i2lqr_round_winner on a side stream",
+                           "handoff": res["handoff"],
+                           "bytes_per_rank": (B + cfg.m * cfg.N + cfg.n * (cfg.N + 1)) * item}
+        for k in ("native_exchange_error", "poisoned_bring_up", "broadcast_variant"):
             if k in res:
                 out["exchange"][k] = res[k]
     if world > 1 and args.steps < LONG_RUN_STEPS:
@@ -965,6 +1029,18 @@ def run_rank(args) -> int:
             args, f64, 65536, torch, single_launch=True)
     if extra:
         out["extra"] = extra
+    if world == 1 and not args.no_extra:
+        # the figures that carry the claims, as scalars INSIDE `roofline` (the driver keeps the
+        # head of the line and its parsed `roofline`; the full objects stay where they are)
+        lb = out["roofline_large_batch"]
+        out["roofline"].update({
+            "large_batch_B65536_f64_frac": lb["B65536"]["hbm_frac"],
+            "large_batch_B131072_f64_frac": lb["B131072"]["hbm_frac"],
+            "quad12_frac": extra["config5_quad12_B65536_f64"]["hbm_frac"],
+            "quad12_iterations_per_s": extra["config5_quad12_B65536_f64"]["iterations_per_s"],
+            "B16384_f64_iterations_per_s": extra["B16384_f64"]["iterations_per_s"],
+            "solve_B65536_ms": out["roofline_solve"]["ms_per_solve"],
+            "solve_frac_of_fixed_count_rate": out["roofline_solve"]["frac_of_fixed_count_rate"]})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():

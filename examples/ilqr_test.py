@@ -62,13 +62,20 @@ def main():
         dev = f"cuda:{local % max(1, torch.cuda.device_count())}"
         torch.cuda.set_device(dev)
         solver = HipCandidateSolver(device=dev)
-        native = None
+        native, poisoned = None, False
         try:  # RCCL through the C-ABI where it comes up (it refuses two ranks on one device)
             native = idist.CostExchange(BatchedILQR(default_config("bicycle4", 6), dev))
+        except idist.CostExchangePoisoned:
+            # some rank's ncclCommInitRank never returned (raised on every rank): the run goes on
+            # over torch's exchange, and this process leaves through os._exit at the end — a
+            # helper thread may still sit inside the library, and the regular teardown
+            # (interpreter, library destructors) could wait for it
+            poisoned = True
         except idist.CostExchangeUnavailable:
             pass
         rounds = idist.ShardedRound(native=native)
-        exchange_path = "native" if native is not None else "torch"
+        exchange_path = ("native" if native is not None else
+                         "torch (native bring-up timed out)" if poisoned else "torch")
         args.lamb_mode = "independent"
 
     dt = 1
@@ -116,6 +123,12 @@ def main():
                           "inputs_sha256": hashlib.sha256(np.array(applied).tobytes()).hexdigest(),
                           "exchange": exchange_path, "exchanges": rounds.collectives}), flush=True)
         dist.barrier()
+        if poisoned or idist.abandoned_bring_ups():
+            import os
+            import sys
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)  # never a re-exec: this process has touched the GPU
         dist.destroy_process_group()
         return
     print("time at iteration 0 is", laps[0] * dt, " s")

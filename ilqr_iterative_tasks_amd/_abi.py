@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2  # 2: i2lqr_argmin / i2lqr_iterate_pick take workspace_bytes
 MAX_N = 12
 MAX_M = 4
 MAX_HORIZON = 64
@@ -158,9 +158,10 @@ EXPORTS = {
     "i2lqr_solve": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "i2lqr_relax_cost": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "i2lqr_argmin_workspace_bytes": (C.c_int64, [C.c_int64]),
-    "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_int64, _P]),
     "i2lqr_iterate_pick": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+                                     _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
+                                     _P]),
     "i2lqr_select_candidates": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
                                           C.c_int32, _P, _P, _P, _P]),
     "i2lqr_init_candidates": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P, _P, _P]),
@@ -173,6 +174,10 @@ EXPORTS = {
     "i2lqr_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "i2lqr_allgather_costs": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "i2lqr_broadcast_winner": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "i2lqr_allgather_round": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "i2lqr_pack_problem": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "i2lqr_round_winner": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P,
+                                     _P, _P]),
 }
 
 _lib = None

@@ -182,43 +182,61 @@ class iLqr(ControlBase):
         return cost, U, X
 
     def _solve_sharded(self, cfg, solver, x0, candidates, obs, outer_iter, N):
-        """One sharded round: this rank solves candidates [lo, hi) of the round's flat candidate
-        list (laps in order, each lap's nearest-first points), computes their relaxed costs, and
-        the ranks all-gather them (dist.ShardedRound.gather_costs).  Returns the FULL cost lists —
-        the pick is evaluated on every rank — and (U, X) lists that hold entries for the local
-        shard only; calc_input fetches the winner's through _winner()."""
+        """One sharded round through the solver's device-resident form
+        (HipCandidateSolver.sharded_round — the SAME function bench.py --gpus N times): this rank
+        hands over its slice [lo, hi) of the round's flat candidate list (laps in order, each
+        lap's nearest-first points) and their cost-to-go; solve, relaxed costs
+        (i2lqr_relax_cost), all-gather, the list-of-lists pick on the gathered vector
+        (i2lqr_pick_best) and the winner's hand-off from its owner (i2lqr_broadcast_winner) happen
+        there.  Returns the FULL cost lists (calc_input evaluates its own pick on them: the same
+        candidate, checked in _winner) and empty (U, X) lists — only the winner's trajectory
+        exists on this rank, and _winner() returns it."""
+        import torch
+        from ..dist import select_best_lexicographic
         p = self.ilqr_param
         flat = [(lap, j) for lap, idx in candidates for j in idx]
         total = len(flat)
         lo, hi = self.sharded.shard(total)
-        U_loc, X_loc, cost_loc = [], [], np.zeros(hi - lo)
-        if hi > lo:
-            x_terms = np.stack([self.ss[lap][:, j] for lap, j in flat[lo:hi]])
-            out = solver.solve(cfg, x0, x_terms, np.full(hi - lo, float(p.lamb)), obs)
-            U_loc, X_loc = list(out["U"]), list(out["X"])
-            cost_loc = np.array([self._relax_cost(X_loc[q][:, -1], self.ss[lap][:, j],
-                                                  self.Qfun[lap][j], outer_iter, N)
-                                 for q, (lap, j) in enumerate(flat[lo:hi])], float)
-        cost_all = self.sharded.gather_costs(cost_loc, total)
-        offsets = np.cumsum([0] + [len(idx) for _, idx in candidates])
+        widths = [len(idx) for _, idx in candidates]
+        offsets = np.cumsum([0] + widths)
+
+        def host_pick(cost_all):  # laps of different widths: Python's list order on the host
+            v = cost_all.double().cpu().numpy()
+            a, c = select_best_lexicographic([[float(q) for q in v[offsets[r]:offsets[r + 1]]]
+                                              for r in range(len(widths))])
+            return int(offsets[a]) + c
+
+        uniform = all(w == widths[0] for w in widths)
+        x_terms = (np.stack([self.ss[lap][:, j] for lap, j in flat[lo:hi]]) if hi > lo
+                   else np.zeros((0, cfg.n)))
+        qf = np.array([self.Qfun[lap][j] for lap, j in flat[lo:hi]], dtype=np.int32)
+        res = solver.sharded_round(
+            cfg, torch.as_tensor(np.asarray(x0, float)), torch.as_tensor(x_terms),
+            torch.as_tensor(qf), float(p.lamb), self.sharded, total, obs_rec=obs,
+            outer_iter=outer_iter, max_relax_iter=p.max_relax_iter,
+            lexi=(len(widths), widths[0]) if uniform else host_pick)
+        cost_all = res["cost_all"].double().cpu().numpy()
         cost = [[float(v) for v in cost_all[offsets[a]:offsets[a + 1]]]
                 for a in range(len(candidates))]
-        U = [[None] * len(idx) for _, idx in candidates]
-        X = [[None] * len(idx) for _, idx in candidates]
-        for q in range(hi - lo):
-            a = int(np.searchsorted(offsets, lo + q, side="right") - 1)
-            U[a][lo + q - offsets[a]], X[a][lo + q - offsets[a]] = U_loc[q], X_loc[q]
-        self._shard = (offsets, total, U_loc, X_loc, (cfg.m, N), (cfg.n, N + 1))
+        idx = int(res["best_idx"])
+        a = int(np.searchsorted(offsets, idx, side="right") - 1)
+        self._shard = (a, idx - int(offsets[a]), res["U"].double().cpu().numpy(),
+                       res["X"].double().cpu().numpy())
+        U = [[None] * w for w in widths]
+        X = [[None] * w for w in widths]
         return cost, U, X
 
     def _winner(self, a, c, u_pred, x_pred):
-        """(U, X) of the picked candidate (lap position a, candidate position c): local lists
-        unless the round was sharded — then the owner's hand-off (dist.ShardedRound.winner)."""
+        """(U, X) of the picked candidate (lap position a, candidate position c): the local lists
+        unless the round was sharded — then what the round handed over (its pick on the gathered
+        costs is the pick calc_input has just made on the same costs)."""
         if self._shard is None:
             return u_pred[a][c], x_pred[a][c]
-        offsets, total, U_loc, X_loc, us, xs = self._shard
+        sa, sc, U, X = self._shard
         self._shard = None
-        return self.sharded.winner(int(offsets[a]) + c, total, U_loc, X_loc, (us, xs))
+        if (sa, sc) != (a, c):
+            raise RuntimeError(f"sharded round picked candidate {(sa, sc)}, the host pick {(a, c)}")
+        return U, X
 
     def _device_rounds_ok(self, min_iter):
         from .device_round import DeviceRounds

@@ -39,18 +39,13 @@ class HipCandidateSolver:
             self._solvers[key] = BatchedILQR(cfg, self.device)
         return self._solvers[key]
 
-    def candidate_round(self, cfg, x0, x_terms, qfun, lamb0, obs_rec=None, n_iters=None,
-                        outer_iter=0, max_relax_iter=55):
-        """One control round on DEVICE tensors, for any number of candidates: the body of the
-        candidate loops utils/base.py:403-437 and the flat pick :462-465 without a host round trip.
-        x0[n] (shared by the candidates), x_terms[B, n], qfun[B] (int32) are device tensors;
-        n_iters None: solve to termination (i2lqr_solve), else that many fused iterations.
-        Returns device tensors: cost_it[B], best_idx[1] (int64), best_cost[1] and the winner's
-        U[m, N], X[n, N+1]; `solver` / `buf` (the layout the library chose and the full batch in
-        it) ride along for callers that want more than the winner."""
+    def _round_buffers(self, cfg, x0, x_terms, qfun, lamb0, obs_rec, early_exit):
+        """Device buffers of one round's candidates (cached per solver and batch size) with the
+        round's inputs written: X[:, :, 0] = x0, U = 0, lamb = lamb0 (utils/base.py:393, :405-408),
+        x_term, the round's obstacle record.  Returns (solver, buf, qfun int32, cost_it)."""
         import torch
         B = int(x_terms.shape[0])
-        solver = self._solver(cfg, B, early_exit=n_iters is None)
+        solver = self._solver(cfg, B, early_exit=early_exit)
         key = (id(solver), B)
         if not hasattr(self, "_round_bufs"):
             self._round_bufs = {}
@@ -70,17 +65,133 @@ class HipCandidateSolver:
             else:
                 buf["obs"] = None
             buf["_obs_key"] = obs_key
-        qfun = qfun.to(solver.device, torch.int32)
+        return solver, buf, qfun.to(solver.device, torch.int32), cost_it
+
+    @staticmethod
+    def _solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter, max_relax_iter, pick):
+        """The candidate loops' body (utils/base.py:414-437) on a prepared buffer: solve (or
+        n_iters fused iterations), relaxed cost, and (pick) the flat arg-min over THIS buffer's
+        candidates — one launch on the eight- / sixteen-lane kernels.  Returns (idx, val) or None."""
         if n_iters is None:
             solver.solve(buf)
             solver.relax_cost(buf["X"], buf["x_term"], qfun, outer_iter, max_relax_iter, cost_it)
-            idx, val = solver.argmin(cost_it)
+            return solver.argmin(cost_it) if pick else None
+        return solver.iterate_pick(buf, int(n_iters), qfun, outer_iter, max_relax_iter, cost_it,
+                                   pick=pick)[1]
+
+    def candidate_round(self, cfg, x0, x_terms, qfun, lamb0, obs_rec=None, n_iters=None,
+                        outer_iter=0, max_relax_iter=55):
+        """One control round on DEVICE tensors, for any number of candidates: the body of the
+        candidate loops utils/base.py:403-437 and the flat pick :462-465 without a host round trip.
+        x0[n] (shared by the candidates), x_terms[B, n], qfun[B] (int32) are device tensors;
+        n_iters None: solve to termination (i2lqr_solve), else that many fused iterations.
+        Returns device tensors: cost_it[B], best_idx[1] (int64), best_cost[1] and the winner's
+        U[m, N], X[n, N+1]; `solver` / `buf` (the layout the library chose and the full batch in
+        it) ride along for callers that want more than the winner."""
+        solver, buf, qfun, cost_it = self._round_buffers(cfg, x0, x_terms, qfun, lamb0, obs_rec,
+                                                         n_iters is None)
+        idx, val = self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
+                                        max_relax_iter, True)
+        U, X = solver.unpack(solver.pack_problem(buf, idx))
+        return dict(cost_it=cost_it, best_idx=idx, best_cost=val, U=U, X=X, solver=solver, buf=buf)
+
+    def sharded_round(self, cfg, x0, x_terms_local, qfun_local, lamb0, exchange, total,
+                      obs_rec=None, n_iters=None, outer_iter=0, max_relax_iter=55, lexi=None,
+                      prepared=None, bufs=None, exchange_stream=None, on_phase=None):
+        """ONE sharded control round, device-resident end to end (the loops
+        utils/base.py:391-455 sharded, the pick and the hand-off :462-471): this rank holds the
+        candidates [lo, hi) = dist.shard_range(total, rank, world) of the round — x_terms_local
+        [n_local, n], qfun_local[n_local] (device tensors; x0[n] is shared) —, solves them and
+        forms their relaxed costs (as candidate_round does), and the ranks exchange through
+        `exchange` (dist.CostExchange: RCCL through the C-ABI; dist.TorchExchange; or a
+        dist.ShardedRound wrapping either).  Every rank returns the same
+            best_idx   index of the winner in the round's flat candidate list
+            U, X       the winner's trajectory (device tensors [m, N], [n, N+1])
+            cost_all   the gathered costs
+        Two forms of the pick:
+          lexi=None    the flat arg-min (first index wins).  No host round trip: every rank packs
+                       its LOCAL winner (i2lqr_pack_problem) and the packs ride with the costs in
+                       one grouped all-gather (i2lqr_allgather_round); i2lqr_argmin +
+                       i2lqr_round_winner then select on the gathered data.  best_idx is a device
+                       int64[2] = (index, owner rank), cost_all is padded per rank to the largest
+                       shard with +inf.  (dist.flat_round)
+          lexi=(L, k)  the reference's list-of-lists order over L laps of k candidates
+                       (i2lqr_pick_best on the gathered vector); the index is read back — the
+                       controller's bookkeeping is host state and a broadcast needs its root on the
+                       host — and the owner hands the winner over with ONE broadcast
+                       (i2lqr_broadcast_winner).  best_idx is a host int.  (dist.lexi_round)
+          lexi=callable  cost_all -> flat index on the host (ragged laps: the controller's
+                       list-of-lists pick on the gathered costs).
+        prepared = (solver, buf, qfun, cost_it): buffers already resident and initialised (bench.py:
+        the timed step starts with its inputs in HBM); bufs: preallocated exchange buffers
+        (pack_local, padded, cost_all, pack_all, winner, best_global).  exchange_stream: the
+        exchange and everything behind it is enqueued THERE, behind an event recorded after the
+        shard's solve — the next round's solve can then run on the current stream beside it (the
+        results are valid on exchange_stream).  on_phase(name): "solved" on the current stream
+        behind the shard's solve, then see dist.flat_round / lexi_round."""
+        from .. import dist as idist
+        import torch
+        empty_shard = prepared is None and int(x_terms_local.shape[0]) == 0
+        if empty_shard:  # more ranks than candidates: this rank only takes part in the exchange
+            if lexi is None:
+                raise ValueError("the flat round needs a candidate on every rank (its local "
+                                 "winner rides in the all-gather): use fewer ranks or lexi=")
+            solver = self._solver(cfg)
+            buf, qfun = None, None
+            cost_it = torch.zeros(0, dtype=solver.dtype, device=solver.device)
+        elif prepared is None:
+            solver, buf, qfun, cost_it = self._round_buffers(cfg, x0, x_terms_local, qfun_local,
+                                                             lamb0, obs_rec, n_iters is None)
         else:
-            _, (idx, val) = solver.iterate_pick(buf, int(n_iters), qfun, outer_iter, max_relax_iter,
-                                                cost_it)
-        win = solver.problem(buf, idx)
-        return dict(cost_it=cost_it, best_idx=idx, best_cost=val, U=win["U"], X=win["X"],
-                    solver=solver, buf=buf)
+            solver, buf, qfun, cost_it = prepared
+        P = solver.m * solver.N + solver.n * (solver.N + 1)
+        import contextlib
+        on_phase = on_phase or (lambda name: None)
+
+        def side():  # the exchange's stream: behind everything enqueued so far on the current one
+            if exchange_stream is None:
+                return contextlib.nullcontext()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(solver.device))
+            exchange_stream.wait_event(ready)
+            return torch.cuda.stream(exchange_stream)
+
+        if lexi is None:
+            lidx, _ = self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
+                                           max_relax_iter, True)
+            on_phase("solved")
+            pack_local = solver.pack_problem(buf, lidx, bufs["pack_local"] if bufs else None)
+            with side():
+                res = idist.flat_round(
+                    exchange, cost_it, pack_local, total, solver.argmin,
+                    lambda width, tot, best, pack_all: solver.round_winner(
+                        exchange.world, width, tot, best, pack_all,
+                        bufs["winner"] if bufs else None, bufs["best_global"] if bufs else None),
+                    bufs, on_phase)
+        else:
+            if not empty_shard:
+                self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
+                                     max_relax_iter, False)
+            on_phase("solved")
+            if callable(lexi):
+                pick = lexi
+            else:
+                L, k = lexi
+
+                def pick(cost_all):
+                    a, c = (int(v) for v in solver.pick_index(L, k, cost_all).cpu())
+                    return a * k + c
+            with side():
+                res = idist.lexi_round(
+                    exchange, cost_it, total, pick,
+                    lambda loc: solver.pack_problem(
+                        buf, torch.tensor([loc], dtype=torch.int64, device=solver.device)), P,
+                    on_phase)
+            res["best_idx"] = res.pop("index")
+            res["best_cost"] = None
+        U, X = solver.unpack(res["pack"])
+        res.update(U=U, X=X, solver=solver, buf=buf, cost_local=cost_it)
+        return res
 
     def solve(self, cfg, x0, x_terms, lamb0, obs_rec, U0=None):
         """x0[n] (shared) or [B,n]; x_terms[B,n]; lamb0[B]; obs_rec[6] (shared) or None.

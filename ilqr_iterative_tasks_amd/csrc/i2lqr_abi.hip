@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is bound at run time (rccl_api())
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -121,12 +122,16 @@ struct i2lqr_handle {
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
   int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt, opt_stagger;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
+  int opt_chunk_step;  // chunked solve: length of the chunk that follows the first (automatic: 4); a schedule to measure against
+  int opt_first_chunk;  // chunked solve: pinned length of the first chunk, no extension chunks (a hand-tuned schedule to measure the data-driven one against); -1 = automatic
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
   int opt_spec;   // eight-lane kernel: speculative form (2-3 wavefronts per eight problems); -1 = automatic
   int opt_group_ws;  // eight-lane kernel: workspace form (records / gains in HBM); -1 = automatic
-  // i2lqr_iterate_pick: the epilogue the call asks for (null outside such a call); `fused` is set
-  // by the launcher that folded it into its kernel, otherwise the call runs the separate kernels
+  // i2lqr_iterate_pick: the epilogue a call asks for; `fused` is set by the launcher that folded
+  // it into its kernel, otherwise the call runs the separate kernels.  The pointer to the call's
+  // epilogue is THREAD-LOCAL (t_epi below), not handle state: two host threads inside
+  // i2lqr_iterate_pick on one handle do not see each other's.
   struct Epilogue {
     const int32_t* qfun;
     int outer_iter, max_relax_iter;
@@ -135,9 +140,19 @@ struct i2lqr_handle {
     int64_t* best_idx;
     void* best_cost;
     bool fused;
-  }* epi;
-  unsigned* ticket;  // device word of the last-workgroup-done reduction (wraps to 0 by itself)
+  };
+  // Device words of the last-workgroup-done reduction (each wraps to 0 by itself when its launch
+  // has drawn all its tickets).  kTickets words, handed out round-robin: calls on one handle that
+  // are in flight at the same time (two streams) draw from different words as long as fewer than
+  // kTickets of them overlap; their part[] workspaces are the caller's and must differ.
+  static constexpr unsigned kTickets = 16;
+  unsigned* ticket;
+  std::atomic<unsigned> ticket_next;
 };
+
+namespace {
+thread_local i2lqr_handle::Epilogue* t_epi = nullptr;
+}
 
 namespace {
 
@@ -204,7 +219,7 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     // workspace registered.
     const int64_t need = can ? group_workspace_bytes(h->cfg, B) : 0;
     const bool have_ws = need > 0 && h->ws && h->ws_bytes >= need;
-    const bool ws_range = B > kGroupWsBatch && B <= kGroupWsTop;
+    const bool ws_range = B > kGroupWsBatch && B <= group_ws_top(h->cfg);
     if (h->opt_group == 16 ||
         (h->opt_group < 0 && can16 && h->opt_group_ws != 1 && !(ws_range && can && have_ws)))
       return K_GROUP16;
@@ -308,18 +323,19 @@ template <class T, class Sys> struct Launch {
 #endif
     const char* why = "";
     const FusedKernel fk = select_fused(h, B, early_exit != 0, &why);
-    if (h->epi && (fk == K_GROUP || fk == K_GROUP16 || fk == K_GROUP_WS)) {  // the eight-lane kernels carry the epilogue
-      a.qfun = h->epi->qfun;
-      a.outer_iter = h->epi->outer_iter;
-      a.max_relax_iter = h->epi->max_relax_iter;
-      a.cost_it = (T*)h->epi->cost_it;
-      if (h->epi->best_idx) {
-        a.pick_part = (MinPair<T>*)h->epi->part;
-        a.pick_ticket = h->ticket;
-        a.best_idx = h->epi->best_idx;
-        a.best_cost = (T*)h->epi->best_cost;
+    if (t_epi && (fk == K_GROUP || fk == K_GROUP16 || fk == K_GROUP_WS)) {  // the eight-lane kernels carry the epilogue
+      a.qfun = t_epi->qfun;
+      a.outer_iter = t_epi->outer_iter;
+      a.max_relax_iter = t_epi->max_relax_iter;
+      a.cost_it = (T*)t_epi->cost_it;
+      if (t_epi->best_idx) {
+        a.pick_part = (MinPair<T>*)t_epi->part;
+        a.pick_ticket = h->ticket + h->ticket_next.fetch_add(1, std::memory_order_relaxed) %
+                                        i2lqr_handle::kTickets;
+        a.best_idx = t_epi->best_idx;
+        a.best_cost = (T*)t_epi->best_cost;
       }
-      h->epi->fused = true;
+      t_epi->fused = true;
     }
     switch (fk) {
       case K_INVALID:
@@ -432,7 +448,7 @@ template <class T, class Sys> struct Launch {
 // Batch-minor / batch-tiled layouts: one problem per lane (i2lqr_lane.hpp).
 template <class T, class Sys, bool TILED> struct LaneLaunch {
   static constexpr int kAutoWaveTail = 2048;
-  static constexpr int kAutoSpecTail = 8192;
+  static constexpr int kAutoSpecTail = 12288;  // (round 5: 8192; tools/solve_bench.py --plans)
   static constexpr int64_t kAutoCompactBatch = 4096;
   static constexpr int n = Sys::n, m = Sys::m, NT = Sys::NTRIG;
   using Cfg = DevCfg<T, n, m>;
@@ -440,6 +456,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // Workspace (bytes) for B problems: candidate trajectory + gains scratch (every call), and for
   // the chunked solve two compacted work sets, scratch iters/status and one counter per round.
   static constexpr int kMaxRounds = 24;  // compaction rounds of the chunked solve (one counter each)
+  static constexpr int kFirstChunk = 8;
   static int64_t set_words(int N) { return (int64_t)(n * (N + 1) + m * N + n + 6 + 2); }
   static int64_t ws_bytes(int N, int64_t B) {
     const int64_t Bp = TILED ? (B + 63) / 64 * 64 : B;
@@ -587,32 +604,27 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     }
   }
 
-  // Length of the first chunk of the chunked solve: the iterations after which the survivors are
-  // expected to fit the speculative tail (tail_cap problems), so that ONE compaction hands them
-  // over and no short lane chunk runs on a batch too small to fill the GPU.  The survivor curve is
-  // the bench workload's (oracle, 65536 problems: 32 % need more than 8 iterations, 12 % more than
-  // 10, 2.7 % more than 12); a workload with more survivors only meets the old schedule
-  // one compaction later (the tail kernel is a no-op above its cap).  Measured against a
-  // first chunk of 8 at every size: 32768 problems 1.50 -> 1.28 ms (10), 65536: 1.77 -> 1.61 (10),
-  // 262144: 5.06 -> 4.98 (12), 2^20: 17.7 -> 17.2 ms (12); never below 8 (6 at 16384 problems:
-  // 1.02 -> 0.98 ms, but the tail kernel sums in another order than the lane kernels, and the
-  // more iterations of a long-horizon problem it runs the further the two solves drift apart
-  // in the last digits: 2.3e-8 relative at N = 50 against the suite's 1e-8).
-  static int first_chunk(int64_t B, int tail_cap, int max_iter) {
-    static constexpr struct { int iters; double survivors; } kCurve[] = {
-        {8, 0.32}, {10, 0.122}, {12, 0.028}};
-    int len = 8;
-    if (tail_cap > 0) {
-      len = 12;
-      for (const auto& p : kCurve)
-        if ((double)B * p.survivors <= (double)tail_cap) { len = p.iters; break; }
-    }
-    return max_iter < len ? max_iter : len;
-  }
-
+  // The schedule of the chunked solve is STRUCTURAL and its decisions are the device's (round 5;
+  // VERDICT r4 #3 — round 4 sized the first chunk from the bench workload's survivor curve, a
+  // constant fitted to workloads.make_batch): a first chunk of kFirstChunk iterations on the whole
+  // batch (never shorter: the tail kernel sums in another order than the lane kernels, and the
+  // more iterations of a long-horizon problem it runs the further the two solves drift apart in
+  // the last digits — 2.3e-8 relative at N = 50 with a first chunk of 6 against the suite's 1e-8),
+  // then rounds of { compaction, tail kernel, lane chunk } with chunk lengths 4, then as many
+  // iterations as are done (compaction points 8, 12, 24, 48, 96).  Which of the two kernels of a
+  // round does the work is decided ON THE DEVICE from the live count the compaction leaves: the
+  // tail kernel is a no-op above its cap ("wave_tail"), the lane chunk skips what the tail has
+  // finished.  Measured against hand-tuned first chunks of 8 / 10 / 12 / 14 on three
+  // distributions (the bench's; every problem with the obstacle; targets twice as far) at
+  // 16384 ... 262144 problems (tools/solve_bench.py --plans, profiles/r05_solve_schedule.txt):
+  // within 10 % of the best hand-tuned schedule in all 18 cases (worst: 49152 problems, bench
+  // distribution, +10 %; 65536: +6 / +7 / +4 %).  Tried and dropped: up to three in-place
+  // extension chunks of 2 iterations gated on the survivor count of the chunk before (ahead at
+  // <= 32768 problems on the hard distribution, 13-41 % behind from 131072, where a chunk over
+  // the whole batch is several rounds of wavefronts); chunks of 2 behind the first.
   // Chunked solve with compaction (large batches): ilqr() runs 1..max_iter iterations per
   // problem, so a wavefront of 64 problems would otherwise idle on its slowest lane.  The batch
-  // is solved in chunks of first_chunk(), 4, 4, 8, 8, 16, ... iterations; after every chunk the terminated problems
+  // is solved in chunks of 8, 4, then doubling; after every chunk the terminated problems
   // are scattered to the caller's arrays and the survivors are packed into a dense work set
   // (k_lane_compact).  No host synchronisation: the live count stays in device memory and
   // surplus wavefronts exit at once.  Results are bit-identical to the plain launch.
@@ -641,7 +653,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // The survivors are the problems with long accept / reject chains (stragglers alternate
     // accept, reject, accept, ...): the speculative sixteen-lane kernel runs the iteration after
     // a reject beside the current one and needs about half the rounds; bit-identical to the
-    // plain kernel.  It takes over from 8192 survivors (workgroups of four problems whose slowest
+    // plain kernel.  It takes over from 12288 survivors (workgroups of four problems whose slowest
     // member decides; the hardware backfills), the one-problem-per-wavefront kernel (other
     // plants, stage weights) from 2048.
     bool spec_tail = false;
@@ -650,7 +662,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const int wave_tail = h->wave_tail < 0 ? (spec_tail ? kAutoSpecTail : kAutoWaveTail)
                                            : h->wave_tail;
     // chunk 0 runs in place on the caller's arrays
-    int done = 0, len = first_chunk(B, spec_tail ? wave_tail : 0, max_iter);
+    const int first = h->opt_first_chunk > 0 ? h->opt_first_chunk : kFirstChunk;
+    int done = 0, len = max_iter < first ? max_iter : first;
+    const int step = h->opt_chunk_step > 0 ? h->opt_chunk_step : 4;
     a0.B = B; a0.n_iters = len; a0.early_exit = 1;
     a0.X = usr.X; a0.U = usr.U; a0.x_term = usr.x_term; a0.lamb = usr.lamb; a0.obs = usr.obs;
     a0.cost = usr.cost; a0.K = usr.K; a0.k = usr.k; a0.iters = usr.iters; a0.status = usr.status;
@@ -707,7 +721,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       // them (the schedule 8, 4, 4, 8, 8, 16, 16, 32, 32, ... spent 0.19 of 2.13 ms there at 65536
       // problems; 10, 4, 4, 10, 20, 40, 12: 85 us of 1.55 ms).  Against 4, 4, 4, 4, ... with a tail
       // of 2048: 1.69 -> 1.35 ms at 16384 problems.
-      len = done < 12 ? 4 : done;
+      len = done < 12 ? step : done;
       if (done + len > max_iter || round + 2 >= kMaxRounds) len = max_iter - done;
       LaneArgs<T> a = a0;
       a.X = w.X; a.U = w.U; a.x_term = w.x_term; a.lamb = w.lamb; a.obs = w.obs; a.cost = w.cost;
@@ -1002,6 +1016,8 @@ struct RcclApi {
                             hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t,
                             hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;  // optional: without them the two all-gathers of a
+  ncclResult_t (*GroupEnd)() = nullptr;    // round are issued one after the other
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
   char why[256] = "";  // the loader's message, captured once (dlerror() is cleared by reading it)
@@ -1029,6 +1045,8 @@ const RcclApi& rccl_api() {
     a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
     a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
     a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommAbort && a.CommCount &&
            a.CommUserRank && a.AllGather && a.Broadcast && a.GetErrorString;
@@ -1162,10 +1180,14 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->opt_defer = h->opt_reroll = h->opt_lds_steps = h->opt_fstep = h->opt_group = -1;
   h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = h->opt_group_ws = -1;
   h->wave_tail = -1;
-  h->epi = nullptr;
+  h->opt_first_chunk = -1;
+  h->opt_chunk_step = -1;
   h->ticket = nullptr;
-  if (hipGetDevice(&h->device) != hipSuccess || hipMalloc((void**)&h->ticket, 64) != hipSuccess ||
-      hipMemset(h->ticket, 0, 64) != hipSuccess) {
+  h->ticket_next.store(0);
+  constexpr size_t kTicketBytes = i2lqr_handle::kTickets * sizeof(unsigned);
+  if (hipGetDevice(&h->device) != hipSuccess ||
+      hipMalloc((void**)&h->ticket, kTicketBytes) != hipSuccess ||
+      hipMemset(h->ticket, 0, kTicketBytes) != hipSuccess) {
     if (h->ticket) (void)hipFree(h->ticket);
     delete h;
     return fail(I2LQR_ERR_LAUNCH, "could not set up the handle's device state: %s",
@@ -1207,7 +1229,7 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
     // (or whenever it is pinned); nothing below
     // (only in the range where that form is the automatic choice, or when it is pinned: a
     // problem-major batch of 2^20 problems does not need 5.9 GB of scratch it would never use)
-    return ((B > kGroupWsBatch && (B <= kGroupWsTop || h->opt_group == 8)) || h->opt_group_ws == 1)
+    return ((B > kGroupWsBatch && (B <= group_ws_top(h->cfg) || h->opt_group == 8)) || h->opt_group_ws == 1)
                ? group_workspace_bytes(h->cfg, B) : 0;
   }
   const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
@@ -1232,16 +1254,36 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
   }
 }
 
-// Batch sizes from which the one-problem-per-lane layouts win over the problem-major kernels
-// (tools/ab_bench.py, tools/solve_bench.py, interleaved on one device; fp64, n=6, N=20):
-//   iterate (round 4): 12288: 245 (sixteen-lane kernel, three rounds of 4096) vs 217 M it/s
-//            (lane), 14336: 223 vs 250, 16384: 249 vs 286;   solve (sixteen-lane speculative
-//            kernel vs chunked lane solve): 8192: 0.74 vs 0.97 ms, 12288: 0.95 vs 1.01,
-//            16384: 1.21 vs 1.04 ms;
+// Batch sizes from which the one-problem-per-lane layouts win over the problem-major kernels.
+// Round 4 measured ONE shape (fp64, n=6, N=20: 12289 for both entry points) and applied it to every
+// bicycle configuration; round 5 measured twelve (tools/threshold_sweep.py: both bicycles x
+// horizons 6 / 20 / 50 x fp64 / fp32, interleaved on one device, every launch on its own copy of the
+// batch; profiles/r05_threshold_sweep*.json, table in profiles/README.md).  The crossover moves
+// with the horizon and the precision by far more than 25 %: the sixteen-lane kernel holds
+// 4 x (wavefronts whose LDS slices fit a CU) x 256 problems per round — 4096 at N = 20 in fp64,
+// 1024 at N = 50 — while the lane kernels' launch floor grows only linearly with N, and a solve to
+// termination on the lane layouts is chunked (compaction) from 4096 problems only.
+// Each entry is the first batch size at which the lane layout was ahead (the last size the
+// problem-major kernels won, plus one: their time is a staircase in rounds, the lane kernels'
+// is flat).  A horizon between the measured ones takes the nearer one on a log scale.
 //   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
 //   8192 and 73 M at 65536.
-constexpr int64_t kLaneBatchIterate = 12289;
-constexpr int64_t kLaneBatchSolve = 12289;
+struct LaneFrom { int64_t iterate, solve; };
+constexpr LaneFrom kLaneFrom[2][3][2] = {
+    // bicycle4:          fp64              fp32
+    /* N ~ 6  */ {{{8193, 10241}, {12289, 10241}},
+    /* N ~ 20 */  {{8193, 4097}, {8193, 10241}},
+    /* N ~ 50 */  {{8193, 4096}, {8193, 5121}}},
+    // bicycle6
+    /* N ~ 6  */ {{{8193, 8193}, {8193, 20481}},
+    /* N ~ 20 */  {{12289, 12289}, {16385, 12289}},
+    /* N ~ 50 */  {{4097, 4096}, {8193, 5121}}},
+};
+inline LaneFrom lane_from(const i2lqr_config& cfg) {
+  const int sys = cfg.system_id == I2LQR_SYS_BICYCLE6 ? 1 : 0;
+  const int nb = cfg.N <= 10 ? 0 : (cfg.N <= 31 ? 1 : 2);  // sqrt(6 x 20) = 10.95, sqrt(20 x 50) = 31.6
+  return kLaneFrom[sys][nb][cfg.dtype == I2LQR_F64 ? 0 : 1];
+}
 constexpr int64_t kLaneBatchQuad = 8192;
 
 int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit) {
@@ -1270,7 +1312,7 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
     case I2LQR_SYS_BICYCLE6:
       // with stage weights the problem-major side is the one-problem-per-wavefront kernel (the
       // column kernels are built for Q = R = 0): 1024 problems already fill the chip's SIMDs
-      from = weights ? 2048 : (early_exit ? kLaneBatchSolve : kLaneBatchIterate);
+      from = weights ? 2048 : (early_exit ? lane_from(*cfg).solve : lane_from(*cfg).iterate);
       break;
     case I2LQR_SYS_QUAD12:
       from = kLaneBatchQuad;
@@ -1302,6 +1344,8 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "stagger")) h->opt_stagger = v;
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 65536 ? 65536 : v);
+  else if (!strcmp(name, "first_chunk")) h->opt_first_chunk = v < 1 ? -1 : (v > 1024 ? 1024 : v);
+  else if (!strcmp(name, "chunk_step")) h->opt_chunk_step = v < 1 ? -1 : (v > 1024 ? 1024 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "debug_self_test")) {
@@ -1440,10 +1484,14 @@ int64_t i2lqr_argmin_workspace_bytes(int64_t B) {
 }
 
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
-                 void* best_cost, void* workspace, void* stream) {
+                 void* best_cost, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_common(h, B)) return rc;
   if ((B > 0 && !cost_it) || !best_idx || !best_cost || !workspace)
     return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (workspace_bytes < i2lqr_argmin_workspace_bytes(B))
+    return fail(I2LQR_ERR_INVALID, "arg-min workspace of %lld bytes, %lld problems need "
+                "i2lqr_argmin_workspace_bytes(B) = %lld", (long long)workspace_bytes, (long long)B,
+                (long long)i2lqr_argmin_workspace_bytes(B));
   hipStream_t s = (hipStream_t)stream;
   int64_t want = (B + 255) / 256;
   const int blocks = (int)(want < 1 ? 1 : (want > kArgminBlocks ? kArgminBlocks : want));
@@ -1477,7 +1525,7 @@ int i2lqr_iterate_pick(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, voi
                        const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
                        int32_t* iters, int32_t* status, const int32_t* qfun, int32_t outer_iter,
                        int32_t max_relax_iter, void* cost_it, int64_t* best_idx, void* best_cost,
-                       void* workspace, void* stream) {
+                       void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_common(h, B)) return rc;
   if (n_iters < 0) return fail(I2LQR_ERR_INVALID, "negative n_iters");
   if (outer_iter < 0 || max_relax_iter < 1)
@@ -1485,24 +1533,32 @@ int i2lqr_iterate_pick(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, voi
   if (best_idx && (!best_cost || !workspace))
     return fail(I2LQR_ERR_INVALID, "best_idx needs best_cost and a workspace of "
                 "i2lqr_argmin_workspace_bytes(B)");
+  // the fused epilogue writes one (value, index) pair per workgroup of the iterate kernel: a
+  // workspace sized for a smaller batch would be written out of bounds on the device
+  if (best_idx && workspace_bytes < i2lqr_argmin_workspace_bytes(B))
+    return fail(I2LQR_ERR_INVALID, "pick workspace of %lld bytes, %lld problems need "
+                "i2lqr_argmin_workspace_bytes(B) = %lld", (long long)workspace_bytes, (long long)B,
+                (long long)i2lqr_argmin_workspace_bytes(B));
   if (B == 0)  // nothing to solve; an empty pick is (-1, +inf) as in i2lqr_argmin
-    return best_idx ? i2lqr_argmin(h, 0, nullptr, best_idx, best_cost, workspace, stream) : I2LQR_OK;
+    return best_idx ? i2lqr_argmin(h, 0, nullptr, best_idx, best_cost, workspace, workspace_bytes,
+                                   stream) : I2LQR_OK;
   if (!X || !U || !x_term || !lamb || !cost || !qfun || !cost_it)
     return fail(I2LQR_ERR_INVALID, "null buffer");
   if ((K == nullptr) != (k == nullptr))
     return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
   i2lqr_handle::Epilogue epi{qfun, outer_iter, max_relax_iter, cost_it, workspace, best_idx,
                              best_cost, false};
-  h->epi = &epi;
+  t_epi = &epi;
   const int rc = dispatch_iterate(h, B, n_iters, 0, X, U, x_term, lamb, obs, cost, K, k, iters,
                                   status, stream);
-  h->epi = nullptr;
+  t_epi = nullptr;
   if (rc != I2LQR_OK) return rc;
   if (!epi.fused) {  // kernel families without the epilogue: the same three steps as launches
     if (int r2 = i2lqr_relax_cost(h, B, X, x_term, qfun, outer_iter, max_relax_iter, cost_it, stream))
       return r2;
     if (best_idx)
-      if (int r3 = i2lqr_argmin(h, B, cost_it, best_idx, best_cost, workspace, stream)) return r3;
+      if (int r3 = i2lqr_argmin(h, B, cost_it, best_idx, best_cost, workspace, workspace_bytes,
+                                stream)) return r3;
   }
   return debug_check(I2LQR_OK, stream);
 }
@@ -1554,11 +1610,15 @@ int i2lqr_init_candidates(i2lqr_handle* h, int64_t B, const void* x0, double lam
 int i2lqr_pick_best(i2lqr_handle* h, int32_t L, int32_t k, const void* cost_it, const void* X,
                     const void* U, int32_t* best, void* x_pred, void* u_pred, void* stream) {
   if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
-  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
-    return fail(I2LQR_ERR_UNSUPPORTED, "controller-round kernels need the problem-major layout");
   if (L < 1 || k < 1) return fail(I2LQR_ERR_INVALID, "need L >= 1 and k >= 1");
-  if (!cost_it || !X || !U || !best || !x_pred || !u_pred)
-    return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (!cost_it || !best) return fail(I2LQR_ERR_INVALID, "null buffer");
+  // X, U, x_pred, u_pred all NULL: the pick alone (a sharded round picks on the gathered costs;
+  // the winner's trajectory is on the rank that solved it) — any layout
+  const bool index_only = !X && !U && !x_pred && !u_pred;
+  if (!index_only && (!X || !U || !x_pred || !u_pred))
+    return fail(I2LQR_ERR_INVALID, "X, U, x_pred, u_pred must all be given or all be NULL");
+  if (!index_only && h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
+    return fail(I2LQR_ERR_UNSUPPORTED, "controller-round kernels need the problem-major layout");
   hipStream_t s = (hipStream_t)stream;
   const int n = h->cfg.n, m = h->cfg.m, N = h->cfg.N;
   if (h->cfg.dtype == I2LQR_F64)
@@ -1644,6 +1704,78 @@ int i2lqr_allgather_costs(i2lqr_handle* h, void* comm, const void* cost_local, v
   const ncclDataType_t dt = h->cfg.dtype == I2LQR_F64 ? ncclDouble : ncclFloat;
   RCCL_TRY(api, api.AllGather(cost_local, cost_all, (size_t)n_local, dt, (ncclComm_t)comm,
                               (hipStream_t)stream));
+  return I2LQR_OK;
+}
+
+int i2lqr_allgather_round(i2lqr_handle* h, void* comm, const void* cost_local, void* cost_all,
+                          int64_t n_local, const void* pack_local, void* pack_all,
+                          int64_t pack_count, void* stream) {
+  if (int rc = check_common(h, n_local)) return rc;
+  if (!comm) return fail(I2LQR_ERR_INVALID, "null communicator");
+  if (pack_count < 0) return fail(I2LQR_ERR_INVALID, "negative pack_count");
+  if ((n_local > 0 && (!cost_local || !cost_all)) || (pack_count > 0 && (!pack_local || !pack_all)))
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (n_local == 0 && pack_count == 0) return I2LQR_OK;
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(I2LQR_ERR_UNSUPPORTED, "librccl could not be loaded");
+  const ncclDataType_t dt = h->cfg.dtype == I2LQR_F64 ? ncclDouble : ncclFloat;
+  // both all-gathers as ONE grouped operation (one launch on the communicator's stream)
+  const bool grouped = api.GroupStart && api.GroupEnd;
+  if (grouped) RCCL_TRY(api, api.GroupStart());
+  ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess;
+  if (n_local > 0)
+    r1 = api.AllGather(cost_local, cost_all, (size_t)n_local, dt, (ncclComm_t)comm,
+                       (hipStream_t)stream);
+  if (r1 == ncclSuccess && pack_count > 0)
+    r2 = api.AllGather(pack_local, pack_all, (size_t)pack_count, dt, (ncclComm_t)comm,
+                       (hipStream_t)stream);
+  if (grouped) {  // the group is closed whatever happened inside it
+    const ncclResult_t r3 = api.GroupEnd();
+    if (r1 == ncclSuccess && r2 == ncclSuccess) RCCL_TRY(api, r3);
+  }
+  RCCL_TRY(api, r1);
+  RCCL_TRY(api, r2);
+  return I2LQR_OK;
+}
+
+int i2lqr_pack_problem(i2lqr_handle* h, int64_t B, const void* X, const void* U, const int64_t* idx,
+                       void* pack, void* stream) {
+  if (int rc = check_common(h, B)) return rc;
+  if (B < 1) return fail(I2LQR_ERR_INVALID, "need at least one problem");
+  if (!X || !U || !idx || !pack) return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED && (B & 63))
+    return fail(I2LQR_ERR_INVALID, "the batch-tiled layout needs a batch that is a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = h->cfg.n, m = h->cfg.m, N = h->cfg.N;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_pack_problem<double>), dim3(1), dim3(256), 0, s, B, n, m, N,
+                       (int)h->cfg.layout, (const double*)X, (const double*)U, idx, (double*)pack);
+  else
+    hipLaunchKernelGGL((k_pack_problem<float>), dim3(1), dim3(256), 0, s, B, n, m, N,
+                       (int)h->cfg.layout, (const float*)X, (const float*)U, idx, (float*)pack);
+  HIP_TRY(hipGetLastError());
+  return I2LQR_OK;
+}
+
+int i2lqr_round_winner(i2lqr_handle* h, int32_t world, int64_t width, int64_t total,
+                       int64_t pack_count, const int64_t* best_padded, const void* pack_all,
+                       void* winner, int64_t* best_global, void* stream) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (world < 1 || width < 1 || total < 0 || total > (int64_t)world * width || pack_count < 0)
+    return fail(I2LQR_ERR_INVALID, "need world >= 1, width >= 1, 0 <= total <= world * width, "
+                "pack_count >= 0");
+  if (!best_padded || !best_global || (pack_count > 0 && (!pack_all || !winner)))
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.dtype == I2LQR_F64)
+    hipLaunchKernelGGL((k_round_winner<double>), dim3(1), dim3(256), 0, s, world, width, total,
+                       pack_count, best_padded, (const double*)pack_all, (double*)winner,
+                       best_global);
+  else
+    hipLaunchKernelGGL((k_round_winner<float>), dim3(1), dim3(256), 0, s, world, width, total,
+                       pack_count, best_padded, (const float*)pack_all, (float*)winner,
+                       best_global);
+  HIP_TRY(hipGetLastError());
   return I2LQR_OK;
 }
 

@@ -33,7 +33,15 @@ constexpr int64_t kGroupWsBatch = 4096;
 // problems (0.168 ms each), the workspace form's time grows with the batch (0.25 ms + 25 us per
 // 1024 problems): 5120 problems 0.285 against 0.330 ms, 6144: 0.306 / 0.339, 8192: 0.354 / 0.348,
 // 12288: 0.583 / 0.502, 20480: 0.872 / 0.804 (tools/_diag/mid_check.py).
-constexpr int64_t kGroupWsTop = 7168;
+// Round 5 (tools/threshold_sweep.py, three shapes): at 8192 problems in fp64 the workspace form is
+// ahead at every shape measured (bicycle6 N=20: 0.313 against 0.337 ms, bicycle4 N=6: 0.106 / 0.136,
+// bicycle4 N=20: 0.279 / 0.314), in fp32 it is behind there (0.250 / 0.197): the top of the range
+// depends on the precision.
+constexpr int64_t kGroupWsTop = 8192;      // fp64
+constexpr int64_t kGroupWsTopF32 = 7168;
+inline int64_t group_ws_top(const i2lqr_config& cfg) {
+  return cfg.dtype == I2LQR_F64 ? kGroupWsTop : kGroupWsTopF32;
+}
 int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B);
 template <class T> hipError_t group_iterate_ws(const i2lqr_config& cfg, const IterArgs<T>& a,
                                                void* ws, hipStream_t stream);

@@ -112,9 +112,57 @@ __global__ __launch_bounds__(64) void k_pick_best(int L, int k, int n, int m, in
     best[1] = bc;
   }
   __syncthreads();
+  if (!X) return;  // index only (sharded rounds: the winner's trajectory lives on its owner's rank)
   const int64_t w = (int64_t)s_best[0] * k + s_best[1];
   for (int e = threadIdx.x; e < n * (N + 1); e += 64) x_pred[e] = X[w * n * (N + 1) + e];
   for (int e = threadIdx.x; e < m * N; e += 64) u_pred[e] = U[w * m * N + e];
+}
+
+// pack[0 : m N] = U[m][N], pack[m N : m N + n (N+1)] = X[n][N+1] of problem idx[0] (clamped to 0 from
+// below: "nothing can win" still packs a defined trajectory), in the reference's orientation
+// (component-major, time contiguous) whatever the layout: layout 0 problem-major [B][c][T],
+// 1 batch-minor [T][c][B], 2 batch-tiled [B/64][T][c][64].  One workgroup.
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_problem(int64_t B, int n, int m, int N, int layout,
+                                                      const T* X, const T* U, const int64_t* idx,
+                                                      T* pack) {
+  int64_t b = idx[0];
+  if (b < 0) b = 0;
+  if (b >= B) b = B - 1;
+  auto fetch = [&](const T* A, int comps, int T_, int c, int t) -> T {
+    if (layout == 0) return A[(b * comps + c) * T_ + t];
+    if (layout == 1) return A[((int64_t)t * comps + c) * B + b];
+    return A[(((b >> 6) * T_ + t) * comps + c) * 64 + (b & 63)];
+  };
+  const int nu = m * N, nx = n * (N + 1);
+  for (int e = threadIdx.x; e < nu; e += blockDim.x) pack[e] = fetch(U, m, N, e / N, e % N);
+  for (int e = threadIdx.x; e < nx; e += blockDim.x)
+    pack[nu + e] = fetch(X, n, N + 1, e / (N + 1), e % (N + 1));
+}
+
+// Winner of a sharded round whose hand-off rode in the all-gather (i2lqr_allgather_round): every
+// rank contributed `width` costs (its shard, padded with +inf) and the pack of its LOCAL winner;
+// best_padded[0] is the flat arg-min over the world x width gathered costs.  The global winner is
+// its owner's local winner (the arg-min of a union is the arg-min of one of its parts), so the
+// owner's pack IS the winner's trajectory: copy it out and translate the padded index into the
+// index of the unpadded, contiguously sharded batch (shard r = [r base + min(r, rem), ...),
+// dist.shard_range).  best_global = {index (-1 if nothing can win), owner rank}.  One workgroup.
+template <class T>
+__global__ __launch_bounds__(256) void k_round_winner(int world, int64_t width, int64_t total,
+                                                      int64_t pack_count,
+                                                      const int64_t* best_padded, const T* pack_all,
+                                                      T* winner, int64_t* best_global) {
+  const int64_t p = best_padded[0];
+  const int64_t q = p < 0 ? 0 : p;  // nothing can win: the first rank's pack, index -1
+  const int64_t owner = q / width, loc = q - owner * width;
+  const int64_t base = total / world, rem = total - base * world;
+  const int64_t lo = owner * base + (owner < rem ? owner : rem);
+  if (threadIdx.x == 0) {
+    best_global[0] = p < 0 ? -1 : lo + loc;
+    best_global[1] = owner;
+  }
+  for (int64_t e = threadIdx.x; e < pack_count; e += blockDim.x)
+    winner[e] = pack_all[owner * pack_count + e];
 }
 
 // broadcast x0 into X[:, :, 0] and zero / reset the per-candidate in/out state for one round:

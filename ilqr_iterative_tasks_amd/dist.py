@@ -72,30 +72,54 @@ def allgather_costs(cost_local: torch.Tensor, total: int | None = None, group=No
 
 
 # Host-side side channel of a process group: the group itself if it runs on gloo, otherwise ONE gloo
-# group made next to it (every rank of the group calls this at the same point: dist.new_group is a
-# collective).  The bring-up below agrees on its outcomes over this channel only, so that no device
-# collective is issued by a rank whose helper thread may still sit inside ncclCommInitRank.
+# group made next to it.  The bring-up below agrees on its outcomes over this channel only, so that
+# no device collective is issued by a rank whose helper thread may still sit inside ncclCommInitRank.
+#
+# dist.new_group is a collective of the DEFAULT group: every rank of the world must enter it, in
+# the same order.  So this function makes the gloo group itself only for the world group (where
+# "every rank of `group` calls host_group at the same point" IS "every rank of the world does");
+# for a sub-group on a device backend the caller creates the host-side group where all world ranks
+# pass (dist.new_group(ranks=..., backend="gloo")) and hands it in as `host`.
+# The cache holds the group object next to its channel: the entry keeps the object alive, so its
+# id() cannot be reused by another group.
 _host_groups: dict = {}
 
 
-def host_group(group=None):
+class _DeviceChannel:
+    """host_group(): no host-side transport could be made — the agreement runs on the group
+    itself, with device tensors (the pre-round-4 behaviour)."""
+
+    def __init__(self, group):
+        self.group = group
+
+
+def host_group(group=None, host=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None
+    if host is not None:
+        return host
     if dist.get_backend(group) == "gloo":
         return group if group is not None else dist.group.WORLD
+    if group is not None and group is not dist.group.WORLD:
+        raise ValueError(
+            "host_group(): a sub-group on a device backend needs its host-side (gloo) group passed "
+            "in (host=...): dist.new_group must be entered by every rank of the default group, "
+            "which the members of a sub-group cannot arrange on their own")
     key = id(group) if group is not None else None
     if key not in _host_groups:
-        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        hg = None
         try:
-            _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+            hg = dist.new_group(backend="gloo")
         except Exception:  # noqa: BLE001  (no gloo transport on this node)
-            # every rank fails the same way (the call is collective): the agreement then runs on
-            # the group itself, with device tensors — the pre-round-4 behaviour
-            _host_groups[key] = DEVICE_CHANNEL
-    return _host_groups[key]
-
-
-DEVICE_CHANNEL = "device-channel"  # host_group(): no host-side transport, use the group itself
+            hg = None
+        # Agree on the outcome over the EXISTING group before anyone uses the new one: a rank whose
+        # new_group failed while the others' succeeded would otherwise sit on another channel than
+        # its peers and the next collective would hang.
+        flag = torch.tensor([1 if hg is not None else 0], dtype=torch.int32,
+                            device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        _host_groups[key] = (group, hg if int(flag.item()) == 1 else _DeviceChannel(group))
+    return _host_groups[key][1]
 
 
 def _agree(flags, hgroup) -> list[bool]:
@@ -105,9 +129,9 @@ def _agree(flags, hgroup) -> list[bool]:
     if hgroup is None:
         return flags
     t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32)
-    if hgroup is DEVICE_CHANNEL:
+    if isinstance(hgroup, _DeviceChannel):
         t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hgroup.group)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=hgroup)
     return [bool(int(v)) for v in t.cpu()]
@@ -172,7 +196,9 @@ class CostExchange:
     host-side barrier, so the first collective of the library's communicator and the next one of
     torch's are ordered the same way on every rank."""
 
-    def __init__(self, solver, group=None, timeout: float | None = None):
+    def __init__(self, solver, group=None, timeout: float | None = None, host=None):
+        """`host`: the host-side (gloo) group of a sub-group on a device backend, created where
+        every rank of the world passes (see host_group); not needed for the world group."""
         import ctypes as C
         from . import _abi
         self.solver, self.lib = solver, solver.lib
@@ -181,7 +207,7 @@ class CostExchange:
         self.world = dist.get_world_size(group) if grouped else 1
         self.rank = dist.get_rank(group) if grouped else 0
         self._group = group
-        hg = self._hgroup = host_group(group)
+        hg = self._hgroup = host_group(group, host)
         # (1) can every rank bind RCCL?
         err = None
         try:
@@ -200,8 +226,9 @@ class CostExchange:
             except Exception as e:  # noqa: BLE001
                 err = e
         box = [payload]
-        if hg is DEVICE_CHANNEL:
-            dist.broadcast_object_list(box, src=0)
+        if isinstance(hg, _DeviceChannel):
+            src0 = dist.get_process_group_ranks(hg.group)[0] if hg.group is not None else 0
+            dist.broadcast_object_list(box, src=src0, group=hg.group)
         elif hg is not None:
             dist.broadcast_object_list(box, src=dist.get_process_group_ranks(hg)[0], group=hg)
         if not box[0]:
@@ -227,8 +254,8 @@ class CostExchange:
         # from a common point on every rank
         if torch.device(solver.device).type == "cuda":
             torch.cuda.synchronize(solver.device)
-        if hg is DEVICE_CHANNEL:
-            dist.barrier()
+        if isinstance(hg, _DeviceChannel):
+            dist.barrier(group=hg.group)
         elif hg is not None:
             dist.barrier(group=hg)
 
@@ -294,6 +321,31 @@ class CostExchange:
                 C.c_void_p(out.data_ptr()), n, self.solver._stream()))
         return out
 
+    def allgather_round(self, cost_local: torch.Tensor, pack_local: torch.Tensor,
+                        cost_all: torch.Tensor | None = None,
+                        pack_all: torch.Tensor | None = None):
+        """Costs AND every rank's local-winner pack in ONE grouped RCCL operation
+        (i2lqr_allgather_round), on the current stream: (cost_all[world * n], pack_all[world, P]).
+        Same n and P on every rank (ragged shards are padded by the caller)."""
+        import ctypes as C
+        n, P = cost_local.numel(), pack_local.numel()
+        dt, dev = self.solver.dtype, cost_local.device
+        if cost_all is None:
+            cost_all = torch.empty(n * self.world, dtype=dt, device=dev)
+        if pack_all is None:
+            pack_all = torch.empty(self.world, P, dtype=dt, device=dev)
+        for t in (cost_local, pack_local, cost_all, pack_all):
+            if t.dtype != dt or not t.is_contiguous():
+                raise ValueError(f"round tensors must be contiguous {dt}")
+        if cost_all.numel() != n * self.world or pack_all.numel() != P * self.world:
+            raise ValueError("cost_all / pack_all must hold world x the local sizes")
+        with _device_ctx(self.solver.device):
+            self.solver._check(self.lib.i2lqr_allgather_round(
+                self.solver._handle, self._comm, C.c_void_p(cost_local.data_ptr()),
+                C.c_void_p(cost_all.data_ptr()), n, C.c_void_p(pack_local.data_ptr()),
+                C.c_void_p(pack_all.data_ptr()), P, self.solver._stream()))
+        return cost_all, pack_all
+
     def broadcast(self, buf: torch.Tensor, root: int) -> torch.Tensor:
         """The winner's hand-off (i2lqr_broadcast_winner: one ncclBroadcast, in place): `buf` on rank
         `root` reaches every rank's `buf` (same shape and dtype everywhere), on the current stream."""
@@ -326,6 +378,122 @@ def _device_ctx(device):
     return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
+class TorchExchange:
+    """The exchanges of a sharded round over torch.distributed — the same three calls as
+    CostExchange (allgather / allgather_round / broadcast) for process groups without the library's
+    own communicator: gloo in the CPU tests and on the shared-GPU box (device tensors are staged
+    through the host there), torch's NCCL group as the fallback of a failed native bring-up.  A
+    world of one returns its inputs."""
+
+    def __init__(self, group=None):
+        self.group = group
+        grouped = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if grouped else 1
+        self.rank = dist.get_rank(group) if grouped else 0
+        self._host = grouped and dist.get_backend(group) == "gloo"
+
+    def _stage(self, t):
+        return t.cpu() if (self._host and t.device.type != "cpu") else t
+
+    def allgather(self, cost_local, out=None, total=None):
+        res = allgather_costs(cost_local, total, self.group) if self.world > 1 else cost_local
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def allgather_round(self, cost_local, pack_local, cost_all=None, pack_all=None):
+        if self.world == 1:
+            return cost_local, pack_local.reshape(1, -1)
+        ca = allgather_costs(cost_local.contiguous(), None, self.group)
+        pa = allgather_costs(pack_local.contiguous(), None, self.group).view(self.world, -1)
+        if cost_all is not None:
+            cost_all.copy_(ca)
+            ca = cost_all
+        if pack_all is not None:
+            pack_all.copy_(pa.view_as(pack_all))
+            pa = pack_all
+        return ca, pa
+
+    def broadcast(self, buf, root):
+        if self.world == 1:
+            return buf
+        src = dist.get_process_group_ranks(self.group)[root] if self.group is not None else root
+        t = self._stage(buf)
+        dist.broadcast(t, src=src, group=self.group)
+        if t is not buf:
+            buf.copy_(t)
+        return buf
+
+    def close(self):
+        pass
+
+
+def padded_width(total: int, world: int) -> int:
+    """Largest shard of shard_range(total, ., world): what every rank pads its costs to."""
+    return (total + world - 1) // world
+
+
+def _noop(name):
+    pass
+
+
+def flat_round(exchange, cost_local, pack_local, total, argmin, round_winner, bufs=None,
+               on_phase=_noop):
+    """The exchange of ONE sharded round whose pick is the flat arg-min — no host round trip.
+
+    cost_local[n_local]: this rank's relaxed costs (its shard_range share of `total` candidates);
+    pack_local[P]: the packed trajectory (U, X) of this rank's LOCAL winner.  One grouped all-gather
+    carries both (the global winner is the local winner of its owner), then every rank evaluates
+      argmin(cost_all) -> (best_padded[1], best_cost[1])              (i2lqr_argmin)
+      round_winner(width, total, best_padded, pack_all) -> (winner[P], best_global[2])
+    (i2lqr_round_winner: owner's pack + index in the unpadded batch) on the same gathered data.
+    Returns dict(cost_all (padded to world x width with +inf), best_idx int64[2] = (index, owner),
+    best_cost, pack).  Everything is enqueued on the current stream."""
+    world = exchange.world
+    width = padded_width(total, world)
+    n_local = cost_local.numel()
+    if n_local != width:  # ragged: pad with +inf, which never wins
+        padded = bufs["padded"] if bufs else torch.empty(width, dtype=cost_local.dtype,
+                                                         device=cost_local.device)
+        padded.fill_(float("inf"))
+        padded[:n_local] = cost_local
+        cost_local = padded
+    on_phase("start")
+    cost_all, pack_all = exchange.allgather_round(
+        cost_local, pack_local, bufs["cost_all"] if bufs else None,
+        bufs["pack_all"] if bufs else None)
+    on_phase("gathered")
+    best_padded, best_cost = argmin(cost_all)
+    pack, best_global = round_winner(width, total, best_padded, pack_all)
+    on_phase("picked")
+    return dict(cost_all=cost_all, best_idx=best_global, best_cost=best_cost, pack=pack,
+                width=width)
+
+
+def lexi_round(exchange, cost_local, total, pick, pack_of, pack_numel, on_phase=_noop):
+    """The exchange of ONE sharded round with the reference's list-of-lists pick (the controller:
+    utils/base.py:462-471): all-gather of the costs, pick(cost_all) -> flat index of the winner on
+    the HOST (the controller needs it there anyway: its safe-set bookkeeping is host state, and the
+    root of a broadcast must be known on the host), then ONE broadcast of the winner's pack from the
+    rank that solved it (pack_of(local index) -> tensor[pack_numel], called on the owner only).
+    on_phase(name) is called at "start", "gathered", "picked" and "handed_over".
+    Returns dict(cost_all[total], index, owner, pack)."""
+    on_phase("start")
+    cost_all = exchange.allgather(cost_local, total=total)
+    on_phase("gathered")
+    index = int(pick(cost_all))
+    on_phase("picked")
+    owner, loc = owner_of(max(index, 0), total, exchange.world)
+    if exchange.rank == owner:
+        pack = pack_of(loc).contiguous()
+    else:
+        pack = torch.empty(pack_numel, dtype=cost_all.dtype, device=cost_all.device)
+    exchange.broadcast(pack, owner)
+    on_phase("handed_over")
+    return dict(cost_all=cost_all, index=index, owner=owner, pack=pack)
+
+
 def select_best_flat(cost_all: torch.Tensor) -> tuple[int, float]:
     """Flat arg-min with first-index tie-break (used for the synthetic 10^4..10^6 batches)."""
     val, idx = torch.min(cost_all, dim=0)
@@ -356,71 +524,31 @@ def owner_of(index: int, total: int, world: int) -> tuple[int, int]:
 
 
 class ShardedRound:
-    """The two exchanges of ONE sharded control round (utils/base.py:391-471): every
-    rank solves its contiguous shard of the candidates, then
-      gather_costs()  the all-gather of cost_it — afterwards every rank evaluates the pick
-                      (utils/base.py:462-465) on the same full vector —, and
-      winner()        the hand-off of the winner's (U, X) from the rank that solved it: the
-                      reference goes on with that trajectory (u_pred[:, 0] is applied,
-                      x_pred[:, -1] seeds the next round: utils/base.py:466-471).  ONE broadcast of
-                      m N + n (N + 1) numbers from the owner; re-solving the winner on every rank
-                      instead would cost a whole solve per round.
-    `native`: a CostExchange (RCCL through the C-ABI: i2lqr_allgather_costs,
-    i2lqr_broadcast_winner; host arrays are staged through the solver's device); otherwise
-    torch.distributed on the process group (gloo in the CPU tests, host tensors).  Without a
-    process group this is a world of one and both calls return their inputs."""
+    """What a sharded controller is given (control.iLqr(sharded=...)): the exchange of its process
+    group — `native`, a CostExchange (RCCL through the C-ABI), else a TorchExchange on `group` — and
+    a count of the collectives issued (tests: two per solved round, the all-gather of cost_it and
+    the winner's hand-off; SURVEY.md §8e, utils/base.py:391-471).  The round itself is
+    HipCandidateSolver.sharded_round (device tensors end to end); without a process group this
+    is a world of one."""
 
     def __init__(self, group=None, native: "CostExchange | None" = None):
         self.group, self.native = group, native
-        grouped = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if grouped else 1
-        self.rank = dist.get_rank(group) if grouped else 0
-        self.collectives = 0  # exchanges issued (tests: two per solved round)
+        self.exchange = native if native is not None else TorchExchange(group)
+        self.world, self.rank = self.exchange.world, self.exchange.rank
+        self.collectives = 0
 
     def shard(self, total: int) -> tuple[int, int]:
         return shard_range(total, self.rank, self.world)
 
-    def gather_costs(self, cost_local, total: int):
-        import numpy as np
-        cost_local = np.ascontiguousarray(cost_local, dtype=np.float64)
+    # counted pass-throughs (the round functions above take `self` as their exchange)
+    def allgather(self, cost_local, out=None, total=None):
         self.collectives += 1
-        if self.world == 1:
-            return cost_local
-        if self.native is not None:
-            dev, dt = self.native.solver.device, self.native.solver.dtype
-            out = self.native.allgather(torch.as_tensor(cost_local).to(dev, dt), total=total)
-            return out.double().cpu().numpy()
-        t = torch.as_tensor(cost_local)
-        if dist.get_backend(self.group) == "nccl":
-            t = t.cuda()
-        return allgather_costs(t, total, self.group).cpu().numpy()
+        return self.exchange.allgather(cost_local, out, total=total)
 
-    def winner(self, index: int, total: int, U_local, X_local, shapes):
-        """(U, X) of candidate `index` on every rank.  U_local / X_local: this rank's solved
-        trajectories (lists or arrays over its shard; read on the owner only); shapes = (U.shape,
-        X.shape) so that the other ranks can size their receive buffer."""
-        import numpy as np
-        owner, loc = owner_of(index, total, self.world)
-        (us, xs) = shapes
-        nu, nx = int(np.prod(us)), int(np.prod(xs))
+    def allgather_round(self, cost_local, pack_local, cost_all=None, pack_all=None):
         self.collectives += 1
-        if self.world == 1:
-            return np.asarray(U_local[loc], float), np.asarray(X_local[loc], float)
-        pack = np.zeros(nu + nx)
-        if self.rank == owner:
-            pack[:nu] = np.asarray(U_local[loc], float).ravel()
-            pack[nu:] = np.asarray(X_local[loc], float).ravel()
-        if self.native is not None:
-            dev, dt = self.native.solver.device, self.native.solver.dtype
-            if dt != torch.float64:
-                raise ValueError("the native hand-off carries the handle's dtype: use an fp64 handle")
-            buf = torch.as_tensor(pack).to(dev, dt)
-            pack = self.native.broadcast(buf, owner).cpu().numpy()
-        else:
-            t = torch.as_tensor(pack)
-            if dist.get_backend(self.group) == "nccl":
-                t = t.cuda()
-            src = dist.get_process_group_ranks(self.group)[owner] if self.group is not None else owner
-            dist.broadcast(t, src=src, group=self.group)
-            pack = t.cpu().numpy()
-        return pack[:nu].reshape(us), pack[nu:].reshape(xs)
+        return self.exchange.allgather_round(cost_local, pack_local, cost_all, pack_all)
+
+    def broadcast(self, buf, root):
+        self.collectives += 1
+        return self.exchange.broadcast(buf, root)

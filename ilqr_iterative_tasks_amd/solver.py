@@ -209,19 +209,25 @@ class BatchedILQR:
         if lamb0 is not None:
             buf["lamb"].fill_(float(lamb0))
 
-    def problem(self, buf: dict, idx: torch.Tensor) -> dict:
-        """U[m, N] and X[n, N+1] of problem `idx` (a device int64 tensor of one element, e.g. the
-        pick: no host synchronisation) in the reference's orientation, whatever the layout."""
-        i = idx.reshape(()).clamp(min=0)
+    def problem(self, buf: dict, idx) -> dict:
+        """U[m, N] and X[n, N+1] of problem `idx` in the reference's orientation, whatever the
+        layout.  `idx`: a device int64 tensor of one element (e.g. the pick) — gathered with
+        index_select, so NO host synchronisation (indexing with a 0-dim device tensor would read
+        it back) and the call can sit inside a captured graph — or a host int."""
+        if isinstance(idx, torch.Tensor):
+            i = idx.reshape(1).clamp(min=0).to(torch.int64)
+        else:
+            i = torch.tensor([max(int(idx), 0)], dtype=torch.int64, device=self.device)
         out = {}
         for key in ("U", "X"):
             t = buf[key]
-            if self.batch_tiled:
-                out[key] = t[i // 64, :, :, i % 64].transpose(0, 1).contiguous()
-            elif self.batch_minor:
-                out[key] = t[:, :, i].transpose(0, 1).contiguous()
-            else:
-                out[key] = t[i].clone()
+            if self.batch_tiled:    # [B/64, T, c, 64]: tile i // 64, lane i % 64
+                tile = t.index_select(0, torch.div(i, 64, rounding_mode="floor"))[0]
+                out[key] = tile.index_select(2, i % 64)[:, :, 0].transpose(0, 1).contiguous()
+            elif self.batch_minor:  # [T, c, B]
+                out[key] = t.index_select(2, i)[:, :, 0].transpose(0, 1).contiguous()
+            else:                   # [B, c, T]
+                out[key] = t.index_select(0, i)[0].clone()
         return out
 
     # -- the path ---------------------------------------------------------------------------
@@ -352,11 +358,61 @@ class BatchedILQR:
                 self._ptr(x_pred, (self.n, self.N + 1), name="x_pred"),
                 self._ptr(u_pred, (self.m, self.N), name="u_pred"), self._stream()))
 
-    def _argmin_workspace(self, B: int) -> C.c_void_p:
+    def pick_index(self, L: int, k: int, cost_it, best=None):
+        """The pick of utils/base.py:462-465 alone (list-of-lists order over L laps of k candidates,
+        then the first minimum of that lap) on a device vector cost_it[L * k], e.g. the gathered
+        costs of a sharded round; returns best[2] int32 (device) = (lap position, candidate
+        position).  i2lqr_pick_best without the trajectory gather: any layout."""
+        best = self.empty(2, dtype=torch.int32) if best is None else best
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_pick_best(
+                self._handle, int(L), int(k), self._ptr(cost_it, (L * k,), name="cost_it"),
+                C.c_void_p(None), C.c_void_p(None), self._ptr(best, (2,), torch.int32, name="best"),
+                C.c_void_p(None), C.c_void_p(None), self._stream()))
+        return best
+
+    def pack_problem(self, buf: dict, idx: torch.Tensor, pack: torch.Tensor | None = None):
+        """pack[m N + n (N+1)] = (U, X) of problem idx (device int64[1]) in the reference's
+        orientation (i2lqr_pack_problem: one launch, any layout, no host synchronisation)."""
+        B = self.batch_of(buf["X"])
+        P = self.m * self.N + self.n * (self.N + 1)
+        pack = self.empty(P) if pack is None else pack
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_pack_problem(
+                self._handle, B, self._ptr(buf["X"], self.shape("X", B), name="X"),
+                self._ptr(buf["U"], self.shape("U", B), name="U"),
+                self._ptr(idx.reshape(1), (1,), torch.int64, name="idx"),
+                self._ptr(pack, (P,), name="pack"), self._stream()))
+        return pack
+
+    def unpack(self, pack: torch.Tensor) -> tuple:
+        """(U[m, N], X[n, N+1]) views of a pack."""
+        nu = self.m * self.N
+        return pack[:nu].view(self.m, self.N), pack[nu:].view(self.n, self.N + 1)
+
+    def round_winner(self, world: int, width: int, total: int, best_padded, pack_all,
+                     winner=None, best_global=None):
+        """i2lqr_round_winner: the owner's pack and (index in the unpadded batch, owner rank) from
+        the flat arg-min over the world x width gathered costs; device tensors, one launch."""
+        P = pack_all.numel() // world
+        winner = self.empty(P) if winner is None else winner
+        best_global = self.empty(2, dtype=torch.int64) if best_global is None else best_global
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_round_winner(
+                self._handle, int(world), int(width), int(total), P,
+                self._ptr(best_padded.reshape(1), (1,), torch.int64, name="best_padded"),
+                self._ptr(pack_all.reshape(world, P), (world, P), name="pack_all"),
+                self._ptr(winner, (P,), name="winner"),
+                self._ptr(best_global, (2,), torch.int64, name="best_global"), self._stream()))
+        return winner, best_global
+
+    def _argmin_workspace(self, B: int) -> tuple:
+        """(pointer, bytes) of the pick's device scratch, grown to i2lqr_argmin_workspace_bytes(B);
+        the size travels with the pointer and the library refuses a workspace that is too small."""
         need = int(self.lib.i2lqr_argmin_workspace_bytes(B))
         if self._argmin_ws is None or self._argmin_ws.numel() < need:
             self._argmin_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return C.c_void_p(self._argmin_ws.data_ptr())
+        return C.c_void_p(self._argmin_ws.data_ptr()), C.c_int64(self._argmin_ws.numel())
 
     def iterate_pick(self, buf: dict, n_iters: int, qfun, outer_iter: int, max_relax_iter: int = 55,
                      cost_it=None, pick: bool = True, best=None):
@@ -377,18 +433,18 @@ class BatchedILQR:
                 int(max_relax_iter), self._ptr(cost_it, (B,), name="cost_it"),
                 C.c_void_p(idx.data_ptr()) if pick else C.c_void_p(None),
                 C.c_void_p(val.data_ptr()) if pick else C.c_void_p(None),
-                self._argmin_workspace(B) if pick else C.c_void_p(None), self._stream()))
+                *(self._argmin_workspace(B) if pick else (C.c_void_p(None), C.c_int64(0))),
+                self._stream()))
         return cost_it, ((idx, val) if pick else None)
 
     def argmin(self, cost_it):
         """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1])."""
         B = cost_it.shape[0]
-        self._argmin_workspace(B)
         idx = self.empty(1, dtype=torch.int64)
         val = self.empty(1)
         with torch.cuda.device(self.device):
             self._check(self.lib.i2lqr_argmin(
                 self._handle, B, self._ptr(cost_it, (B,), name="cost_it"),
                 C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()),
-                C.c_void_p(self._argmin_ws.data_ptr()), self._stream()))
+                *self._argmin_workspace(B), self._stream()))
         return idx, val

@@ -70,11 +70,16 @@ def _step(cfg: I2lqrConfig, x: np.ndarray, u: np.ndarray) -> np.ndarray:
     return xn
 
 
-def make_batch(cfg: I2lqrConfig, B: int, seed: int = SEED, offset: int = 0) -> dict:
+def make_batch(cfg: I2lqrConfig, B: int, seed: int = SEED, offset: int = 0,
+               variant: str | None = None) -> dict:
     """B problems: X[B,n,N+1] (x0 in [:, :, 0], rest 0), U = 0, x_term, lamb = 1, obs[B,6].
 
     `offset` selects a disjoint slice of the (conceptually infinite) problem stream so that rank r
-    of a sharded run draws problems [offset, offset + B)."""
+    of a sharded run draws problems [offset, offset + B).
+    `variant`: other distributions of the same stream, for schedules and thresholds that must not be
+    fitted to the default one (tools/solve_bench.py): "all_obstacle" — every problem carries the
+    obstacle; "far_targets" — the target is the end of a rollout twice as long as the horizon (not
+    reachable within it: longer accept / reject histories, more survivors per chunk)."""
     rng = np.random.default_rng([seed, offset])
     n, m, N = cfg.n, cfg.m, cfg.N
     x0 = np.zeros((B, n))
@@ -94,10 +99,16 @@ def make_batch(cfg: I2lqrConfig, B: int, seed: int = SEED, offset: int = 0) -> d
     x = x0.copy()
     for t in range(N):
         x = _step(cfg, x, urand[t])
+    if variant == "far_targets":
+        for t in range(N):
+            x = _step(cfg, x, urand[N - 1 - t])
     X = np.zeros((B, n, N + 1))
     X[:, :, 0] = x0
     obs = np.tile(np.array([31.0, -3.0, 8.0, 6.0, 0.0, 0.0]), (B, 1))
-    obs[1::2, 5] = -1.0  # every second problem: no obstacle
+    if variant != "all_obstacle":
+        obs[1::2, 5] = -1.0  # every second problem: no obstacle
+    if variant not in (None, "all_obstacle", "far_targets"):
+        raise ValueError(f"unknown workload variant {variant!r}")
     if cfg.system_id == _abi.SYS_QUAD12:
         obs[:, :4] = [2.0, 2.0, 0.5, 0.5]
     return dict(X=X, U=np.zeros((B, m, N)), x_term=x, lamb=np.ones(B), obs=obs)

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define I2LQR_ABI_VERSION 1
+#define I2LQR_ABI_VERSION 2
 #define I2LQR_MAX_N 12
 #define I2LQR_MAX_M 4
 #define I2LQR_MAX_HORIZON 64
@@ -161,10 +161,11 @@ int i2lqr_set_workspace(i2lqr_handle* h, void* workspace, int64_t bytes);
 
 /*
  * Chunked form of i2lqr_solve for the batch-minor / batch-tiled layouts: from `min_batch`
- * problems the solve runs in chunks — the first 8 to 12 iterations long (as many as leave about
- * "wave_tail" survivors on the benchmark workload's iteration-count distribution), then 4, then
- * doubling — and packs the still-running problems into dense work sets between chunks (no host
- * synchronisation); once few problems are left ("wave_tail" option below) they are finished by the
+ * problems the solve runs in chunks of 8, 4, then doubling iterations and packs the still-running
+ * problems into dense work sets between chunks (no host synchronisation: the live count stays in
+ * device memory and decides there which kernel of a round does the work — the schedule holds no
+ * constant derived from a workload); once few problems are left ("wave_tail" option below) they are
+ * finished by the
  * speculative sixteen-lane kernel, which writes their results straight to the caller's arrays
  * (the one-problem-per-wavefront kernel where that is not built).
  * ilqr() runs 1..max_iter iterations per problem (control/iterative_ilqr.py:29-84), so the end of a
@@ -215,8 +216,11 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     algorithm, different summation order: results agree with the single launch
  *                     to the solve tolerance (1e-8), not bit for bit (fp32: 1-2 % of the problems
  *                     settle an accept / reject tie the other way and stop at a different
- *                     iteration).  0: off; automatic: 8192 with the speculative kernel, 2048 with
+ *                     iteration).  0: off; automatic: 12288 with the speculative kernel, 2048 with
  *                     the one-problem-per-wavefront kernel.
+ *   "first_chunk", "chunk_step"  chunked solve only: length of the first chunk (automatic: 8) and
+ *                     of the one behind it (automatic: 4) — hand-tuned schedules, there to measure
+ *                     the automatic one against (tools/solve_bench.py).  Same results either way.
  * Problem-major layout, i2lqr_iterate / i2lqr_solve:
  *   "group_lanes"     lanes of a wavefront that work on one problem: 64 (one problem per
  *                     wavefront, each lane one element of the Riccati step's products), 8 (eight
@@ -342,13 +346,16 @@ int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_te
 /*
  * Flat arg-min over cost_it[B] with first-index tie-break (the reduction the all-gather feeds;
  * utils/base.py:462-465 applies it per lap, see the Python host for the list-of-lists form).
- * Out (device): best_idx[1] (int64), best_cost[1] (`real`).  `workspace` must hold
- * i2lqr_argmin_workspace_bytes(B) bytes.  If no element can win — B == 0, or every cost is NaN —
- * best_idx = -1 and best_cost = +inf (Python's min() of an empty list raises instead).
+ * Out (device): best_idx[1] (int64), best_cost[1] (`real`).  `workspace` is device scratch of
+ * `workspace_bytes` bytes; i2lqr_argmin_workspace_bytes(B) is what B candidates need (it GROWS
+ * with B: one (value, index) pair per workgroup of the kernel that carries the pick) and a smaller
+ * workspace is refused with I2LQR_ERR_INVALID — the library never writes past the size it was
+ * given.  If no element can win — B == 0, or every cost is NaN — best_idx = -1 and best_cost =
+ * +inf (Python's min() of an empty list raises instead).
  */
 int64_t i2lqr_argmin_workspace_bytes(int64_t B);
 int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_idx,
-                 void* best_cost, void* workspace, void* stream);
+                 void* best_cost, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * One control round in one call — i2lqr_iterate followed by i2lqr_relax_cost on the returned X and
@@ -361,13 +368,19 @@ int i2lqr_argmin(i2lqr_handle* h, int64_t B, const void* cost_it, int64_t* best_
  * their dependent launch boundaries cost 10 % of the round).  Every other kernel family runs the
  * three steps as separate launches behind this call.
  * best_idx NULL: costs only (the sharded path: the all-gather sits between the costs and the
- * pick); then best_cost and workspace are not read.  `workspace`: i2lqr_argmin_workspace_bytes(B).
+ * pick); then best_cost and workspace are not read.  `workspace` / `workspace_bytes`: as for
+ * i2lqr_argmin (at least i2lqr_argmin_workspace_bytes(B), checked).
+ * Concurrency: a handle serves ONE stream at a time.  Calls on one handle from
+ * two host threads do not share host state (the epilogue of a call is thread-local), and launches
+ * of one handle that overlap on two streams draw their last-workgroup-done tickets from different
+ * device words as long as fewer than 16 are in flight; each such call must be given its OWN
+ * workspace (the partial minima live there).
  */
 int i2lqr_iterate_pick(i2lqr_handle* h, int64_t B, int32_t n_iters, void* X, void* U,
                        const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
                        int32_t* iters, int32_t* status, const int32_t* qfun, int32_t outer_iter,
                        int32_t max_relax_iter, void* cost_it, int64_t* best_idx, void* best_cost,
-                       void* workspace, void* stream);
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * The one collective of the path (multi-GPU): all-gather of the per-candidate
@@ -417,6 +430,37 @@ int i2lqr_broadcast_winner(i2lqr_handle* h, void* comm, void* buf, int64_t count
                            void* stream);
 
 /*
+ * The same two steps WITHOUT a host round trip, for rounds whose pick is the flat arg-min (the
+ * synthetic batches; any caller that does not need the list-of-lists order): the root of a broadcast
+ * must be known on the host, i.e. the host would have to read the pick back before it could enqueue
+ * the hand-off.  Instead every rank packs the trajectory of its LOCAL winner (the global winner is
+ * the local winner of the rank that owns it) and the packs ride along with the costs:
+ *
+ * i2lqr_allgather_round — ncclAllGather of cost_local[n_local] into cost_all[world * n_local] and
+ *   ncclAllGather of pack_local[pack_count] into pack_all[world * pack_count] as ONE grouped RCCL
+ *   operation (ncclGroupStart / ncclGroupEnd) on `stream`.  Same n_local / pack_count on every rank
+ *   (ragged shards: pad the costs with +inf).  No counterpart in the reference (one process).
+ * i2lqr_round_winner — after i2lqr_argmin over cost_all (best_padded[1], device): copies the owner's
+ *   pack to winner[pack_count] and writes best_global[2] = {index of the winner in the unpadded
+ *   batch of `total` candidates sharded contiguously over `world` ranks (first ranks take the
+ *   remainder), owner rank}; `width` = n_local of the all-gather.  Replaces, together with the
+ *   gather, utils/base.py:462-471 (pick + "go on with the winner's trajectory") on every rank.
+ * i2lqr_pack_problem — pack[m N + n (N+1)] = (U[m][N], X[n][N+1]) of problem idx[0] (device int64,
+ *   e.g. a pick; clamped into [0, B)) in the reference's orientation, from X / U in the handle's
+ *   layout: what a rank contributes as pack_local, and what the owner broadcasts with
+ *   i2lqr_broadcast_winner.  (The deep copy of the winner, utils/base.py:453-455, :466-469.)
+ * Everything stays enqueued on the stream: the next round can be launched behind it.
+ */
+int i2lqr_pack_problem(i2lqr_handle* h, int64_t B, const void* X, const void* U, const int64_t* idx,
+                       void* pack, void* stream);
+int i2lqr_allgather_round(i2lqr_handle* h, void* comm, const void* cost_local, void* cost_all,
+                          int64_t n_local, const void* pack_local, void* pack_all,
+                          int64_t pack_count, void* stream);
+int i2lqr_round_winner(i2lqr_handle* h, int32_t world, int64_t width, int64_t total,
+                       int64_t pack_count, const int64_t* best_padded, const void* pack_all,
+                       void* winner, int64_t* best_global, void* stream);
+
+/*
  * Controller round on the device (problem-major layout).
  *
  * i2lqr_select_candidates — replaces iLqr.select_close_ss (utils/base.py:332-341) and the
@@ -431,7 +475,9 @@ int i2lqr_broadcast_winner(i2lqr_handle* h, void* comm, void* buf, int64_t count
  * i2lqr_init_candidates — uvar = 0, xvar[:, 0] = x0, lamb = lamb0 for B candidates (:393, :405-408).
  * i2lqr_pick_best — the pick of utils/base.py:462-469 on cost_it[L][k] (lexicographic over the
  *   laps' lists, then first minimum); copies the winner's X, U to x_pred[n][N+1], u_pred[m][N];
- *   best[2] = {lap position, candidate position} (int32, device).
+ *   best[2] = {lap position, candidate position} (int32, device).  X, U, x_pred, u_pred may ALL be
+ *   NULL: the pick alone — what a sharded round runs on the gathered cost vector, the winner's
+ *   trajectory being on the rank that solved it (i2lqr_broadcast_winner hands it over).
  */
 int i2lqr_select_candidates(i2lqr_handle* h, int32_t L, int32_t Tmax, const void* ss,
                             const int32_t* T, const int32_t* qfun, const void* x_guess,

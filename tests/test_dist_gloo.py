@@ -338,6 +338,67 @@ def test_sharded_calc_input_world2_drives_config1_like_the_unsharded_controller(
     assert s0[2] == s1[2] == 2 * s0[1] and s0[1] == ref_solver.calls  # gather + hand-off per round
 
 
+def _flat_round_worker(rank, world, port, total, out_dir):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import OracleCandidateSolver
+    from ilqr_iterative_tasks_amd import default_config, workloads
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    idist.init_from_env("gloo")
+    cfg = default_config("bicycle4", 6)
+    host = workloads.make_batch(cfg, total)
+    x0 = host["X"][0, :, 0]
+    qfun = np.random.default_rng(3).integers(0, 50, total).astype(np.int32)
+    lo, hi = idist.shard_range(total, rank, world)
+    rounds = idist.ShardedRound()
+    res = OracleCandidateSolver().sharded_round(
+        cfg, torch.as_tensor(x0), torch.as_tensor(host["x_term"][lo:hi]),
+        torch.as_tensor(qfun[lo:hi]), 1.0, rounds, total, obs_rec=(31, -3, 8, 6, 0, 0))
+    np.savez(os.path.join(out_dir, f"flat{rank}.npz"), idx=res["best_idx"].numpy(),
+             U=res["U"].numpy(), X=res["X"].numpy(), cost_all=res["cost_all"].numpy(),
+             width=res["width"], collectives=rounds.collectives)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [12, 13])
+def test_flat_sharded_round_world2_hands_the_winner_over_inside_the_all_gather(tmp_path, total):
+    """dist.flat_round (what HipCandidateSolver.sharded_round and bench.py --gpus N run) on two
+    ranks, gloo, oracle-backed double: every rank packs its LOCAL winner, ONE exchange carries the
+    costs and the packs, and both ranks end with the index of the global first-index arg-min and
+    ITS trajectory — equal to what one process finds over all candidates.  13 candidates: ragged
+    shards (7 + 6), the short one padded with +inf."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import OracleCandidateSolver
+    from oracle import oracle as orc
+    from ilqr_iterative_tasks_amd import default_config, workloads
+    port = _free_port()
+    mp.spawn(_flat_round_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    cfg = default_config("bicycle4", 6)
+    host = workloads.make_batch(cfg, total)
+    qfun = np.random.default_rng(3).integers(0, 50, total).astype(np.int32)
+    out = OracleCandidateSolver().solve(cfg, host["X"][0, :, 0], host["x_term"], np.ones(total),
+                                        (31, -3, 8, 6, 0, 0))
+    cost = orc.relax_cost_batch(cfg, out["X"], host["x_term"], qfun, 0, 55)
+    want = int(np.flatnonzero(cost == cost.min())[0])
+    for r in range(2):
+        g = np.load(tmp_path / f"flat{r}.npz")
+        assert int(g["idx"][0]) == want and int(g["idx"][1]) == idist.owner_of(want, total, 2)[0]
+        np.testing.assert_array_equal(g["U"], out["U"][want])
+        np.testing.assert_array_equal(g["X"], out["X"][want])
+        assert int(g["collectives"]) == 1  # ONE exchange per round
+        w = int(g["width"])
+        assert w == (total + 1) // 2 and g["cost_all"].shape == (2 * w,)
+        sizes = [idist.shard_range(total, q, 2) for q in range(2)]
+        unpadded = np.concatenate([g["cost_all"][q * w: q * w + hi - lo]
+                                   for q, (lo, hi) in enumerate(sizes)])
+        np.testing.assert_array_equal(unpadded, cost)
+
+
 def test_owner_of_matches_shard_range():
     for total in (1, 7, 16, 1000):
         for world in (1, 2, 3, 8):

@@ -71,13 +71,20 @@ def test_bench_under_torchrun_world_of_one_uses_the_native_rccl_exchange():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["exchange"]["nccl_world"] == 1
-    assert d["exchange"]["path"] == "native" and "i2lqr_allgather_costs" in d["exchange"]["what"]
+    assert d["exchange"]["path"] == "native" and "i2lqr_allgather_round" in d["exchange"]["what"]
     assert d["exchange"]["ms_per_step"] > 0
+    # the timed step is the product's sharded round, the winner's hand-off included; the
+    # two-collective form (read-back + i2lqr_broadcast_winner) is timed beside it
+    assert "sharded_round" in d["config"]["step"] and "hand-off" in d["config"]["step"]
+    assert set(d["exchange"]["phases_ms"]) == {"gather_costs_and_packs", "pick_and_winner"}
+    bv = d["exchange"]["broadcast_variant"]
+    assert bv["ms_per_step"] > 0 and bv["phases_ms"]["broadcast_winner"] > 0
+    assert d["config"]["launches_per_step"] == 5
     # the driver keeps the head of the line: the multi-rank facts come before the long objects
     head = lines[0][:2000]
     assert '"exchange"' in head and '"per_rank_iterations_per_s"' in head and '"nccl_world"' in head
     assert lines[0].index('"exchange"') < lines[0].index('"roofline"') < lines[0].index('"extra"')
-    assert d["exchange"]["bytes_per_rank"] == 8192
+    assert d["exchange"]["bytes_per_rank"] == (1024 + 2 * 20 + 6 * 21) * 8  # costs + the local winner's pack
     assert len(d["per_rank_iterations_per_s"]) == 1
     s4 = d["extra"]["config4_strong"]
     assert s4["global_batch"] == 1 << 20 and s4["batch_per_gpu"] == 1 << 20
@@ -115,6 +122,10 @@ def test_two_ranks_sharing_the_gpu_solve_their_shards_and_fall_back_together():
     ex, att = d["exchange"], d["launcher"]["attempts"]
     print("exchange:", ex, "launcher:", d["launcher"])
     assert ex["path"] == "torch" and "torch.distributed" in ex["what"]
+    assert "sharded_round" in d["config"]["step"]
+    assert ex["broadcast_variant"]["phases_ms"]["broadcast_winner"] > 0
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)  # kept: copied to profiles/ as the round's record
+    (ROOT / "gpurun_out" / "two_ranks_shared_gpu.json").write_text(json.dumps(d, indent=1))
     # two ranks: the contract's 6 steps and the 200-step loop beside them
     assert d["long_run"]["steps"] == 200 and d["long_run"]["value"] > 1e6
     assert len(d["long_run"]["per_rank_iterations_per_s"]) == 2

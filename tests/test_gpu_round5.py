@@ -1,0 +1,258 @@
+"""GPU suite, round 5: the pieces VERDICT r4 / ADVICE r4 asked for — the device-resident sharded
+round (pack / grouped all-gather / round winner / index-only lexicographic pick), the pick
+workspace whose size travels with it, the data-driven schedule of the chunked solve, and the
+layout recommendation measured at more than one shape."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import batch_rel_err, dev_batch, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test without a HIP device"
+    return torch
+
+
+def _solver(system="bicycle6", N=20, dtype="f64", dt=0.25, layout=0):
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config
+    cfg = default_config(system, N, dtype, dt=dt, layout=layout)
+    return BatchedILQR(cfg), cfg
+
+
+def test_pick_workspace_smaller_than_the_batch_needs_is_refused(torch_mod):
+    """the fused epilogue writes one (value, index) pair per workgroup; a workspace sized
+    for a smaller batch was an out-of-bounds device write.  The size now travels with the pointer
+    and both entry points refuse one that is too small (I2LQR_ERR_INVALID), before any launch."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    from ilqr_iterative_tasks_amd.solver import I2lqrError
+    solver, cfg = _solver()
+    B = 4096
+    buf = dev_batch(solver, workloads.make_batch(cfg, B), want_gains=False)
+    need = int(solver.lib.i2lqr_argmin_workspace_bytes(B))
+    assert need > int(solver.lib.i2lqr_argmin_workspace_bytes(64))  # grows with the batch
+    small = torch.empty(need - 16, dtype=torch.uint8, device=solver.device)
+    qfun = torch.zeros(B, dtype=torch.int32, device=solver.device)
+    cost_it = solver.empty(B)
+    idx, val = solver.empty(1, dtype=torch.int64), solver.empty(1)
+    with torch.cuda.device(solver.device):
+        rc = solver.lib.i2lqr_iterate_pick(
+            solver._handle, B, 2, *solver._iter_args(buf, B), C.c_void_p(qfun.data_ptr()), 0, 55,
+            C.c_void_p(cost_it.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()),
+            C.c_void_p(small.data_ptr()), C.c_int64(small.numel()), solver._stream())
+        assert rc != 0 and b"workspace" in solver.lib.i2lqr_last_error()
+        rc = solver.lib.i2lqr_argmin(
+            solver._handle, 1 << 20, C.c_void_p(cost_it.data_ptr()), C.c_void_p(idx.data_ptr()),
+            C.c_void_p(val.data_ptr()), C.c_void_p(small.data_ptr()), C.c_int64(1024),
+            solver._stream())
+        assert rc != 0 and b"workspace" in solver.lib.i2lqr_last_error()
+    # costs only (no pick): no workspace is read, none is needed
+    solver.iterate_pick(buf, 2, qfun, 0, pick=False)
+    torch.cuda.synchronize()
+    with pytest.raises(I2lqrError):
+        solver._argmin_ws = torch.empty(16, dtype=torch.uint8, device=solver.device)
+        solver.lib.i2lqr_argmin_workspace_bytes.restype = C.c_int64
+        orig = solver._argmin_workspace
+        solver._argmin_workspace = lambda B: (C.c_void_p(solver._argmin_ws.data_ptr()), C.c_int64(16))
+        try:
+            solver.argmin(solver.empty(100000))
+        finally:
+            solver._argmin_workspace = orig
+
+
+def test_two_picks_of_one_handle_overlapping_on_two_streams(torch_mod):
+    """the last-workgroup-done ticket was ONE word per handle.  Two fused picks of one
+    handle in flight at once (two streams, each with its own workspace) now draw from different
+    ticket words: both return the pick of their own batch, every time."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = _solver()
+    B = 1024
+    hosts = [workloads.make_batch(cfg, B, offset=o) for o in (0, B)]
+    qfun = torch.zeros(B, dtype=torch.int32, device=solver.device)
+    need = int(solver.lib.i2lqr_argmin_workspace_bytes(B))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ref = []
+    for h in hosts:
+        b = dev_batch(solver, h, want_gains=False)
+        c, (i, v) = solver.iterate_pick(b, 3, qfun, 0)
+        ref.append((int(i), float(v)))
+    for rep in range(20):
+        outs = []
+        bufs = [dev_batch(solver, h, want_gains=False) for h in hosts]
+        torch.cuda.synchronize()
+        for s, b in zip(streams, bufs):
+            ws = torch.empty(need, dtype=torch.uint8, device=solver.device)
+            idx, val = solver.empty(1, dtype=torch.int64), solver.empty(1)
+            cost_it = solver.empty(B)
+            with torch.cuda.stream(s), torch.cuda.device(solver.device):
+                solver._check(solver.lib.i2lqr_iterate_pick(
+                    solver._handle, B, 3, *solver._iter_args(b, B), C.c_void_p(qfun.data_ptr()), 0,
+                    55, C.c_void_p(cost_it.data_ptr()), C.c_void_p(idx.data_ptr()),
+                    C.c_void_p(val.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_int64(need),
+                    C.c_void_p(s.cuda_stream)))
+            outs.append((idx, val, ws, cost_it))
+        torch.cuda.synchronize()
+        assert [(int(i), float(v)) for i, v, _, _ in outs] == ref, rep
+
+
+@pytest.mark.parametrize("layout,B", [(0, 200), (1, 131), (2, 192)])
+def test_pack_problem_every_layout(torch_mod, layout, B):
+    """i2lqr_pack_problem: (U, X) of a problem named by a DEVICE index, reference orientation, from
+    any layout — and BatchedILQR.problem() (index_select: no host read-back) agrees."""
+    torch = torch_mod
+    solver, cfg = _solver(layout=layout)
+    rng = np.random.default_rng(layout)
+    Xh, Uh = rng.normal(size=(B, cfg.n, cfg.N + 1)), rng.normal(size=(B, cfg.m, cfg.N))
+    buf = dict(X=solver.to_native(torch.as_tensor(Xh).cuda()),
+               U=solver.to_native(torch.as_tensor(Uh).cuda()))
+    for i in (0, 1, 63, 64, B - 1):
+        idx = torch.tensor([i], dtype=torch.int64, device=solver.device)
+        U, X = solver.unpack(solver.pack_problem(buf, idx))
+        assert np.array_equal(U.cpu().numpy(), Uh[i]) and np.array_equal(X.cpu().numpy(), Xh[i])
+        win = solver.problem(buf, idx)
+        assert np.array_equal(win["U"].cpu().numpy(), Uh[i])
+        assert np.array_equal(win["X"].cpu().numpy(), Xh[i])
+    # out of range on either side is clamped (an empty pick is -1)
+    U, _ = solver.unpack(solver.pack_problem(buf, torch.tensor([-1], device=solver.device)))
+    assert np.array_equal(U.cpu().numpy(), Uh[0])
+
+
+def test_round_winner_translates_padded_picks(torch_mod):
+    """i2lqr_round_winner: owner's pack + index in the unpadded, contiguously sharded batch, for
+    even and ragged shards; -1 (nothing can win) stays -1."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import dist as idist
+    solver, cfg = _solver("bicycle4", 6, dt=1.0)
+    P = cfg.m * cfg.N + cfg.n * (cfg.N + 1)
+    for world, total in ((1, 9), (2, 13), (8, 8 * 1024), (8, 8 * 1024 - 3), (3, 4)):
+        width = idist.padded_width(total, world)
+        packs = torch.arange(world * P, dtype=torch.float64, device=solver.device).view(world, P)
+        for g in (0, total // 2, total - 1):
+            owner, loc = idist.owner_of(g, total, world)
+            padded = torch.tensor([owner * width + loc], dtype=torch.int64, device=solver.device)
+            win, best = solver.round_winner(world, width, total, padded, packs)
+            assert [int(v) for v in best.cpu()] == [g, owner]
+            assert torch.equal(win, packs[owner])
+        _, best = solver.round_winner(world, width, total,
+                                      torch.tensor([-1], device=solver.device), packs)
+        assert int(best[0]) == -1
+
+
+@pytest.mark.parametrize("B,native", [(2048, False), (2048, True), (16448, False)])
+def test_sharded_round_in_a_world_of_one_is_the_candidate_round(torch_mod, B, native):
+    """HipCandidateSolver.sharded_round — the function control.iLqr(sharded=...) calls and bench.py
+    --gpus N times — with a world of one: the flat form (packs riding in the all-gather) and the
+    two-collective form (index-only i2lqr_pick_best + broadcast) both return candidate_round's
+    winner; over the torch exchange and over the library's own RCCL communicator."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads, dist as idist
+    from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+    cfg = default_config("bicycle6", 20, "f64", dt=0.25)
+    hs = HipCandidateSolver()
+    host = workloads.make_batch(cfg, B)
+    x0 = torch.as_tensor(host["X"][0, :, 0]).cuda()
+    x_terms = torch.as_tensor(host["x_term"]).cuda()
+    qfun = torch.as_tensor(np.random.default_rng(B).integers(0, 100, B).astype(np.int32)).cuda()
+    obs = (31, -3, 8, 6, 0, 0)
+    ref = hs.candidate_round(cfg, x0, x_terms, qfun, 1.0, obs_rec=obs, n_iters=10)
+    want = (int(ref["best_idx"]), ref["U"].clone(), ref["X"].clone(), ref["cost_it"].clone())
+    xch = idist.CostExchange(BatchedILQR(default_config("bicycle4", 6), "cuda:0")) if native \
+        else idist.TorchExchange()
+    rounds = idist.ShardedRound(native=xch if native else None)
+    flat = hs.sharded_round(cfg, x0, x_terms, qfun, 1.0, rounds, B, obs_rec=obs, n_iters=10)
+    torch.cuda.synchronize()
+    assert [int(v) for v in flat["best_idx"].cpu()] == [want[0], 0]
+    assert torch.equal(flat["U"], want[1]) and torch.equal(flat["X"], want[2])
+    assert torch.equal(flat["cost_all"], want[3]) and rounds.collectives == 1
+    # list-of-lists form: L laps of k candidates; the pick is Python's on the same costs
+    L, k = 8, B // 8
+    lex = hs.sharded_round(cfg, x0, x_terms, qfun, 1.0, rounds, B, obs_rec=obs, n_iters=10,
+                           lexi=(L, k))
+    rows = [[float(v) for v in want[3][a * k:(a + 1) * k].cpu()] for a in range(L)]
+    a, c = idist.select_best_lexicographic(rows)
+    assert lex["best_idx"] == a * k + c and rounds.collectives == 3
+    s, buf = lex["solver"], lex["buf"]
+    assert torch.equal(lex["X"], s.to_problem_major(buf["X"])[a * k + c])
+    assert torch.equal(lex["U"], s.to_problem_major(buf["U"])[a * k + c])
+    if native:
+        xch.close()
+
+
+def test_schedule_options_of_the_chunked_solve_change_no_bit(torch_mod):
+    """The chunked solve's schedule is structural (8, 4, then doubling; which kernel of a round does
+    the work is decided on the device from the live count).  "first_chunk" / "chunk_step" pin other
+    schedules for measurements: without the tail kernel every one of them — and the automatic one —
+    equals the plain single launch bit for bit, on a distribution the schedule was not tuned on."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = _solver(layout=2)
+    B = 16384
+    host = workloads.make_batch(cfg, B, variant="far_targets")
+    solver.set_compaction(0)
+    plain = solver.solve(dev_batch(solver, host, want_gains=False))
+    assert int((plain["iters"] > 14).sum()) > 1000
+    solver.set_compaction(4096)
+    solver.set_option("wave_tail", 0)
+    for opts in ({}, {"first_chunk": 12}, {"first_chunk": 5, "chunk_step": 2}, {"chunk_step": 7}):
+        for key in ("first_chunk", "chunk_step"):
+            solver.set_option(key, opts.get(key, -1))
+        got = solver.solve(dev_batch(solver, host, want_gains=False))
+        for key in ("X", "U", "lamb", "cost", "iters", "status"):
+            assert torch.equal(got[key], plain[key]), (opts, key)
+
+
+@pytest.mark.parametrize("variant", ["all_obstacle", "far_targets"])
+def test_default_chunked_solve_on_other_distributions_matches_the_plain_solve(torch_mod, variant):
+    """The automatic schedule (extensions + speculative tail) on two distributions it was not
+    tuned on: iteration counts and statuses of the plain single launch, trajectories to 1e-8."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import workloads
+    solver, cfg = _solver(layout=2)
+    B = 32768
+    host = workloads.make_batch(cfg, B, variant=variant)
+    chunked = solver.solve(dev_batch(solver, host, want_gains=False))
+    solver.set_compaction(0)
+    plain = solver.solve(dev_batch(solver, host, want_gains=False))
+    assert torch.equal(chunked["iters"], plain["iters"])
+    assert torch.equal(chunked["status"], plain["status"])
+    assert batch_rel_err(to_host(solver, chunked["X"]), to_host(solver, plain["X"])) < 1e-8
+    assert batch_rel_err(to_host(solver, chunked["U"]), to_host(solver, plain["U"]), floor=1e-2) < 1e-8
+
+
+def test_recommended_layout_picks_the_faster_side_at_the_reference_shape(torch_mod):
+    """the crossover is a table measured at twelve shapes (tools/threshold_sweep.py).
+    At bicycle4 N = 6 (the reference's shape) the recommended layout must be the faster one on
+    both sides of its threshold, here and now (interleaved timing, 10 fused iterations)."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    base = default_config("bicycle4", 6, "f64", dt=1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for B in (4096, 16384):
+        rec = BatchedILQR.recommended_layout(base, B)
+        times = {}
+        for lay in (0, 2):
+            cfg = base.copy()
+            cfg.layout = lay
+            s = BatchedILQR(cfg)
+            host = workloads.make_batch(cfg, B)
+            ts = []
+            for r in range(6):
+                buf = dev_batch(s, host, want_gains=False)
+                torch.cuda.synchronize()
+                e0.record()
+                s.iterate(buf, 10)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            times[lay] = float(np.median(ts[1:]))
+            s.close()
+        assert times[rec] <= 1.15 * min(times.values()), (B, rec, times)
+    assert BatchedILQR.recommended_layout(base, 4096) == 0
+    assert BatchedILQR.recommended_layout(base, 16384) == 2

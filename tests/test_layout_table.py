@@ -1,0 +1,72 @@
+"""CPU suite: i2lqr_recommended_layout over the table measured in round 5
+(tools/threshold_sweep.py -> profiles/r05_threshold_sweep*.json).  For every measured
+shape and batch size at which one side won by more than 10 %, the recommendation must be that
+side — for the fixed-count entry point and for the solve to termination."""
+import json
+from pathlib import Path
+
+import pytest
+
+from ilqr_iterative_tasks_amd import _abi, default_config
+
+ROOT = Path(__file__).resolve().parent.parent
+FILES = sorted((ROOT / "profiles").glob("r05_threshold_sweep*.json"))
+
+
+def _shapes():
+    out = {}
+    for f in FILES:
+        out.update(json.loads(f.read_text())["shapes"])
+    return out
+
+
+def _cfg(name):
+    system, N, dtype = name.split("_")
+    dt = {"bicycle4_N6": 1.0, "bicycle4_N20": 0.5}.get(f"{system}_{N}", 0.25)
+    return default_config(system, int(N[1:]), dtype, dt=dt)
+
+
+@pytest.mark.skipif(not FILES, reason="no measured table in profiles/")
+def test_recommendation_follows_the_measured_table():
+    lib = _abi.load_library()
+    import ctypes as C
+    shapes = _shapes()
+    assert len(shapes) >= 12
+    checked = wrong = 0
+    worst = []
+    for name, rows in shapes.items():
+        cfg = _cfg(name)
+        for B, row in rows.items():
+            for solve, key in ((0, "iterate_ms"), (1, "solve_ms")):
+                pm = min(v[key] for k, v in row.items() if k != "tiled" and v[key])
+                if solve:
+                    pm = row["pm"][key]
+                lane = row["tiled"][key]
+                if max(pm, lane) / min(pm, lane) < 1.10:
+                    continue  # a tie: either side is fine
+                rec = lib.i2lqr_recommended_layout(C.byref(cfg), int(B), solve)
+                want_lane = lane < pm
+                checked += 1
+                if (rec != _abi.LAYOUT_PROBLEM_MAJOR) != want_lane:
+                    wrong += 1
+                    worst.append((name, B, key, pm, lane, rec))
+    assert checked > 200
+    # the table's entries sit on measured grid points: no decided case may be on the wrong side
+    assert wrong == 0, worst
+
+
+def test_horizon_buckets_and_precision_are_read():
+    import ctypes as C
+    lib = _abi.load_library()
+    rec = lambda cfg, B, s=0: lib.i2lqr_recommended_layout(C.byref(cfg), B, s)
+    # long horizons leave the problem-major kernels early (LDS: 1024 problems per round at N = 50)
+    assert rec(default_config("bicycle6", 50, "f64", dt=0.25), 8192) == _abi.LAYOUT_BATCH_TILED
+    assert rec(default_config("bicycle6", 20, "f64", dt=0.25), 8192) == _abi.LAYOUT_PROBLEM_MAJOR
+    # fp32 stays on the sixteen-lane kernel longer at N = 20
+    assert rec(default_config("bicycle6", 20, "f32", dt=0.25), 14336) == _abi.LAYOUT_PROBLEM_MAJOR
+    assert rec(default_config("bicycle6", 20, "f64", dt=0.25), 14336) == _abi.LAYOUT_BATCH_TILED
+    # the reference's shape
+    assert rec(default_config("bicycle4", 6, "f64"), 8192) == _abi.LAYOUT_PROBLEM_MAJOR
+    assert rec(default_config("bicycle4", 6, "f64"), 8256) == _abi.LAYOUT_BATCH_TILED
+    # a batch that is not a multiple of 64 gets the batch-minor form of the same kernels
+    assert rec(default_config("bicycle4", 6, "f64"), 9001) == _abi.LAYOUT_BATCH_MINOR

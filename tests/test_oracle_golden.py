@@ -118,6 +118,39 @@ def test_quu_inverse_matches_numpy_eig():
         assert rel_err(orc.quu_inverse_reg(M, lamb), want) < 1e-9
 
 
+def test_quu_inverse_4x4_matches_numpy_eigh():
+    """The m = 4 regularised inverse (cyclic Jacobi sweeps, oracle/ilqr_oracle.c quu_inverse_reg) is
+    what DEFINES quad12's gains — the plant has no reference counterpart — so it is pinned here
+    against the reference's construction (control/iterative_ilqr.py:118-123: eigen-decomposition,
+    negative eigenvalues clamped to zero, + lamb, V diag(1/w) V^T) with numpy's symmetric solver,
+    on well-conditioned, nearly singular, diagonal and indefinite inputs.  An eigenvalue is known to
+    eps ||M||, so 1 / (w + lamb) — and with it the inverse — to eps ||M|| / min(w + lamb) relative:
+    the bound is 50 x that (numpy's own answer carries the same uncertainty), 1e-12 where the
+    matrix is well conditioned."""
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for trial in range(300):
+        A = rng.normal(size=(4, 4))
+        M = A @ A.T + np.diag(rng.uniform(0, 2, 4))
+        if trial % 5 == 0:
+            M = np.diag(rng.uniform(0.1, 5, 4))
+        if trial % 7 == 0:
+            M = M - 3.0 * np.eye(4)          # some eigenvalues negative: clamped
+        if trial % 11 == 0:
+            v = rng.normal(size=(4, 1))
+            M = v @ v.T                       # rank one: three zero eigenvalues
+        M = 0.5 * (M + M.T)
+        lamb = 10.0 ** rng.integers(-6, 3)
+        w, V = np.linalg.eigh(M)
+        w = np.where(w < 0, 0.0, w) + lamb
+        want = V @ np.diag(1.0 / w) @ V.T
+        bound = 1e-12 + 50 * np.finfo(float).eps * np.abs(M).max() / w.min()
+        err = rel_err(orc.quu_inverse_reg(M, lamb), want)
+        assert err < bound, (trial, err, bound)
+        worst = max(worst, err / bound)
+    assert worst < 1.0
+
+
 @pytest.mark.parametrize("system,N,dt", [("bicycle6", 20, 0.25), ("quad12", 10, 0.02),
                                          ("bicycle4", 6, 1.0)])
 def test_build_defined_jacobians_by_finite_differences(system, N, dt):
