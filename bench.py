@@ -884,8 +884,9 @@ def run_rank(args) -> int:
                    "batch_per_gpu": B, "global_batch": B * world, "layout": res["layout"],
                    "iterations_per_step": args.iters,
                    "step": ("i2lqr_iterate_pick: ONE launch (iterations + relaxed cost + pick)"
-                            if res["launches_per_step"] == 1 and world == 1 else
-                            "i2lqr_iterate + i2lqr_relax_cost + i2lqr_argmin" if world == 1 else
+                            if res["launches_per_step"] == 1 and "exchange_ms" not in res else
+                            "i2lqr_iterate + i2lqr_relax_cost + i2lqr_argmin"
+                            if "exchange_ms" not in res else
                             "HipCandidateSolver.sharded_round (the product's sharded control round): "
                             "i2lqr_iterate_pick on the shard (iterations + relaxed cost + local "
                             "pick) + i2lqr_pack_problem + ONE grouped all-gather of costs and "

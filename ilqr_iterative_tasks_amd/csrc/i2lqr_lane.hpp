@@ -107,8 +107,8 @@ template <bool TILED> struct LaneView {
 #ifndef I2LQR_DEEP_PREFETCH
 #define I2LQR_DEEP_PREFETCH 1
 #endif
-#ifndef I2LQR_W_PAIRS
-#define I2LQR_W_PAIRS 1  // k_lane_iterate_rows: the value update takes two rows of Quu Kc per sweep
+#ifndef I2LQR_FWD_DEPTH
+#define I2LQR_FWD_DEPTH 2  // forward_rows: horizon steps between a step's loads and their use
 #endif
 #ifndef I2LQR_WARM_INPUTS
 #define I2LQR_WARM_INPUTS 1  // k_lane_iterate_rows: LDS-direct warm-up loads of the next step's inputs
@@ -1227,90 +1227,45 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         }
       });
       // [W | w] = [Vxx | Vx] - Kc^T (Quu [Kc | k]), the UNregularised Quu
-      // (control/iterative_ilqr.py:128-129 before the state Jacobian is applied), one row b of
-      // Y = Quu Kc at a time: [W | w][i][j] -= Y[b][i] [Kc | k][b][j].  The rows of Kc come back
-      // from LDS two at a time (24 words in flight, one wait per pair, fenced: with the loads left
-      // to the scheduler every pair of words was waited for on its own, ~100 cycles each — 60 % of
-      // the step's time in this phase).
+      // (control/iterative_ilqr.py:128-129 before the state Jacobian is applied):
+      // [W | w][i][j] -= sum_b Y[b][i] [Kc | k][b][j] with Y = Quu Kc.  ONE sweep, row by row
+      // (round 5): the four rows of [Kc | k] come back from LDS once and stay in registers (52
+      // doubles), the column Y[:, i] is formed when row i is updated (4 doubles live), every word
+      // of [W | w] is touched ONCE per step.  Rounds 3-4 swept twice (two rows of Y per sweep, Kc read
+      // from LDS twice): every word of the part of V that lives in accumulation registers — a lane
+      // has 128 doubles of vector registers, 90 of them are V — then travelled to the vector
+      // registers and back twice per step.  Same operations on every word in the same order (b = 0,
+      // 1, 2, 3; Y accumulated over a = 0 .. 3 from zero): bit-identical.  361 -> 268 accumulation-
+      // register moves and 127 -> 103 LDS operations per step, 72.7-73.4 -> 75.8-76.8 M it/s at 65536
+      // problems (tools/ab_bench.py, same process).  Keeping [Kc | k] in registers from its
+      // formation instead of reloading it (no LDS reads at all) spills: 62.5 M it/s.
       I2LQR_PHASE_FENCE();
-      if constexpr (I2LQR_W_PAIRS && m % 2 == 0) {
-        // two rows of Y per sweep over Kc: every word of [W | w] is updated twice per sweep —
-        // half the register <-> accumulation-register traffic for the part of V that does not fit
-        // the vector registers — and Kc is read m / 2 times instead of m.  Same operations on every
-        // word in the same order: bit-identical to one row per sweep.
-        static_for<0, m / 2>([&](auto p_) {
-          constexpr int b0 = 2 * decltype(p_)::value, b1 = b0 + 1;
-          T y0[n], y1[n], k0[n + 1], k1[n + 1];
-          asm volatile("" : "+v"(lrd));  // this sweep reads its words again (no reuse across sweeps)
+      {
+        T kr[m][n + 1];
+        asm volatile("" : "+v"(lrd));  // this step's words (no forwarding from the stores above)
 #pragma unroll
-          for (int i = 0; i < n; i++) y0[i] = y1[i] = T(0);
-          static_for<0, m / 2>([&](auto h_) {
-            constexpr int a0 = 2 * decltype(h_)::value;
-            T r0[n], r1[n];
+        for (int a = 0; a < m; a++)
 #pragma unroll
-            for (int i = 0; i < n; i++) {
-              r0[i] = kcs[(a0 * (n + 1) + i) * 64 + lrd];
-              r1[i] = kcs[((a0 + 1) * (n + 1) + i) * 64 + lrd];
-            }
-            I2LQR_PHASE_FENCE();
+          for (int j = 0; j <= n; j++) kr[a][j] = kcs[(a * (n + 1) + j) * 64 + lrd];
+        I2LQR_PHASE_FENCE();
+        static_for<0, n>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          T y[m];
 #pragma unroll
-            for (int i = 0; i < n; i++) {
-              y0[i] = t_fma(Quu[b0 * m + a0], r0[i], y0[i]);
-              y0[i] = t_fma(Quu[b0 * m + a0 + 1], r1[i], y0[i]);
-              y1[i] = t_fma(Quu[b1 * m + a0], r0[i], y1[i]);
-              y1[i] = t_fma(Quu[b1 * m + a0 + 1], r1[i], y1[i]);
-              if constexpr (a0 == b0) {
-                k0[i] = r0[i];
-                k1[i] = r1[i];
-              }
-            }
-            I2LQR_PHASE_FENCE();
-          });
-          k0[n] = kcs[(b0 * (n + 1) + n) * 64 + lrd];
-          k1[n] = kcs[(b1 * (n + 1) + n) * 64 + lrd];
+          for (int bb = 0; bb < m; bb++) {
+            T acc = T(0);
 #pragma unroll
-          for (int i = 0; i < n; i++) {
-#pragma unroll
-            for (int j = i; j < n; j++) {
-              V[i][j] = t_fma(-y0[i], k0[j], V[i][j]);
-              V[i][j] = t_fma(-y1[i], k1[j], V[i][j]);
-            }
-            vx[i] = t_fma(-y0[i], k0[n], vx[i]);
-            vx[i] = t_fma(-y1[i], k1[n], vx[i]);
+            for (int a = 0; a < m; a++) acc = t_fma(Quu[bb * m + a], kr[a][i], acc);
+            y[bb] = acc;
           }
+#pragma unroll
+          for (int j = i; j < n; j++) {
+#pragma unroll
+            for (int bb = 0; bb < m; bb++) V[i][j] = t_fma(-y[bb], kr[bb][j], V[i][j]);
+          }
+#pragma unroll
+          for (int bb = 0; bb < m; bb++) vx[i] = t_fma(-y[bb], kr[bb][n], vx[i]);
         });
-      } else {
-      static_for<0, m>([&](auto b_) {
-        constexpr int bb = decltype(b_)::value;
-        T y[n], kb[n + 1];
-        asm volatile("" : "+v"(lrd));  // this pass reads its words again (no reuse across passes)
-#pragma unroll
-        for (int i = 0; i < n; i++) y[i] = T(0);
-        static_for<0, m / 2>([&](auto h_) {
-          constexpr int a0 = 2 * decltype(h_)::value;
-          T r0[n], r1[n];
-#pragma unroll
-          for (int i = 0; i < n; i++) {
-            r0[i] = kcs[(a0 * (n + 1) + i) * 64 + lrd];
-            r1[i] = kcs[((a0 + 1) * (n + 1) + i) * 64 + lrd];
-          }
-          I2LQR_PHASE_FENCE();
-#pragma unroll
-          for (int i = 0; i < n; i++) {
-            y[i] = t_fma(Quu[bb * m + a0], r0[i], y[i]);
-            y[i] = t_fma(Quu[bb * m + a0 + 1], r1[i], y[i]);
-            if constexpr (a0 == (bb & ~1)) kb[i] = (bb & 1) ? r1[i] : r0[i];
-          }
-          I2LQR_PHASE_FENCE();
-        });
-        kb[n] = kcs[(bb * (n + 1) + n) * 64 + lrd];
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-#pragma unroll
-          for (int j = i; j < n; j++) V[i][j] = t_fma(-y[i], kb[j], V[i][j]);
-          vx[i] = t_fma(-y[i], kb[n], vx[i]);
-        }
-      });
       }
       // K = Kc A row by row, then straight to HBM
       I2LQR_PHASE_FENCE();
@@ -1515,38 +1470,42 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     // an HBM round trip under load (~3 us with every wavefront streaming): with a one-step
     // distance every step waited ~8000 cycles for its 56 words.
     struct Buf { T ul[m], kl[m][n + 1]; };
-    Buf A, B;
+    constexpr int D = I2LQR_FWD_DEPTH;  // register sets = prefetch distance in horizon steps
+    Buf q[D];
     for_rows<n>(X, rx(0, 0), [&](auto i_, const T& w) { x[decltype(i_)::value] = w; });
 #pragma unroll
     for (int i = 0; i < n; i++) xo[i] = x[i];
-    auto load_step = [&](const int t, Buf& q) __attribute__((always_inline)) {
-      for_rows<m>(U, ru(0, t), [&](auto a_, const T& w) { q.ul[decltype(a_)::value] = w; });
+    auto load_step = [&](const int t, Buf& b) __attribute__((always_inline)) {
+      for_rows<m>(U, ru(0, t), [&](auto a_, const T& w) { b.ul[decltype(a_)::value] = w; });
       for_rows<m * n>(gK, rK(0, 0, t), [&](auto e_, const T& w) {
         constexpr int e = decltype(e_)::value;
-        q.kl[e / n][e % n] = w;
+        b.kl[e / n][e % n] = w;
       });
-      for_rows<m>(gk, ru(0, t), [&](auto a_, const T& w) { q.kl[decltype(a_)::value][n] = w; });
+      for_rows<m>(gk, ru(0, t), [&](auto a_, const T& w) { b.kl[decltype(a_)::value][n] = w; });
     };
     // step 0: x_0 is common to the nominal and the candidate, K_0 multiplies zeros and is not read
-    for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { A.ul[decltype(a_)::value] = w; });
-    for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { A.kl[decltype(a_)::value][n] = w; });
+    for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { q[0].ul[decltype(a_)::value] = w; });
+    for_rows<m>(gk, ru(0, 0), [&](auto a_, const T& w) { q[0].kl[decltype(a_)::value][n] = w; });
 #pragma unroll
     for (int a = 0; a < m; a++)
 #pragma unroll
-      for (int j = 0; j < n; j++) A.kl[a][j] = T(0);
-    load_step(N >= 2 ? 1 : 0, B);
+      for (int j = 0; j < n; j++) q[0].kl[a][j] = T(0);
+    static_for<1, D>([&](auto d_) {
+      constexpr int d = decltype(d_)::value;
+      load_step(d < N ? d : N - 1, q[d]);
+    });
     T cost = T(0);
-    auto body = [&](const int t, Buf& q) __attribute__((always_inline)) {
+    auto body = [&](const int t, Buf& b) __attribute__((always_inline)) {
       T uo[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < n; j++) acc = t_fma(q.kl[a][j], x[j] - xo[j], acc);
-        u[a] = clip(q.ul[a] + q.kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
-        uo[a] = q.ul[a];
+        for (int j = 0; j < n; j++) acc = t_fma(b.kl[a][j], x[j] - xo[j], acc);
+        u[a] = clip(b.ul[a] + b.kl[a][n] + acc, -c.u_max[a], c.u_max[a]);
+        uo[a] = b.ul[a];
       }
-      load_step(t + 2 < N ? t + 2 : N - 1, q);  // (the last steps load a row again: no branch)
+      load_step(t + D < N ? t + D : N - 1, b);  // (the last steps load a row again: no branch)
       for_rows<m>(Un, ru(0, t), [&](auto a_, T& w) { w = u[decltype(a_)::value]; });
       // nominal state of step t + 1, re-rolled from the nominal inputs (the pass streams the gains
       // at the HBM rate and has issue slots to spare: n fewer rows to read per step)
@@ -1563,11 +1522,12 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       for (int i = 0; i < n; i++) x[i] = xn[i];
     };
     int t = 0;
-    for (; t + 1 < N; t += 2) {
-      body(t, A);
-      body(t + 1, B);
-    }
-    if (t < N) body(t, A);
+    for (; t + D <= N; t += D)
+      static_for<0, D>([&](auto d_) { body(t + decltype(d_)::value, q[decltype(d_)::value]); });
+    static_for<0, D - 1>([&](auto d_) {
+      constexpr int d = decltype(d_)::value;
+      if (t + d < N) body(t + d, q[d]);
+    });
     cost = cost + terminal_cost(x, xT);
     return cost;
   }

@@ -1256,16 +1256,23 @@ def test_eight_lane_workspace_form_is_bit_identical(torch_mod):
         for a, b in zip(res[0], res[1]):
             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
                 assert torch.equal(a[key], b[key]), (system, B, key)
-    # automatic: the sixteen-lane kernel (rounds of 4096 problems) except between 4097 and 7168
-    # problems with the workspace registered, where the eight-lane workspace form is ahead
+    # automatic: the sixteen-lane kernel (rounds of 4096 problems) except between 4097 and 8192
+    # problems (fp64; fp32: 7168) with the workspace registered, where the eight-lane workspace
+    # form is ahead (round 5: measured at three shapes, tools/threshold_sweep.py)
     auto = BatchedILQR(default_config("bicycle6", 20, "f64", dt=0.25))
     assert auto.iterate_kernel(6144) == "k_group_iterate (sixteen lanes)"  # no workspace registered yet
     auto.ensure_workspace(6144)
     assert auto.iterate_kernel(6144) == "k_group_iterate (workspace form)"
     assert auto.iterate_kernel(4096) == "k_group_iterate (sixteen lanes)"
     assert auto.iterate_kernel(4097) == "k_group_iterate (workspace form)"
-    assert auto.iterate_kernel(8192) == "k_group_iterate (sixteen lanes)"
-    assert int(auto.lib.i2lqr_workspace_bytes(auto._handle, 8192)) == 0  # nothing to allocate there
+    auto.ensure_workspace(8192)
+    assert auto.iterate_kernel(8192) == "k_group_iterate (workspace form)"
+    assert auto.iterate_kernel(8193) == "k_group_iterate (sixteen lanes)"
+    assert int(auto.lib.i2lqr_workspace_bytes(auto._handle, 8193)) == 0  # nothing to allocate there
+    f32 = BatchedILQR(default_config("bicycle6", 20, "f32", dt=0.25))
+    f32.ensure_workspace(7168)
+    assert f32.iterate_kernel(7168) == "k_group_iterate (workspace form)"
+    assert f32.iterate_kernel(8192) == "k_group_iterate (sixteen lanes)"
 
 
 def test_inputs_outside_the_benchmark_distribution_vs_oracle(torch_mod, layout):
