@@ -468,8 +468,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     h->lds_bytes = 0;
     return I2LQR_OK;
   }
-  // stage weights Q, R != 0: built for the plants without the row-block form (the bicycles)
-  static constexpr bool kStageWeights = Sys::NBLK == 0;
+  // stage weights Q, R != 0: the bicycles in both precisions; the row-block plant (quad12) in fp64
+  // (round 5: instantiations of their own, i2lqr_lane12qr.hip)
+  static constexpr bool kStageWeights = Sys::NBLK == 0 || sizeof(T) == 8;
   static int need_ws(i2lqr_handle* h, int64_t B) {
     if constexpr (!kStageWeights) {
       bool hasqr = false;
@@ -593,7 +594,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
                        (a.ckpt ? kSegBytes : 0);
     if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
-      hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      if (c.flags)
+        hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, true, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+      else
+        hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, false, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
     } else {
       if (c.flags)
         hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c,
@@ -1293,7 +1297,7 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
                 sizeof(i2lqr_config));
   if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
   // what the lane layouts cannot run stays problem-major: non-symmetric weights (the kernels keep
-  // the upper triangles), and for quad12 (row-block kernel) stage weights and fp32
+  // the upper triangles), and for quad12 (row-block kernel) fp32
   bool lane_ok = true, weights = false;
   for (int i = 0; i < cfg->n; i++)
     for (int j = 0; j < cfg->n; j++) {
@@ -1315,8 +1319,8 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
       from = weights ? 2048 : (early_exit ? lane_from(*cfg).solve : lane_from(*cfg).iterate);
       break;
     case I2LQR_SYS_QUAD12:
-      from = kLaneBatchQuad;
-      if (cfg->dtype != I2LQR_F64 || weights) lane_ok = false;
+      from = kLaneBatchQuad;  // (with stage weights too: round 5)
+      if (cfg->dtype != I2LQR_F64) lane_ok = false;
       break;
     default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
   }

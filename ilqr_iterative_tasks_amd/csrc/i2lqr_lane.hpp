@@ -1749,8 +1749,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 // forward pass stores no states, accepted candidates are merged into the one input buffer while
 // the states are re-rolled — with every access through row groups and no LDS (see LaneWorker::
 // for_rows, backward_blocked).  Same arguments and results as k_lane_iterate (chunked solves
-// included); the defer / reroll / merge / lds / ckpt options do not apply.  Q = R = 0.
-template <class T, class Sys, bool TILED>
+// included); the defer / reroll / merge / lds / ckpt options do not apply.  HASQR: stage weights
+// Q, R != 0 (round 5; an instantiation of its own: the plant's default is Q = R = 0 and the 12 words
+// of l_x = 2 Q (x_t - xtarget) that live through the step cost the hot kernel registers it does not have).
+template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys::n, Sys::m> c,
                                                              const LaneArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
@@ -1761,7 +1763,7 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   if (a.resume && a.status[b] != 0) return;
   const int N = c.N;
   const LaneView<TILED> v(a.B);
-  LaneWorker<T, Sys, false, TILED> w(c, v.Bs, v.bl);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   const T* gxt = v.rebase(a.x_term, n);
   const T* gob = v.rebase(a.obs, 6);
   T xT[n], ob[6];
@@ -1775,7 +1777,7 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   T* const X = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
-  __shared__ T lds_gains[LaneWorker<T, Sys, false, TILED>::kGainWords];
+  __shared__ T lds_gains[LaneWorker<T, Sys, HASQR, TILED>::kGainWords];
   __shared__ unsigned lds_sink[64];  // LaneWorker::warm_rows
   w.sink = lds_sink;
   // Stagger: every wavefront of a full-chip launch does the same work in the same order, so all of
@@ -1824,7 +1826,8 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
       lamb /= c.lamb_factor;
       const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
       cost_ret = cost_new;
-      cost = cost_new;
+      // next iteration's nominal cost: stage terms are measured to xtarget, not x_terminal
+      cost = HASQR ? w.nominal_cost(X, Uc, xT) : cost_new;
       if (conv) {
         if (a.early_exit) { status = 1; break; }
         if (status == 0) status = 1;

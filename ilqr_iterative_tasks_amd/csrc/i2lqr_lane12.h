@@ -6,30 +6,36 @@
 
 namespace i2lqr {
 
-#define I2LQR_LANE12_KERNELS(DECL)                                                               \
-  DECL void k_lane_iterate_rows<double, Quad12<double>, false>(const DevCfg<double, 12, 4>,       \
-                                                               const LaneArgs<double>);           \
-  DECL void k_lane_iterate_rows<double, Quad12<double>, true>(const DevCfg<double, 12, 4>,        \
-                                                              const LaneArgs<double>);            \
-  DECL void k_lane_rollout<double, Quad12<double>, false, false>(                                 \
+// (QR: the stage-weight instantiations, compiled in i2lqr_lane12qr.hip)
+#define I2LQR_LANE12_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, false)
+#define I2LQR_LANE12QR_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, true)
+#define I2LQR_LANE12_KERNELS_(DECL, QR)                                                          \
+  DECL void k_lane_iterate_rows<double, Quad12<double>, QR, false>(const DevCfg<double, 12, 4>,   \
+                                                                   const LaneArgs<double>);       \
+  DECL void k_lane_iterate_rows<double, Quad12<double>, QR, true>(const DevCfg<double, 12, 4>,    \
+                                                                  const LaneArgs<double>);        \
+  DECL void k_lane_rollout<double, Quad12<double>, QR, false>(                                 \
       const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
-  DECL void k_lane_rollout<double, Quad12<double>, false, true>(                                  \
+  DECL void k_lane_rollout<double, Quad12<double>, QR, true>(                                  \
       const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
-  DECL void k_lane_backward<double, Quad12<double>, false, false>(                                \
+  DECL void k_lane_backward<double, Quad12<double>, QR, false>(                                \
       const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
       const double*, const double*, double*, double*);                                            \
-  DECL void k_lane_backward<double, Quad12<double>, false, true>(                                 \
+  DECL void k_lane_backward<double, Quad12<double>, QR, true>(                                 \
       const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
       const double*, const double*, double*, double*);                                            \
-  DECL void k_lane_forward<double, Quad12<double>, false, false>(                                 \
+  DECL void k_lane_forward<double, Quad12<double>, QR, false>(                                 \
       const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
       const double*, const double*, double*, double*, double*);                                   \
-  DECL void k_lane_forward<double, Quad12<double>, false, true>(                                  \
+  DECL void k_lane_forward<double, Quad12<double>, QR, true>(                                  \
       const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
       const double*, const double*, double*, double*, double*);
 
 #ifndef I2LQR_LANE12_DEFINE
 I2LQR_LANE12_KERNELS(extern template __global__)
+#endif
+#ifndef I2LQR_LANE12QR_DEFINE
+I2LQR_LANE12QR_KERNELS(extern template __global__)
 #endif
 
 }  // namespace i2lqr

@@ -85,7 +85,7 @@ def test_no_flat_memory_operations(isa):
 
 
 def test_hot_loops_of_the_quad12_lane_kernel_do_not_spill_to_scratch(isa):
-    loops = _loops(isa["lane12"], "_ZN5i2lqr19k_lane_iterate_rowsIdNS_6Quad12IdEELb1EEE")
+    loops = _loops(isa["lane12"], "_ZN5i2lqr19k_lane_iterate_rowsIdNS_6Quad12IdEELb0ELb1EEE")
     # the Riccati step of the hot (branch-free) backward pass: the loop with the LDS-resident gains
     # and ~2000 fp64 operations; the forward / re-roll loops stream global memory without LDS
     hot = [ins for ins in loops.values()

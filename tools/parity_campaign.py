@@ -56,23 +56,53 @@ PLANTS = {
     "bicycle4": dict(N=[1, 2, 5, 6, 13, 20], dt=[0.25, 1.0], fam=["wave", "group", "row16", "group-ws", "spec", "lane", "tiled"]),
     "bicycle6": dict(N=[2, 7, 20, 31], dt=[0.1, 0.25], fam=["wave", "group", "row16", "group-ws", "spec", "lane", "tiled"]),
     "quad12": dict(N=[3, 10, 50], dt=[0.02], fam=["wave", "quad16", "lane", "tiled"]),
+    # stage weights Q, R != 0 and a non-zero xtarget (utils/base.py:243-246): the column kernels are
+    # built for Q = R = 0; round 5: quad12's one-problem-per-lane kernels take them
+    "bicycle6+QR": dict(system="bicycle6", weights=True, N=[2, 7, 20], dt=[0.1, 0.25],
+                        fam=["wave", "lane", "tiled"]),
+    "quad12+QR": dict(system="quad12", weights=True, N=[3, 10, 50], dt=[0.02],
+                      fam=["wave", "lane", "tiled"]),
 }
+
+
+def with_weights(cfg, wrng):
+    """Random symmetric positive semi-definite Q, positive definite R, a target off the origin."""
+    n, m = cfg.n, cfg.m
+    A = wrng.normal(0, 0.1, (n, n))
+    cfg.set_matrix("Q", A @ A.T + np.diag(wrng.uniform(0.0, 0.1, n)))
+    Bm = wrng.normal(0, 0.05, (m, m))
+    cfg.set_matrix("R", Bm @ Bm.T + np.diag(wrng.uniform(0.02, 0.1, m)))
+    cfg.xtarget[:n] = wrng.normal(0, 0.2, n)
+    # With Q != 0 the reference compares a forward cost measured to x_terminal with a nominal cost
+    # measured to xtarget (control/iterative_ilqr.py:43 vs :151): on these problems every step is
+    # "accepted", no solve converges, and after 150 iterations lamb has decayed to 1e-150 — an
+    # unregularised, chaotic recursion in which three implementations give three answers (oracle
+    # 722, one-problem-per-wavefront kernel 85.2, lane kernel 84.6 on one bicycle6 problem, with
+    # identical accept histories).  Solves are compared over the first 12 iterations.
+    cfg.max_iter = 12
+    return cfg
+
+
 rng = np.random.default_rng(20261003)
 worst = {}
 bad = 0
 t0 = time.time()
 for plant, spec in PLANTS.items():
+    system = spec.get("system", plant)
     for trial in range(TRIALS):
         N = int(rng.choice(spec["N"]))
         dt = float(rng.choice(spec["dt"]))
-        B = int(rng.choice([64, 128, 192])) if plant == "quad12" else int(rng.choice([64, 192, 448, 1024]))
-        cfg0 = default_config(plant, N, "f64", dt=dt)
+        B = int(rng.choice([64, 128, 192])) if system == "quad12" else int(rng.choice([64, 192, 448, 1024]))
+        wseed = int(rng.integers(1 << 30))
+        cfg0 = default_config(system, N, "f64", dt=dt)
+        if spec.get("weights"):
+            with_weights(cfg0, np.random.default_rng(wseed))
         host = workloads.make_batch(cfg0, B, seed=1000 + trial)
         host["lamb"] = 10.0 ** rng.integers(-6, 3, B).astype(float)
         u_max = np.array(cfg0.u_max[:cfg0.m])[None, :, None]
-        scale = 0.05 if plant == "quad12" else 1.5  # beyond the box for the bicycles
+        scale = 0.05 if system == "quad12" else 1.5  # beyond the box for the bicycles
         host["U"] = rng.uniform(-1, 1, host["U"].shape) * scale * u_max
-        if plant != "quad12":
+        if system != "quad12":
             ob = host["obs"]
             ob[:, 0] = host["X"][:, 0, 0] + rng.uniform(5, 40, B)
             ob[:, 1] = rng.uniform(-6, 6, B)
@@ -96,7 +126,9 @@ for plant, spec in PLANTS.items():
             lid, opts = FAMILIES[fam]
             if fam == "tiled" and B % 64:
                 continue
-            cfg = default_config(plant, N, "f64", dt=dt, layout=lid)
+            cfg = default_config(system, N, "f64", dt=dt, layout=lid)
+            if spec.get("weights"):
+                with_weights(cfg, np.random.default_rng(wseed))
             s = BatchedILQR(cfg)
             try:
                 for k, v in opts.items():
@@ -134,10 +166,10 @@ for plant, spec in PLANTS.items():
             s.close()
 print("deviations: worst over the problems whose oracle sensitivity (one ulp on U0) is < 1e-12; ratio: worst "
       "deviation / sensitivity over the others ('sensitive')")
-print(f"{'plant':9s} {'family':9s} configs problems sensitive flipped(iterate) flipped(solve)   X(iterate)  K(iterate)  cost(iterate)  X(solve)   ratio")
+print(f"{'plant':11s} {'family':9s} configs problems sensitive flipped(iterate) flipped(solve)   X(iterate)  K(iterate)  cost(iterate)  X(solve)   ratio")
 for (plant, fam), w in worst.items():
     fi, fs = w["flips_it"] / w["probs"], w["flips_so"] / w["probs"]
-    print(f"{plant:9s} {fam:9s} {w['n']:7d} {w['probs']:8d} {w['ill']:9d} {fi:16.4f} {fs:14.4f}   {w['X']:.2e}   {w['K']:.2e}   {w['cost']:.2e}   {w['Xs']:.2e}   {w['ratio']:.1f}")
+    print(f"{plant:11s} {fam:9s} {w['n']:7d} {w['probs']:8d} {w['ill']:9d} {fi:16.4f} {fs:14.4f}   {w['X']:.2e}   {w['K']:.2e}   {w['cost']:.2e}   {w['Xs']:.2e}   {w['ratio']:.1f}")
     if (w["X"] > 1e-8 or w["Xs"] > 1e-8 or w["cost"] > 1e-7 or w["K"] > 1e-6 or fi > 0.03 or fs > 0.03
             or w["ratio"] > 100):
         bad += 1
