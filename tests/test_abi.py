@@ -119,7 +119,9 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     assert ask(q32, 65536) == 0                                             # fp32: problem-major kernels
     qr = _abi.default_config("quad12", 50)
     qr.set_matrix("R", np.diag([0.1] * 4))
-    assert ask(qr, 65536) == 0                                              # row-block kernel: Q = R = 0
+    assert ask(qr, 65536) == 2 and ask(qr, 4096) == 0                       # stage weights: lane kernels too (round 5)
+    b4 = _abi.default_config("bicycle4", 6)                                 # the reference's shape: its own
+    assert ask(b4, 8192) == 0 and ask(b4, 8256) == 2                        # crossover (measured table)
     br = _abi.default_config("bicycle6", 20)
     br.set_matrix("R", np.diag([0.1, 0.1]))
     assert [ask(br, B) for B in (64, 2047, 2048, 65536)] == [0, 0, 2, 2]   # the bicycles' lane kernels take stage weights
@@ -135,3 +137,37 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
         text = path.read_text()
         assert "i2lqr_recommended_layout" in text or "recommended_layout" in text, path
         assert not re.search(r"THRESHOLD\s*=\s*\d", text), path
+
+
+def test_every_export_refuses_a_null_handle_or_null_buffers_on_the_host():
+    """Host-only walk over the whole C-ABI (no GPU needed; also what tools/run_host_sanitizers.sh
+    drives under AddressSanitizer / UBSan): every entry point that takes a handle or buffers is
+    called with NULL / zero arguments and must come back with an error code and a message — never
+    dereference, never launch."""
+    lib = _abi.load_library()
+    skip = {"i2lqr_version", "i2lqr_last_error", "i2lqr_argmin_workspace_bytes", "i2lqr_destroy",
+            "i2lqr_comm_available", "i2lqr_comm_destroy", "i2lqr_comm_abort", "i2lqr_workspace_bytes",
+            "i2lqr_iterate_kernel", "i2lqr_solve_kernel"}
+    called = 0
+    for name, (restype, argtypes) in _abi.EXPORTS.items():
+        if name in skip:
+            continue
+        args = []
+        for t in argtypes:
+            if t is C.c_double:
+                args.append(0.0)
+            elif t in (C.c_int, C.c_int32, C.c_int64):
+                args.append(0)
+            elif t is C.c_char_p:
+                args.append(None)
+            else:
+                args.append(None)  # pointers (void*, typed pointers): NULL
+        rc = getattr(lib, name)(*args)
+        assert rc < 0, (name, rc)
+        assert lib.i2lqr_last_error(), name
+        called += 1
+    assert called >= 20
+    assert lib.i2lqr_workspace_bytes(None, 1024) == 0
+    assert lib.i2lqr_argmin_workspace_bytes(0) > 0
+    assert lib.i2lqr_argmin_workspace_bytes(1 << 20) == (1 << 18) * 16
+    assert lib.i2lqr_destroy(None) == 0 and lib.i2lqr_comm_destroy(None) in (0, -1, -2, -3, -4, -5)

@@ -115,41 +115,41 @@ def test_headline_kernel_loops_are_clean(isa):
     assert checked >= 2  # the backward and the forward horizon loops at least
 
 
-def _vregs(tok):
-    """VGPR numbers an operand token names: v12 -> {12}, v[4:7] -> {4..7}; anything else -> {}."""
-    tok = tok.strip().rstrip(",").lstrip("-|").rstrip("|")
-    m = re.fullmatch(r"v(\d+)", tok)
-    if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+def _lint():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "check_dpp_hazard", Path(__file__).resolve().parent.parent / "tools" / "check_dpp_hazard.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def test_no_dpp_read_of_a_register_written_by_the_two_instructions_in_front(isa):
     """The DPP row broadcasts of the sixteen-lane form are inline asm (the fp64 ALU's only DPP mode,
     folded into the multiply-add, is not something the compiler emits), so its hazard recogniser
     does not see them: the hardware needs two wait states between a VALU write of a VGPR and a DPP
-    read of it.  Checked here on the compiled code: for every *_dpp instruction, neither of the two
-    issue slots in front of it (an s_nop N fills N + 1) is a VALU instruction whose destination
-    overlaps the DPP source operand."""
-    lines = [l for l in isa["group"].split("\n")
-             if l.startswith("\t") and not l.startswith(("\t;", "\t.")) and l.strip()]
-    found = 0
-    for i, l in enumerate(lines):
-        parts = l.split()
-        if "_dpp" not in parts[0]:
-            continue
-        found += 1
-        src = _vregs(parts[2])  # v_fmac_*_dpp dst, SRC0 (the DPP operand), src1
-        assert src, l
-        slots, j = 0, i - 1
-        while slots < 2 and j >= 0:
-            p = lines[j].split()
-            if p[0] == "s_nop":
-                slots += int(p[1]) + 1
-            else:
-                slots += 1
-                if p[0].startswith("v_") and len(p) > 1:
-                    assert not (_vregs(p[1]) & src), f"DPP hazard: {lines[j].strip()!r} -> {l.strip()!r}"
-            j -= 1
+    read of it.  Checked on the compiled code by tools/check_dpp_hazard.py — the same check `make`
+    runs before it links the library — along every control-flow predecessor of a DPP instruction."""
+    found, bad = _lint().check(isa["group"])
+    assert not bad, bad[:5]
     assert found > 100  # the sixteen-lane kernels are in this translation unit
+
+
+def test_the_dpp_lint_sees_hazards_across_block_boundaries():
+    """a linear scan misses a VALU write at the end of a loop body in front of a DPP read
+    at the loop head.  Synthetic listings: a hazard over a back-edge, over a branch into a block,
+    the same with a wait state inside the block (clean), and a straight-line one."""
+    chk = _lint().check
+    dpp = "\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+    back_edge = ("_Z1kv:\n\tv_mov_b32_e32 v9, 0\n.LBB0_1:\n" + dpp +
+                 "\tv_add_f64 v[6:7], v[6:7], v[6:7]\n\tv_mul_f64 v[2:3], v[6:7], v[6:7]\n"
+                 "\ts_cbranch_vccnz .LBB0_1\n\ts_endpgm\n")
+    assert chk(back_edge)[1], "write of v[2:3] one slot (the branch) in front of the loop-head DPP read"
+    clean = back_edge.replace(".LBB0_1:\n" + dpp, ".LBB0_1:\n\ts_nop 1\n" + dpp)
+    assert chk(clean) == (1, [])
+    branch_in = ("_Z1kv:\n\tv_mul_f64 v[2:3], v[6:7], v[6:7]\n\ts_cbranch_vccz .LBB0_2\n"
+                 "\tv_mov_b32_e32 v9, 0\n\tv_mov_b32_e32 v9, 0\n.LBB0_2:\n" + dpp + "\ts_endpgm\n")
+    assert len(chk(branch_in)[1]) == 1  # over the taken branch only; the fall-through has two slots
+    straight = "_Z1kv:\n\tv_mul_f64 v[2:3], v[6:7], v[6:7]\n\tv_mov_b32_e32 v9, 0\n" + dpp
+    assert chk(straight)[1]
+    assert chk(straight.replace("\tv_mov_b32_e32 v9, 0\n", "\ts_nop 1\n")) == (1, [])
