@@ -382,7 +382,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 res = rounds.sharded_round(
                     cfg, None, None, None, None, xch, world * B, n_iters=args.iters,
                     prepared=(solver, buf, qfun, cost_it),
-                    lexi=lambda cost_all: int(solver.argmin(cost_all)[0]), on_phase=mark)
+                    lexi=lambda cost_all: int(solver.argmin(cost_all, side=True)[0]), on_phase=mark)
             picks.append(res["best_idx"])
             winners.append(res["pack"])
             return

@@ -163,7 +163,8 @@ class HipCandidateSolver:
             pack_local = solver.pack_problem(buf, lidx, bufs["pack_local"] if bufs else None)
             with side():
                 res = idist.flat_round(
-                    exchange, cost_it, pack_local, total, solver.argmin,
+                    exchange, cost_it, pack_local, total,
+                    lambda cost_all: solver.argmin(cost_all, side=True),  # (its own workspace)
                     lambda width, tot, best, pack_all: solver.round_winner(
                         exchange.world, width, tot, best, pack_all,
                         bufs["winner"] if bufs else None, bufs["best_global"] if bufs else None),

@@ -406,13 +406,19 @@ class BatchedILQR:
                 self._ptr(best_global, (2,), torch.int64, name="best_global"), self._stream()))
         return winner, best_global
 
-    def _argmin_workspace(self, B: int) -> tuple:
+    def _argmin_workspace(self, B: int, side: bool = False) -> tuple:
         """(pointer, bytes) of the pick's device scratch, grown to i2lqr_argmin_workspace_bytes(B);
-        the size travels with the pointer and the library refuses a workspace that is too small."""
+        the size travels with the pointer and the library refuses a workspace that is too small.
+        side: a SECOND workspace, for picks enqueued on another stream than the solves' (the pick
+        on the gathered costs of a sharded round runs beside the next round's local pick: two
+        picks in flight must not share their partial minima)."""
         need = int(self.lib.i2lqr_argmin_workspace_bytes(B))
-        if self._argmin_ws is None or self._argmin_ws.numel() < need:
-            self._argmin_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return C.c_void_p(self._argmin_ws.data_ptr()), C.c_int64(self._argmin_ws.numel())
+        name = "_argmin_ws_side" if side else "_argmin_ws"
+        ws = getattr(self, name, None)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            setattr(self, name, ws)
+        return C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel())
 
     def iterate_pick(self, buf: dict, n_iters: int, qfun, outer_iter: int, max_relax_iter: int = 55,
                      cost_it=None, pick: bool = True, best=None):
@@ -437,8 +443,9 @@ class BatchedILQR:
                 self._stream()))
         return cost_it, ((idx, val) if pick else None)
 
-    def argmin(self, cost_it):
-        """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1])."""
+    def argmin(self, cost_it, side: bool = False):
+        """Flat arg-min with first-index tie-break.  Returns (best_idx int64[1], best_cost[1]).
+        side=True: on the second workspace (see _argmin_workspace)."""
         B = cost_it.shape[0]
         idx = self.empty(1, dtype=torch.int64)
         val = self.empty(1)
@@ -446,5 +453,5 @@ class BatchedILQR:
             self._check(self.lib.i2lqr_argmin(
                 self._handle, B, self._ptr(cost_it, (B,), name="cost_it"),
                 C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()),
-                *self._argmin_workspace(B), self._stream()))
+                *self._argmin_workspace(B, side), self._stream()))
         return idx, val

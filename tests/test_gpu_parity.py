@@ -987,13 +987,12 @@ def test_quad12_one_problem_per_lane_kernel_vs_oracle(torch_mod, layout_id, B):
     X2, U2 = it["X"].clone(), it["U"].clone()
     cost2 = solver.rollout(X2, U2, it["x_term"])
     assert torch.equal(U2, it["U"]) and torch.equal(X2, it["X"]) and torch.equal(cost2, it["cost"])
-    # stage weights are not built for this plant on these layouts: a clear error, no fallback
+    # stage weights run on these layouts since round 5 (tests/test_gpu_round5.py checks them against
+    # the oracle); fp32 is still the problem-major kernels' (a clear error, no fallback)
     from ilqr_iterative_tasks_amd.solver import I2lqrError
-    wcfg = default_config("quad12", 50, "f64", dt=0.02, layout=layout_id)
-    wcfg.set_matrix("R", 0.01 * np.eye(4))
-    ws = BatchedILQR(wcfg)
-    with pytest.raises(I2lqrError, match="Q = R = 0"):
-        ws.iterate(dev_batch(ws, workloads.make_batch(wcfg, 64)), 1)
+    with pytest.raises(I2lqrError):
+        f32 = BatchedILQR(default_config("quad12", 50, "f32", dt=0.02, layout=layout_id))
+        f32.iterate(dev_batch(f32, workloads.make_batch(f32.cfg, 64)), 1)
 
 
 def test_quad12_full_size_on_the_lane_kernel(torch_mod):
@@ -1332,5 +1331,7 @@ def test_random_configurations_every_family_against_the_oracle():
                          capture_output=True, text=True, timeout=900, cwd=str(root))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "held everywhere" in out.stdout
-    # 7 + 7 + 4 (plant, family) lines: the bicycles incl. the sixteen-lane DPP form ("row16")
-    assert sum(l.startswith(("bicycle4", "bicycle6", "quad12")) for l in out.stdout.splitlines()) == 18
+    # 7 + 7 + 4 (plant, family) lines: the bicycles incl. the sixteen-lane DPP form ("row16"), and
+    # 3 + 3 with stage weights (round 5: quad12's lane kernels take Q, R != 0)
+    assert sum(l.startswith(("bicycle4", "bicycle6", "quad12")) for l in out.stdout.splitlines()) == 24
+    assert sum(l.startswith("quad12+QR") for l in out.stdout.splitlines()) == 3

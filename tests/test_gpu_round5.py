@@ -59,7 +59,7 @@ def test_pick_workspace_smaller_than_the_batch_needs_is_refused(torch_mod):
         solver._argmin_ws = torch.empty(16, dtype=torch.uint8, device=solver.device)
         solver.lib.i2lqr_argmin_workspace_bytes.restype = C.c_int64
         orig = solver._argmin_workspace
-        solver._argmin_workspace = lambda B: (C.c_void_p(solver._argmin_ws.data_ptr()), C.c_int64(16))
+        solver._argmin_workspace = lambda B, side=False: (C.c_void_p(solver._argmin_ws.data_ptr()), C.c_int64(16))
         try:
             solver.argmin(solver.empty(100000))
         finally:
