@@ -594,9 +594,14 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
                        (a.ckpt ? kSegBytes : 0);
     if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
-      if (c.flags)
-        hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, true, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
-      else
+      bool launched = false;
+      if constexpr (kStageWeights) {  // (need_ws() has refused stage weights where they are not built)
+        if (c.flags) {
+          hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, true, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
+          launched = true;
+        }
+      }
+      if (!launched)
         hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, false, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
     } else {
       if (c.flags)
@@ -861,6 +866,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       } else {                                                                                \
         if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, false>::CALL; \
         if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, false>::CALL; \
+        if (sid_ == I2LQR_SYS_QUAD12) return LaneLaunch<float, Quad12<float>, false>::CALL;     \
       }                                                                                       \
       return fail(I2LQR_ERR_UNSUPPORTED, "system %d is not built for the batch-minor layout", \
                   sid_);                                                                      \
@@ -876,6 +882,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       } else {                                                                                \
         if (sid_ == I2LQR_SYS_BICYCLE4) return LaneLaunch<float, Bicycle4<float>, true>::CALL; \
         if (sid_ == I2LQR_SYS_BICYCLE6) return LaneLaunch<float, Bicycle6<float>, true>::CALL; \
+        if (sid_ == I2LQR_SYS_QUAD12) return LaneLaunch<float, Quad12<float>, true>::CALL;      \
       }                                                                                       \
       return fail(I2LQR_ERR_UNSUPPORTED, "system %d is not built for the batch-tiled layout", \
                   sid_);                                                                      \
@@ -1253,7 +1260,8 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
     case I2LQR_SYS_QUAD12:
       if (f64) return tiled ? LaneLaunch<double, Quad12<double>, true>::ws_bytes(N, B)
                             : LaneLaunch<double, Quad12<double>, false>::ws_bytes(N, B);
-      return 0;
+      return tiled ? LaneLaunch<float, Quad12<float>, true>::ws_bytes(N, B)
+                   : LaneLaunch<float, Quad12<float>, false>::ws_bytes(N, B);
     default: return 0;
   }
 }
@@ -1297,7 +1305,7 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
                 sizeof(i2lqr_config));
   if (B < 0) return fail(I2LQR_ERR_INVALID, "negative batch %lld", (long long)B);
   // what the lane layouts cannot run stays problem-major: non-symmetric weights (the kernels keep
-  // the upper triangles), and for quad12 (row-block kernel) fp32
+  // the upper triangles), and for quad12 (row-block kernel) fp32 WITH stage weights
   bool lane_ok = true, weights = false;
   for (int i = 0; i < cfg->n; i++)
     for (int j = 0; j < cfg->n; j++) {
@@ -1320,7 +1328,7 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
       break;
     case I2LQR_SYS_QUAD12:
       from = kLaneBatchQuad;  // (with stage weights too: round 5)
-      if (cfg->dtype != I2LQR_F64) lane_ok = false;
+      if (cfg->dtype != I2LQR_F64 && weights) lane_ok = false;  // fp32: Q = R = 0 (round 5)
       break;
     default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
   }

@@ -6,36 +6,41 @@
 
 namespace i2lqr {
 
-// (QR: the stage-weight instantiations, compiled in i2lqr_lane12qr.hip)
-#define I2LQR_LANE12_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, false)
-#define I2LQR_LANE12QR_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, true)
-#define I2LQR_LANE12_KERNELS_(DECL, QR)                                                          \
-  DECL void k_lane_iterate_rows<double, Quad12<double>, QR, false>(const DevCfg<double, 12, 4>,   \
-                                                                   const LaneArgs<double>);       \
-  DECL void k_lane_iterate_rows<double, Quad12<double>, QR, true>(const DevCfg<double, 12, 4>,    \
-                                                                  const LaneArgs<double>);        \
-  DECL void k_lane_rollout<double, Quad12<double>, QR, false>(                                 \
-      const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
-  DECL void k_lane_rollout<double, Quad12<double>, QR, true>(                                  \
-      const DevCfg<double, 12, 4>, int64_t, double*, double*, const double*, double*);            \
-  DECL void k_lane_backward<double, Quad12<double>, QR, false>(                                \
-      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
-      const double*, const double*, double*, double*);                                            \
-  DECL void k_lane_backward<double, Quad12<double>, QR, true>(                                 \
-      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
-      const double*, const double*, double*, double*);                                            \
-  DECL void k_lane_forward<double, Quad12<double>, QR, false>(                                 \
-      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
-      const double*, const double*, double*, double*, double*);                                   \
-  DECL void k_lane_forward<double, Quad12<double>, QR, true>(                                  \
-      const DevCfg<double, 12, 4>, int64_t, const double*, const double*, const double*,          \
-      const double*, const double*, double*, double*, double*);
+// (QR: the stage-weight instantiations, compiled in i2lqr_lane12qr.hip; F32: fp32, Q = R = 0,
+// compiled in i2lqr_lane12f.hip)
+#define I2LQR_LANE12_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, double, false)
+#define I2LQR_LANE12QR_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, double, true)
+#define I2LQR_LANE12F_KERNELS(DECL) I2LQR_LANE12_KERNELS_(DECL, float, false)
+#define I2LQR_LANE12_KERNELS_(DECL, REAL, QR)                                                  \
+  DECL void k_lane_iterate_rows<REAL, Quad12<REAL>, QR, false>(const DevCfg<REAL, 12, 4>,   \
+                                                                   const LaneArgs<REAL>);       \
+  DECL void k_lane_iterate_rows<REAL, Quad12<REAL>, QR, true>(const DevCfg<REAL, 12, 4>,    \
+                                                                  const LaneArgs<REAL>);        \
+  DECL void k_lane_rollout<REAL, Quad12<REAL>, QR, false>(                                 \
+      const DevCfg<REAL, 12, 4>, int64_t, REAL*, REAL*, const REAL*, REAL*);            \
+  DECL void k_lane_rollout<REAL, Quad12<REAL>, QR, true>(                                  \
+      const DevCfg<REAL, 12, 4>, int64_t, REAL*, REAL*, const REAL*, REAL*);            \
+  DECL void k_lane_backward<REAL, Quad12<REAL>, QR, false>(                                \
+      const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
+      const REAL*, const REAL*, REAL*, REAL*);                                            \
+  DECL void k_lane_backward<REAL, Quad12<REAL>, QR, true>(                                 \
+      const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
+      const REAL*, const REAL*, REAL*, REAL*);                                            \
+  DECL void k_lane_forward<REAL, Quad12<REAL>, QR, false>(                                 \
+      const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
+      const REAL*, const REAL*, REAL*, REAL*, REAL*);                                   \
+  DECL void k_lane_forward<REAL, Quad12<REAL>, QR, true>(                                  \
+      const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
+      const REAL*, const REAL*, REAL*, REAL*, REAL*);
 
 #ifndef I2LQR_LANE12_DEFINE
 I2LQR_LANE12_KERNELS(extern template __global__)
 #endif
 #ifndef I2LQR_LANE12QR_DEFINE
 I2LQR_LANE12QR_KERNELS(extern template __global__)
+#endif
+#ifndef I2LQR_LANE12F_DEFINE
+I2LQR_LANE12F_KERNELS(extern template __global__)
 #endif
 
 }  // namespace i2lqr

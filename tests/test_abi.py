@@ -116,7 +116,9 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     q = _abi.default_config("quad12", 50)
     assert [ask(q, B) for B in (64, 8191, 8192, 65536)] == [0, 0, 2, 2]
     q32 = _abi.default_config("quad12", 50, "f32")
-    assert ask(q32, 65536) == 0                                             # fp32: problem-major kernels
+    assert ask(q32, 65536) == 2                                             # fp32: lane kernels too (round 5) ...
+    q32.set_matrix("R", np.diag([0.1] * 4))
+    assert ask(q32, 65536) == 0                                             # ... but not with stage weights
     qr = _abi.default_config("quad12", 50)
     qr.set_matrix("R", np.diag([0.1] * 4))
     assert ask(qr, 65536) == 2 and ask(qr, 4096) == 0                       # stage weights: lane kernels too (round 5)
