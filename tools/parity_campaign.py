@@ -93,9 +93,9 @@ for plant, spec in PLANTS.items():
         N = int(rng.choice(spec["N"]))
         dt = float(rng.choice(spec["dt"]))
         B = int(rng.choice([64, 128, 192])) if system == "quad12" else int(rng.choice([64, 192, 448, 1024]))
-        wseed = int(rng.integers(1 << 30))
         cfg0 = default_config(system, N, "f64", dt=dt)
-        if spec.get("weights"):
+        if spec.get("weights"):  # (drawn for these plants only: the other plants' sample is round 4's)
+            wseed = int(rng.integers(1 << 30))
             with_weights(cfg0, np.random.default_rng(wseed))
         host = workloads.make_batch(cfg0, B, seed=1000 + trial)
         host["lamb"] = 10.0 ** rng.integers(-6, 3, B).astype(float)
