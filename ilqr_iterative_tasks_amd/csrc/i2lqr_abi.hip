@@ -1296,7 +1296,17 @@ inline LaneFrom lane_from(const i2lqr_config& cfg) {
   const int nb = cfg.N <= 10 ? 0 : (cfg.N <= 31 ? 1 : 2);  // sqrt(6 x 20) = 10.95, sqrt(20 x 50) = 31.6
   return kLaneFrom[sys][nb][cfg.dtype == I2LQR_F64 ? 0 : 1];
 }
-constexpr int64_t kLaneBatchQuad = 8192;
+// quad12 (round 5, the same sweep: profiles/r05_threshold_sweep3.json, ..4.json; round 4: 8192 for
+// everything, measured at N = 50 fp64 fixed counts only).  The problem-major side is the
+// sixteen-lane kernel with its HBM workspace (rounds of 4096 problems); solves stay there longer
+// because the lane layouts have no latency tail for this plant.  [N <= 31, N > 31][fp64, fp32]
+constexpr LaneFrom kLaneFromQuad[2][2] = {
+    /* N ~ 20 */ {{4097, 8193}, {8193, 24577}},
+    /* N ~ 50 */ {{4097, 6145}, {8193, 12289}},
+};
+// with stage weights the problem-major side is the one-problem-per-wavefront kernel: 2048 problems
+// already fill the chip's SIMDs (as for the bicycles)
+constexpr int64_t kLaneFromWeights = 2048;
 
 int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit) {
   if (!cfg) return fail(I2LQR_ERR_INVALID, "null config");
@@ -1324,12 +1334,15 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
     case I2LQR_SYS_BICYCLE6:
       // with stage weights the problem-major side is the one-problem-per-wavefront kernel (the
       // column kernels are built for Q = R = 0): 1024 problems already fill the chip's SIMDs
-      from = weights ? 2048 : (early_exit ? lane_from(*cfg).solve : lane_from(*cfg).iterate);
+      from = weights ? kLaneFromWeights
+                     : (early_exit ? lane_from(*cfg).solve : lane_from(*cfg).iterate);
       break;
-    case I2LQR_SYS_QUAD12:
-      from = kLaneBatchQuad;  // (with stage weights too: round 5)
+    case I2LQR_SYS_QUAD12: {
+      const LaneFrom q = kLaneFromQuad[cfg->N <= 31 ? 0 : 1][cfg->dtype == I2LQR_F64 ? 0 : 1];
+      from = weights ? kLaneFromWeights : (early_exit ? q.solve : q.iterate);
       if (cfg->dtype != I2LQR_F64 && weights) lane_ok = false;  // fp32: Q = R = 0 (round 5)
       break;
+    }
     default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
   }
   if (!lane_ok || B < from) return I2LQR_LAYOUT_PROBLEM_MAJOR;

@@ -113,15 +113,16 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     assert [ask(b6, B) for B in (12352, 65536, 1 << 20)] == [2, 2, 2]      # multiples of 64: tiled
     assert ask(b6, 12289) == 1 and ask(b6, 65537) == 1                      # ragged: batch-minor
     assert ask(b6, 12288, 1) == 0 and ask(b6, 12352, 1) == 2                # solves: the same crossover
-    q = _abi.default_config("quad12", 50)
-    assert [ask(q, B) for B in (64, 8191, 8192, 65536)] == [0, 0, 2, 2]
+    q = _abi.default_config("quad12", 50)                                   # quad12: its own measured table
+    assert [ask(q, B) for B in (64, 4096, 4160, 8192, 65536)] == [0, 0, 2, 2, 2]
+    assert [ask(q, B, 1) for B in (4160, 6144, 6208)] == [0, 0, 2]          # solves stay problem-major longer
     q32 = _abi.default_config("quad12", 50, "f32")
     assert ask(q32, 65536) == 2                                             # fp32: lane kernels too (round 5) ...
     q32.set_matrix("R", np.diag([0.1] * 4))
     assert ask(q32, 65536) == 0                                             # ... but not with stage weights
     qr = _abi.default_config("quad12", 50)
     qr.set_matrix("R", np.diag([0.1] * 4))
-    assert ask(qr, 65536) == 2 and ask(qr, 4096) == 0                       # stage weights: lane kernels too (round 5)
+    assert ask(qr, 65536) == 2 and ask(qr, 1024) == 0                       # stage weights: lane kernels too (round 5)
     b4 = _abi.default_config("bicycle4", 6)                                 # the reference's shape: its own
     assert ask(b4, 8192) == 0 and ask(b4, 8256) == 2                        # crossover (measured table)
     br = _abi.default_config("bicycle6", 20)

@@ -22,7 +22,7 @@ def _shapes():
 
 def _cfg(name):
     system, N, dtype = name.split("_")
-    dt = {"bicycle4_N6": 1.0, "bicycle4_N20": 0.5}.get(f"{system}_{N}", 0.25)
+    dt = {"bicycle4_N6": 1.0, "bicycle4_N20": 0.5}.get(f"{system}_{N}", 0.02 if system == "quad12" else 0.25)
     return default_config(system, int(N[1:]), dtype, dt=dt)
 
 
@@ -31,7 +31,7 @@ def test_recommendation_follows_the_measured_table():
     lib = _abi.load_library()
     import ctypes as C
     shapes = _shapes()
-    assert len(shapes) >= 12
+    assert len(shapes) >= 16  # twelve bicycle shapes + four of quad12
     checked = wrong = 0
     worst = []
     for name, rows in shapes.items():

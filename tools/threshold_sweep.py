@@ -35,13 +35,17 @@ SHAPES = {
     "bicycle4_N50_f64": ("bicycle4", 50, "f64", 0.25),
     "bicycle4_N50_f32": ("bicycle4", 50, "f32", 0.25),
     "bicycle6_N50_f32": ("bicycle6", 50, "f32", 0.25),
+    "quad12_N50_f64": ("quad12", 50, "f64", 0.02),
+    "quad12_N20_f64": ("quad12", 20, "f64", 0.02),
+    "quad12_N50_f32": ("quad12", 50, "f32", 0.02),
+    "quad12_N20_f32": ("quad12", 20, "f32", 0.02),
 }
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default=",".join(SHAPES))
 ap.add_argument("--batches", default="2048,4096,6144,8192,10240,12288,14336,16384,20480,24576,32768")
 ap.add_argument("--rounds", type=int, default=7)
-ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--iters", type=int, default=10)  # (quad12: 4, as in bench.py)
 ap.add_argument("--solve", type=int, default=1)
 ap.add_argument("--out", default="gpurun_out/threshold_sweep.json")
 args = ap.parse_args()
@@ -67,6 +71,8 @@ def variants_for(B):
 
 for shape in args.shapes.split(","):
     system, N, dtype, dt = SHAPES[shape]
+    if system == "quad12":
+        args.iters = 4
     rows = {}
     for B in [int(b) for b in args.batches.split(",")]:
         runs = []
