@@ -122,6 +122,7 @@ struct i2lqr_handle {
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
   int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt, opt_stagger;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
+  int opt_pair;  // bicycles' lane kernel, fp64: workgroups of two wavefronts (main + helper); -1 = automatic
   int opt_chunk_step;  // chunked solve: length of the chunk that follows the first (automatic: 4); a schedule to measure against
   int opt_first_chunk;  // chunked solve: pinned length of the first chunk, no extension chunks (a hand-tuned schedule to measure the data-driven one against); -1 = automatic
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
@@ -589,10 +590,31 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (a.lds_steps > steps) a.lds_steps = steps;
     }
   }
+  // The helper-wavefront form (k_lane_iterate_pair; round 5): fp64 bicycles with Q = R = 0, states
+  // not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
+  // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
+  static constexpr unsigned kPairMaxGrid = 512;
+  static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
+    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
+      if (c.flags || a.ckpt || opt_pair == 0) return false;
+      return opt_pair == 1 ? true : grid(B) <= kPairMaxGrid;
+    }
+    return false;
+  }
   template <bool TL>
-  static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s) {
+  static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s,
+                             int opt_pair = 0) {
     const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
                        (a.ckpt ? kSegBytes : 0);
+    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
+      if (use_pair(c, a, B, opt_pair)) {
+        using LW = LaneWorker<T, Sys, false, TL>;
+        const size_t lds_pair = lds + 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
+        hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(grid(B)), dim3(128), lds_pair, s,
+                           c, a);
+        return;
+      }
+    }
     if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
       bool launched = false;
       if constexpr (kStageWeights) {  // (need_ws() has refused stage weights where they are not built)
@@ -681,7 +703,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // one live counter per compaction round, all cleared by ONE fill in front of the first chunk (a
     // fill per round was a 5 us launch of its own in each of the rounds that follow the tail)
     HIP_TRY(hipMemsetAsync(cv.count, 0, kMaxRounds * sizeof(int32_t), s));
-    launch_iterate<TILED>(c, a0, B, s);
+    launch_iterate<TILED>(c, a0, B, s, h->opt_pair);
     done += len;
     const unsigned cgrid = (unsigned)((B + 255) / 256);
     int cur = 0;    // work set that receives the survivors
@@ -737,7 +759,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       a.K = nullptr; a.k = nullptr;  // gains of work sets go to the scratch buffer (w.K == wsK)
       a.iters = w.iters; a.status = w.status;
       a.count = count; a.resume = 1; a.n_iters = len;
-      launch_iterate<false>(c, a, B, s);
+      launch_iterate<false>(c, a, B, s, h->opt_pair);
       done += len;
       src = w;
       src_user = false;
@@ -780,7 +802,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (h->opt_defer < 0) a.defer = 0;
       finish_options(h, B, a);
     }
-    launch_iterate<TILED>(c, a, B, s);
+    launch_iterate<TILED>(c, a, B, s, h->opt_pair);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
@@ -1193,6 +1215,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->wave_tail = -1;
   h->opt_first_chunk = -1;
   h->opt_chunk_step = -1;
+  h->opt_pair = -1;
   h->ticket = nullptr;
   h->ticket_next.store(0);
   constexpr size_t kTicketBytes = i2lqr_handle::kTickets * sizeof(unsigned);
@@ -1281,15 +1304,17 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
 //   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
 //   8192 and 73 M at 65536.
 struct LaneFrom { int64_t iterate, solve; };
+// (the fp64 columns re-measured with the helper-wavefront form of the lane kernel, which moved the
+// bicycle6 N = 20 crossover from 12289 to 8193: profiles/r05_threshold_sweep5.json)
 constexpr LaneFrom kLaneFrom[2][3][2] = {
     // bicycle4:          fp64              fp32
     /* N ~ 6  */ {{{8193, 10241}, {12289, 10241}},
-    /* N ~ 20 */  {{8193, 4097}, {8193, 10241}},
-    /* N ~ 50 */  {{8193, 4096}, {8193, 5121}}},
-    // bicycle6
-    /* N ~ 6  */ {{{8193, 8193}, {8193, 20481}},
-    /* N ~ 20 */  {{12289, 12289}, {16385, 12289}},
+    /* N ~ 20 */  {{8193, 4096}, {8193, 10241}},
     /* N ~ 50 */  {{4097, 4096}, {8193, 5121}}},
+    // bicycle6
+    /* N ~ 6  */ {{{8193, 6145}, {8193, 20481}},
+    /* N ~ 20 */  {{8193, 10241}, {16385, 12289}},
+    /* N ~ 50 */  {{3073, 4096}, {8193, 5121}}},
 };
 inline LaneFrom lane_from(const i2lqr_config& cfg) {
   const int sys = cfg.system_id == I2LQR_SYS_BICYCLE6 ? 1 : 0;
@@ -1370,6 +1395,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "per_step_jacobians")) h->opt_fstep = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 65536 ? 65536 : v);
   else if (!strcmp(name, "first_chunk")) h->opt_first_chunk = v < 1 ? -1 : (v > 1024 ? 1024 : v);
+  else if (!strcmp(name, "helper_wavefront")) h->opt_pair = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "chunk_step")) h->opt_chunk_step = v < 1 ? -1 : (v > 1024 ? 1024 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);
@@ -1400,8 +1426,18 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
 
 static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit) {
   if (!h) return "";
-  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR)
-    return h->cfg.system_id == I2LQR_SYS_QUAD12 ? "k_lane_iterate_rows" : "k_lane_iterate";
+  if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) {
+    if (h->cfg.system_id == I2LQR_SYS_QUAD12) return "k_lane_iterate_rows";
+    // the helper-wavefront form: fp64, Q = R = 0, at most 512 workgroups (LaneLaunch::use_pair;
+    // states are checkpointed from 65536 problems only, i.e. never in that range)
+    bool weights = false;
+    for (int i = 0; i < I2LQR_MAX_N * I2LQR_MAX_N && !weights; i++) weights = h->cfg.Q[i] != 0.0;
+    for (int i = 0; i < I2LQR_MAX_M * I2LQR_MAX_M && !weights; i++) weights = h->cfg.R[i] != 0.0;
+    const bool pair = h->cfg.dtype == I2LQR_F64 && !weights && h->opt_pair != 0 &&
+                      (h->opt_pair == 1 || (B + 63) / 64 <= 512) &&
+                      !(early_exit && B >= 65536);
+    return pair ? "k_lane_iterate_pair" : "k_lane_iterate";
+  }
   switch (select_fused(h, B, early_exit, nullptr)) {
     case K_SPEC: return "k_group_spec";
     case K_SPEC16: return "k_group_spec (sixteen lanes)";

@@ -94,7 +94,7 @@ template <bool TILED> struct LaneView {
   unsigned bl;    // this lane's index inside the wavefront's 64 columns of a row
   int64_t tile;   // wavefront index (workgroups are one wavefront): uniform, lives in SGPRs
   __device__ LaneView(int64_t B)
-      : Bs(TILED ? 64 : B), bl(threadIdx.x), tile(blockIdx.x) {}
+      : Bs(TILED ? 64 : B), bl(threadIdx.x & 63), tile(blockIdx.x) {}  // (& 63: two-wavefront workgroups)
   // Re-base an array of `rows` rows to this wavefront's 64 problems.  The result is WAVE-UNIFORM
   // (scalar registers); element (row, lane) is p[row * Bs + bl], which the compiler addresses as
   // scalar base + per-lane 32-bit offset + immediate row offset.
@@ -573,11 +573,24 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   static constexpr bool DEEP = (sizeof(T) == 4 || I2LQR_DEEP64) && I2LQR_DEEP_PREFETCH;
 
   // CK: checkpointed states (kSeg above); seg = (kSeg + 1) n 64 words of LDS for this wavefront.
-  template <bool FASTBAR = false, bool CK = false>
+  // ROLE (k_lane_iterate_pair: a HELPER wavefront beside the main one, where the launch leaves SIMDs
+  // idle): 0 = the whole pass on this wavefront; 2 = the helper's half — the part of every step that
+  // depends on the nominal trajectory only (loads of x_{t+1}, x_t, u_t; sin / cos; Jacobian entries;
+  // the input barriers' exponentials; the obstacle term: 30 % of an iteration's cycles at 16384
+  // problems), written as a RECORD of kRec words per lane into one of two LDS slots; 1 = the main
+  // wavefront's half — the Riccati step on the record the helper left.  One workgroup barrier per
+  // horizon step: helper  R(N-1) | R(N-2) | ... ,  main  | S(N-1) | S(N-2) ...  — the helper is a step
+  // ahead and the shorter of the two, so the main wavefront does not wait.  Same operations on the
+  // same operands as ROLE 0 (the record travels through LDS unchanged): bit-identical.
+  static constexpr int kRec = NV + 5 + 2 * m;  // jv, obstacle terms, l_u, l_uu (Q = R = 0)
+  lds_t* rec = nullptr;                        // [2][kRec][64], set by the kernel
+  template <bool FASTBAR = false, bool CK = false, int ROLE = 0>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
                                            lds_t* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
+    static_assert(ROLE == 0 || (!CK && !DEEP && !HASQR && Sys::NBLK == 0),
+                  "the helper form is built for the plain fp64 pass with Q = R = 0");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
       __shared__ T lds_gains[kGainWords];
@@ -621,7 +634,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     const int last_sg = (N - 1) / kSeg, last_len = N - last_sg * kSeg;
     if constexpr (CK) roll_segment(last_sg, last_len);
     T Va[n][n + 1];  // [Vxx | Vx]; with SYM only Va[i][j >= i] and the last column are live
-    {
+    if constexpr (ROLE != 2) {
       // get_cost_final(): control/ilqr_helper.py:106-150
       T xN[n], o[5];
 #pragma unroll
@@ -650,7 +663,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     // alone on its SIMD cannot hide the rest); fp64 sits on the HBM roof either way.
     constexpr int D = DEEP ? 2 : 1;  // prefetch distance in horizon steps
     T xe[n], xp[n], u[m];  // x_{t+1}, x_t, u_t
-    if constexpr (!CK) {
+    if constexpr (!CK && ROLE != 1) {
 #pragma unroll
       for (int i = 0; i < n; i++) xe[i] = at(X, rx(i, N));
 #pragma unroll
@@ -660,7 +673,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     }
     auto body = [&](const int t, T (&xp)[n], T (&u)[m]) __attribute__((always_inline)) {
       T jv[NV], o[5], tr[NT];
+      T lu[m], luu[m];
+      T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
       STAMP_BEGIN();
+      if constexpr (ROLE != 1) {
       Sys::trig(xe, tr);  // the same values the rollout used for the dynamics of step t+1
       Sys::jac_var(c, xe, u, tr, jv);
       obstacle(ob, ob_pa, ob_pb, xp[0], xp[1], t, o);
@@ -671,7 +687,6 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
       // forward pass, and configurations with |2 q2 u_max| < 600): e_hi e_lo = exp(-2 q2 u_max) is
       // a constant, so e_lo = ctrl_c / e_hi — one short exp (no range handling: the argument is
       // bounded) and one reciprocal per input instead of two general exps; a few ulp apart.
-      T lu[m], luu[m];
 #pragma unroll
       for (int a = 0; a < m; a++) {
         T e_hi, e_lo;
@@ -691,7 +706,6 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         luu[a] = c.ctrl_q122 * e_hi +
                  c.ctrl_q122 * e_lo;
       }
-      T lxq[n];  // 2Q dX[:, t]: control/ilqr_helper.py:29
 #pragma unroll
       for (int a = 0; a < n; a++) {
         T l = T(0);
@@ -710,6 +724,36 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
           for (int a = 0; a < m; a++) u[a] = at(U, ru(a, t - D));
         }
+      }
+      }  // ROLE != 1
+      if constexpr (ROLE == 2) {  // the helper's step ends here: record -> LDS slot t & 1, barrier
+        lds_t* const r = rec + (size_t)(t & 1) * kRec * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int q = 0; q < NV; q++) r[q * 64] = jv[q];
+#pragma unroll
+        for (int q = 0; q < 5; q++) r[(NV + q) * 64] = o[q];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+          r[(NV + 5 + a) * 64] = lu[a];
+          r[(NV + 5 + m + a) * 64] = luu[a];
+        }
+        __syncthreads();
+        return;
+      }
+      if constexpr (ROLE == 1) {  // the main wavefront's step starts here: the helper's record
+        __syncthreads();
+        const lds_t* const r = rec + (size_t)(t & 1) * kRec * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int q = 0; q < NV; q++) jv[q] = r[q * 64];
+#pragma unroll
+        for (int q = 0; q < 5; q++) o[q] = r[(NV + q) * 64];
+#pragma unroll
+        for (int a = 0; a < m; a++) {
+          lu[a] = r[(NV + 5 + a) * 64];
+          luu[a] = r[(NV + 5 + m + a) * 64];
+        }
+#pragma unroll
+        for (int a = 0; a < n; a++) lxq[a] = T(0);
       }
 
       STAMP_END(0);
@@ -1725,6 +1769,190 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
     }
 #endif
   }
+  // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
+  if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
+  if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;
+#ifdef I2LQR_STAMPS
+  if (a.dbg && threadIdx.x == 0)
+    for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
+#endif
+  if constexpr (kCanCkpt) {
+    if (ckpt) w.restore_states(X, Uc);  // the caller's X in full: one re-roll per launch
+  }
+  w.flush_gains(gK, gk);
+  if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
+    for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
+  }
+  a.lamb[b] = lamb;
+  a.cost[b] = cost_ret;
+  if (a.iters) a.iters[b] = it0 + it;
+  if (a.status) a.status[b] = status;
+}
+
+// k_lane_iterate with a HELPER wavefront (round 5; VERDICT r4 #4: 8 k - 32 k problems).  Up to 32768
+// problems the one-problem-per-lane launch is one or two wavefronts per CU — issue-bound on ITS
+// SIMD while the CU's other SIMDs idle (launch floor 0.53 ms per 10 iterations up to 16384
+// problems), and masked lanes do not issue faster.  What CAN run elsewhere is the part of the
+// backward pass that depends on the nominal trajectory only: workgroups of TWO wavefronts, the second
+// one computing every step's record a step ahead of the first (LaneWorker::backward<.., ROLE>).
+// fp64, Q = R = 0, states not checkpointed; same arguments, results bit-identical to k_lane_iterate.
+template <class T, class Sys, bool TILED>
+__global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
+    const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {
+  constexpr int n = Sys::n, m = Sys::m;
+  constexpr bool HASQR = false;
+  const int role = threadIdx.x >> 6;  // 0: main wavefront, 1: helper
+  const unsigned l64 = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 64 + l64;
+  const int64_t live = a.count ? (int64_t)*a.count : a.B;
+  if (b >= live) return;
+  if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
+  const int N = c.N;
+  const LaneView<TILED> v(a.B);
+  LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
+  extern __shared__ __align__(16) unsigned char lane_smem[];
+  typedef __attribute__((address_space(3))) T lds_t;
+  w.lds = (lds_t*)lane_smem;
+  w.has_lds = true;
+  w.lds_steps = a.lds_steps;
+  const T* gxt = v.rebase(a.x_term, n);
+  const T* gob = v.rebase(a.obs, 6);
+  T xT[n], ob[6];
+#pragma unroll
+  for (int i = 0; i < n; i++) xT[i] = gxt[(int64_t)i * v.Bs + v.bl];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ob[q] = gob ? gob[(int64_t)q * v.Bs + v.bl] : T(q == 5 ? -1 : 1);
+  T lamb = a.lamb[b];
+  T* gK = v.rebase(a.K ? a.K : a.wsK, m * n * N);
+  T* gk = v.rebase(a.K ? a.k : a.wsk, m * N);
+  // States live in ONE buffer (the caller's X); only the inputs (m N words) are double-buffered
+  // per lane.  With X double-buffered per lane too, divergent accept/reject decisions split every
+  // row access of a wavefront over two buffers: +38 % HBM traffic per iteration (rocprofv3
+  // FETCH_SIZE / WRITE_SIZE, tools/pmc_iters.sh).  Either the forward pass stores no states and
+  // accepted steps re-roll them (a.defer), or it writes the candidate states over the nominal
+  // ones in place (each x_t is loaded one step ahead of being overwritten) and rejected steps
+  // re-roll the nominal ones; both re-rolls are bit-identical to what the rollout stored.
+  T* const X = v.rebase(a.X, n * (N + 1));
+  T* const U0 = v.rebase(a.U, m * N);
+  T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
+
+  // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
+  // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
+  // checkpointed states (fp64 only; host: deferred + merged + re-rolling forward pass, Q = R = 0)
+  constexpr bool kCanCkpt = false;  // (the host gives this kernel no checkpointed launch)
+  const bool ckpt = false;
+  // LDS behind the gains: the two record slots and the control words of the pair
+  typedef LaneWorker<T, Sys, HASQR, TILED> LW;
+  w.rec = (lds_t*)lane_smem + (size_t)a.lds_steps * 64 * m * (n + 1) + 64 * m;
+  typedef __attribute__((address_space(3))) int lds_i;
+  lds_i* const ctl = (lds_i*)(w.rec + 2 * LW::kRec * 64);  // [64] input buffer of each lane, [64]: go
+  if (role == 1) {
+    // helper: its half of every backward pass the main wavefront announces (same lanes, same
+    // problems; it never touches the gains, the candidate or the accept / reject state)
+    const T* const Xh = v.rebase(a.X, n * (N + 1));
+    const T* const Uh0 = v.rebase(a.U, m * N);
+    const T* const Uh1 = v.rebase(a.wsU, m * N);
+    for (;;) {
+      __syncthreads();  // B0: the control words of this pass are written
+      if (!ctl[64]) return;
+      w.template backward<true, false, 2>(Xh, ctl[l64] ? Uh1 : Uh0, xT, ob, lamb, nullptr, nullptr,
+                                          false);
+    }
+  }
+  if (a.stagger > 0 && ((blockIdx.x >> 9) & 1)) {  // see k_lane_iterate_rows
+    for (int q = 0; q < a.stagger; q++) __builtin_amdgcn_s_sleep(127);
+  }
+  T cost = w.rollout(X, Uc, xT, ckpt);
+  const int it0 = a.resume ? a.iters[b] : 0;  // iterations of earlier chunks
+  int it = 0, status = a.early_exit ? 2 : 0;
+  T cost_ret = cost;
+  while (it < a.n_iters && it0 + it < a.max_total) {
+    // K_0 goes to HBM from the passes that can be this launch's last one for the problem
+    const bool k0_out = a.early_exit || it + 1 >= a.n_iters || it0 + it + 1 >= a.max_total;
+    ctl[l64] = Uc != U0;  // which input buffer holds this lane's nominal inputs
+    ctl[64] = 1;
+    __syncthreads();  // B0
+    w.template backward<true, false, 1>(X, Uc, xT, ob, lamb, gK, gk, k0_out);
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_BEGIN();
+    }
+#endif
+    T cost_new;
+    if (a.defer) {
+      cost_new = a.reroll ? w.template forward<true, false>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false, false>(X, Uc, gK, gk, X, Un, xT);
+    } else {
+      cost_new = a.reroll ? w.template forward<true>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false>(X, Uc, gK, gk, X, Un, xT);
+    }
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_END(4);
+    }
+#endif
+    it++;
+    const bool accepted = cost_new < cost;
+    // X must hold the states of each lane's CURRENT inputs: deferred mode owes them to the lanes
+    // that accepted, in-place mode to the lanes that rejected.  If any lane of the wavefront needs
+    // it, ALL of them re-roll and store (the others rewrite what is already there, bit for bit):
+    // full 64-lane rows instead of masked partial ones, which cost a read-modify-write in HBM.
+    if (a.defer && a.merge) {
+      // the current inputs stay in ONE buffer for the whole wavefront: accepted candidates are
+      // merged into it during the re-roll (Uc == U0, Un == workspace throughout)
+      if (__all(accepted)) {
+        // every lane of the wavefront accepted: the two input buffers change roles for the whole
+        // wavefront (still ONE buffer with full rows, no copy) and the states are re-rolled
+        T* tp = Uc; Uc = Un; Un = tp;
+        if constexpr (kCanCkpt) {
+          if (ckpt) w.template restore_states_paired<false, true>(X, Uc);
+          else w.restore_states(X, Uc);
+        } else {
+          w.restore_states(X, Uc);
+        }
+      } else if (__any(accepted)) {
+        if constexpr (kCanCkpt) {
+          if (ckpt) w.template merge_and_restore<true>(X, Uc, Un, accepted);
+          else w.merge_and_restore(X, Uc, Un, accepted);
+        } else {
+          w.merge_and_restore(X, Uc, Un, accepted);
+        }
+      }
+    } else {
+      if (accepted) {
+        T* tp = Uc; Uc = Un; Un = tp;
+      }
+      if (__any(a.defer ? accepted : !accepted)) w.restore_states(X, Uc);
+    }
+    if (accepted) {  // control/iterative_ilqr.py:74-80
+      lamb /= c.lamb_factor;
+      const bool conv = t_abs((cost_new - cost) / cost) < c.eps;
+      cost_ret = cost_new;
+      // next iteration's nominal cost: stage terms are measured to xtarget, not x_terminal
+      cost = HASQR ? w.nominal_cost(X, Uc, xT) : cost_new;
+      if (conv) {
+        if (a.early_exit) { status = 1; break; }
+        if (status == 0) status = 1;
+      }
+    } else {  // control/iterative_ilqr.py:81-84
+      lamb *= c.lamb_factor;
+      cost_ret = cost;
+      if (lamb > c.max_lamb) {
+        if (a.early_exit) { status = 3; break; }
+        if (status == 0) status = 3;
+      }
+    }
+#ifdef I2LQR_STAMPS
+    {
+      auto& st_t0 = w.st_t0; auto& st_t1 = w.st_t1; auto& st_acc = w.st_acc;
+      STAMP_END(5);
+    }
+#endif
+  }
+  ctl[64] = 0;  // release the helper
+  __syncthreads();
   // a chunk that ran out before the problem terminated: RUNNING unless the iteration cap is hit
   if (a.early_exit && status == 2 && it0 + it < a.max_total) status = 0;
   if (!t_isfinite(cost_ret) && (status != 0 || !a.early_exit)) status = 4;

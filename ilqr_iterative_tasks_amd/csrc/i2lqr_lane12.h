@@ -33,6 +33,21 @@ namespace i2lqr {
       const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
       const REAL*, const REAL*, REAL*, REAL*, REAL*);
 
+// k_lane_iterate_pair (the bicycles' lane kernel with a helper wavefront, fp64): compiled in
+// i2lqr_lanepair.hip
+#define I2LQR_LANEPAIR_KERNELS(DECL)                                                              \
+  DECL void k_lane_iterate_pair<double, Bicycle4<double>, false>(const DevCfg<double, 4, 2>,      \
+                                                                 const LaneArgs<double>);         \
+  DECL void k_lane_iterate_pair<double, Bicycle4<double>, true>(const DevCfg<double, 4, 2>,       \
+                                                                const LaneArgs<double>);          \
+  DECL void k_lane_iterate_pair<double, Bicycle6<double>, false>(const DevCfg<double, 6, 2>,      \
+                                                                 const LaneArgs<double>);         \
+  DECL void k_lane_iterate_pair<double, Bicycle6<double>, true>(const DevCfg<double, 6, 2>,       \
+                                                                const LaneArgs<double>);
+#ifndef I2LQR_LANEPAIR_DEFINE
+I2LQR_LANEPAIR_KERNELS(extern template __global__)
+#endif
+
 #ifndef I2LQR_LANE12_DEFINE
 I2LQR_LANE12_KERNELS(extern template __global__)
 #endif

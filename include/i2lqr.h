@@ -218,6 +218,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     settle an accept / reject tie the other way and stop at a different
  *                     iteration).  0: off; automatic: 12288 with the speculative kernel, 2048 with
  *                     the one-problem-per-wavefront kernel.
+ *   "helper_wavefront"  (fp64 bicycles, Q = R = 0) 1: workgroups of TWO wavefronts — a helper forms
+ *                     the part of every backward step that depends on the nominal trajectory only
+ *                     (loads, sin / cos, Jacobian entries, barrier exponentials, obstacle term: 30 %
+ *                     of an iteration) a step ahead of the main wavefront, on a SIMD the launch
+ *                     leaves idle; bit-identical.  Automatic: up to 512 workgroups (32768 problems):
+ *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M.  0: one wavefront.
  *   "first_chunk", "chunk_step"  chunked solve only: length of the first chunk (automatic: 8) and
  *                     of the one behind it (automatic: 4) — hand-tuned schedules, there to measure
  *                     the automatic one against (tools/solve_bench.py).  Same results either way.

@@ -109,10 +109,10 @@ def test_recommended_layout_is_a_host_call_and_no_caller_holds_a_threshold():
     lib = _abi.load_library()
     ask = lambda cfg, B, ee=0: lib.i2lqr_recommended_layout(C.byref(cfg), B, ee)
     b6 = _abi.default_config("bicycle6", 20)
-    assert [ask(b6, B) for B in (1, 1024, 4096, 12288)] == [0, 0, 0, 0]
-    assert [ask(b6, B) for B in (12352, 65536, 1 << 20)] == [2, 2, 2]      # multiples of 64: tiled
-    assert ask(b6, 12289) == 1 and ask(b6, 65537) == 1                      # ragged: batch-minor
-    assert ask(b6, 12288, 1) == 0 and ask(b6, 12352, 1) == 2                # solves: the same crossover
+    assert [ask(b6, B) for B in (1, 1024, 4096, 8192)] == [0, 0, 0, 0]
+    assert [ask(b6, B) for B in (8256, 65536, 1 << 20)] == [2, 2, 2]       # multiples of 64: tiled
+    assert ask(b6, 8193) == 1 and ask(b6, 65537) == 1                       # ragged: batch-minor
+    assert ask(b6, 10240, 1) == 0 and ask(b6, 10304, 1) == 2                # solves: their own crossover
     q = _abi.default_config("quad12", 50)                                   # quad12: its own measured table
     assert [ask(q, B) for B in (64, 4096, 4160, 8192, 65536)] == [0, 0, 2, 2, 2]
     assert [ask(q, B, 1) for B in (4160, 6144, 6208)] == [0, 0, 2]          # solves stay problem-major longer

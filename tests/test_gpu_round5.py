@@ -341,3 +341,35 @@ def test_quad12_fp32_on_the_lane_layouts_tracks_the_fp64_oracle(torch_mod, layou
     assert set(np.unique(st)) <= {1, 2, 3} and int(so["iters"].min()) >= 1
     ref_so = orc.ilqr_batch(cfg64, host["X"], host["U"], host["x_term"], host["lamb"], host["obs"])
     assert (st == ref_so["status"]).mean() >= 0.9
+
+
+@pytest.mark.parametrize("system,N,dt,layout,B", [("bicycle6", 20, 0.25, 2, 16384), ("bicycle6", 20, 0.25, 1, 1000),
+                                                ("bicycle4", 6, 1.0, 2, 64), ("bicycle4", 50, 0.25, 1, 777)])
+def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout, B):
+    """k_lane_iterate_pair (round 5): workgroups of two wavefronts, the helper forming
+    every backward step's trajectory-dependent half a step ahead of the main wavefront.  The record
+    travels through LDS unchanged, so fused iterations (with gains), the solve to termination
+    (ragged exits: lanes leave the loop at different iterations while the pair keeps its barrier
+    protocol) and the chunked solve equal the one-wavefront kernel bit for bit; automatic up to
+    32768 problems."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    cfg = default_config(system, N, "f64", dt=dt, layout=layout)
+    host = workloads.make_batch(cfg, B)
+    host["lamb"] = 10.0 ** np.random.default_rng(3).integers(-3, 3, B).astype(float)
+    outs = {}
+    for hw in (0, -1):
+        s = BatchedILQR(cfg)
+        s.set_option("helper_wavefront", hw)
+        assert s.iterate_kernel(B) == ("k_lane_iterate" if hw == 0 else "k_lane_iterate_pair")
+        it = s.iterate(dev_batch(s, host), 7)
+        so = s.solve(dev_batch(s, host))
+        torch.cuda.synchronize()
+        outs[hw] = (it, so)
+    for a, b in zip(outs[0], outs[-1]):
+        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+            assert torch.equal(a[key], b[key]), key
+    big = BatchedILQR(cfg)
+    assert big.iterate_kernel(65536) == "k_lane_iterate" and big.iterate_kernel(32768) == "k_lane_iterate_pair"
+    f32 = BatchedILQR(default_config(system, N, "f32", dt=dt, layout=layout))
+    assert f32.iterate_kernel(B) == "k_lane_iterate"  # fp64 only
