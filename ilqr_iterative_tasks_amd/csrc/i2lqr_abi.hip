@@ -123,6 +123,7 @@ struct i2lqr_handle {
   int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt, opt_stagger;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
   int opt_pair;  // bicycles' lane kernel, fp64: workgroups of two wavefronts (main + helper); -1 = automatic
+  int opt_two_x;  // ... its second state buffer (no re-roll of accepted steps); -1 = automatic
   int opt_chunk_step;  // chunked solve: length of the chunk that follows the first (automatic: 4); a schedule to measure against
   int opt_first_chunk;  // chunked solve: pinned length of the first chunk, no extension chunks (a hand-tuned schedule to measure the data-driven one against); -1 = automatic
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
@@ -503,6 +504,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.wsU = p; p += B * (int64_t)(m * N);
     a.wsK = p; p += B * (int64_t)(m * n * N);
     a.wsk = p; p += B * (int64_t)(m * N);
+    // second state buffer of the helper-wavefront form: the states of the first compacted work
+    // set, which no launch uses while a kernel iterates on other arrays (solve_compacting() hands
+    // every chunk the states of the work set it does NOT run on)
+    a.wsX = h->opt_two_x != 0 && grid(B) <= (h->opt_two_x == 1 ? kPairMaxGrid : kTwoXMaxGrid) ? p
+                                                                                               : nullptr;
     a.count = nullptr;
     a.resume = 0;
     a.max_total = 0x7fffffff;
@@ -594,6 +600,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
   // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
   static constexpr unsigned kPairMaxGrid = 512;
+  static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU
   static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
     if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
       if (c.flags || a.ckpt || opt_pair == 0) return false;
@@ -759,6 +766,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       a.K = nullptr; a.k = nullptr;  // gains of work sets go to the scratch buffer (w.K == wsK)
       a.iters = w.iters; a.status = w.status;
       a.count = count; a.resume = 1; a.n_iters = len;
+      if (a.wsX) a.wsX = cv.set[cur ^ 1].X;  // (consumed by the compaction in front of this chunk)
       launch_iterate<false>(c, a, B, s, h->opt_pair);
       done += len;
       src = w;
@@ -1216,6 +1224,7 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->opt_first_chunk = -1;
   h->opt_chunk_step = -1;
   h->opt_pair = -1;
+  h->opt_two_x = -1;
   h->ticket = nullptr;
   h->ticket_next.store(0);
   constexpr size_t kTicketBytes = i2lqr_handle::kTickets * sizeof(unsigned);
@@ -1396,6 +1405,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "wave_tail")) h->wave_tail = v < 0 ? -1 : (v > 65536 ? 65536 : v);
   else if (!strcmp(name, "first_chunk")) h->opt_first_chunk = v < 1 ? -1 : (v > 1024 ? 1024 : v);
   else if (!strcmp(name, "helper_wavefront")) h->opt_pair = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "state_buffers")) h->opt_two_x = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "chunk_step")) h->opt_chunk_step = v < 1 ? -1 : (v > 1024 ? 1024 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);

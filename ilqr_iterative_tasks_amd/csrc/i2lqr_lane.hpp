@@ -57,6 +57,7 @@ template <class T> struct LaneArgs {
   int32_t* iters; int32_t* status;
   // workspace (batch-minor): candidate inputs, gains if K == null
   T* wsU; T* wsK; T* wsk;
+  T* wsX;  // second state buffer (k_lane_iterate_pair; launches of <= 256 workgroups), or null
   // chunked solve (solve_compacting): the live batch size is read from device memory, the
   // iteration counter continues from iters[b], and a problem that is still running when the
   // chunk ends gets status RUNNING unless it has reached max_total iterations
@@ -78,6 +79,17 @@ template <class T> struct LaneArgs {
 // there.  X traffic per iteration drops from n (N+1) read + n N written to a quarter of that, for
 // one more plant step per horizon step; the caller's X is completed by one full re-roll at exit.
 constexpr int kSeg = 4;
+
+// Barrier of a main / helper pair of wavefronts (k_lane_iterate_pair) that orders their LDS traffic
+// ONLY.  __syncthreads() is a workgroup-scope release + acquire on every address space: its
+// s_waitcnt vmcnt(0) would drain the main wavefront's gain stores to HBM — and the helper's
+// prefetch loads — at every horizon step.  What the two wavefronts exchange lives in LDS: the LDS
+// operations of a wavefront complete in order, lgkmcnt(0) lands them, s_barrier makes the other
+// wavefront wait for that point.
+__device__ __forceinline__ void pair_barrier() {
+  static_assert(kGfx9Waitcnt, "s_waitcnt literal below is the gfx9 field layout");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // words of T the workspace needs for B problems
 template <class Sys> __host__ __device__ inline int64_t lane_workspace_words(int N, int64_t B) {
@@ -112,6 +124,11 @@ template <bool TILED> struct LaneView {
 #endif
 #ifndef I2LQR_WARM_INPUTS
 #define I2LQR_WARM_INPUTS 1  // k_lane_iterate_rows: LDS-direct warm-up loads of the next step's inputs
+#endif
+#ifndef I2LQR_PAIR_FWD_DEPTH
+// k_lane_iterate_pair: prefetch distance of the forward pass in horizon steps (tools/ab_bench.py at
+// 16384 problems, fp64: 1: 357, 2: 374, 3: 374, 4: 369 M it/s; the register sets of 3 and 4 spill)
+#define I2LQR_PAIR_FWD_DEPTH 2
 #endif
 #ifndef I2LQR_DEEP64
 #define I2LQR_DEEP64 0  // experiment: the two-step prefetch distance of the fp32 kernels in fp64 too
@@ -737,11 +754,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           r[(NV + 5 + a) * 64] = lu[a];
           r[(NV + 5 + m + a) * 64] = luu[a];
         }
-        __syncthreads();
+        pair_barrier();
         return;
       }
       if constexpr (ROLE == 1) {  // the main wavefront's step starts here: the helper's record
-        __syncthreads();
+        pair_barrier();
         const lds_t* const r = rec + (size_t)(t & 1) * kRec * 64 + (threadIdx.x & 63);
 #pragma unroll
         for (int q = 0; q < NV; q++) jv[q] = r[q * 64];
@@ -1397,11 +1414,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // per horizon step.  Pays where the kernel sits on the HBM roof (fp64).
   // WRITEX = false: the candidate states are not stored at all (the nominal ones stay intact); the
   // caller re-rolls them from the candidate inputs if the step is accepted (restore_states()).
-  template <bool REROLL, bool WRITEX = true>
+  // D: horizon steps between the loads of a step's inputs and their use (D register sets that take
+  // turns).  A step is ~700 cycles of arithmetic and a load from HBM / the far L2 takes 1500-2000:
+  // with D = 1 the pass runs at the memory latency, not at the issue rate.
+  template <bool REROLL, bool WRITEX = true, int D = (DEEP ? 2 : 1)>
   __device__ __forceinline__ T forward(const T* X, const T* U, const T* gK, const T* gk, T* Xn,
                                        T* Un, const T (&xT)[n]) const {
     T x[n], u[m], xn[n], tr[NT];
-    T xo[n], uo[m], kk[m][n + 1];
+    T xo[n];
 #pragma unroll
     for (int i = 0; i < n; i++) {
       x[i] = at(X, rx(i, 0));
@@ -1411,9 +1431,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     T cost = T(0);
     // The nominal state / input / gains of a step are consumed at its very start (the feedback
     // law); the loads for step t+D are issued right after, into the same registers, so the HBM
-    // latency hides under the rest of the serial step(s).  D = 2 with two register sets that take
-    // turns (DEEP, fp32), else 1.
-    constexpr int D = DEEP ? 2 : 1;
+    // latency hides under the rest of the serial step(s).
     auto load_step = [&](int t, T (&xl)[n], T (&ul)[m], T (&kl)[m][n + 1])
         __attribute__((always_inline)) {
       if constexpr (!REROLL) {
@@ -1478,21 +1496,23 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
 #pragma unroll
       for (int i = 0; i < n; i++) x[i] = xn[i];
     };
-    T xl0[n];
+    T xl[D][n], ul[D][m], kl[D][m][n + 1];
 #pragma unroll
-    for (int i = 0; i < n; i++) xl0[i] = xo[i];
-    load_step(0, xl0, uo, kk);
-    if constexpr (DEEP) {
-      T xl1[n], uo1[m], kk1[m][n + 1];
-      if (N >= 2) load_step(1, xl1, uo1, kk1);
+    for (int i = 0; i < n; i++) xl[0][i] = xo[i];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (d < N) load_step(d, xl[d], ul[d], kl[d]);
+    if constexpr (D > 1) {
       int t = 0;
-      for (; t + 1 < N; t += 2) {
-        body(t, xl0, uo, kk);
-        body(t + 1, xl1, uo1, kk1);
+      for (; t + D <= N; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) body(t + d, xl[d], ul[d], kl[d]);
       }
-      if (t < N) body(t, xl0, uo, kk);
+#pragma unroll
+      for (int d = 0; d < D - 1; d++)
+        if (t + d < N) body(t + d, xl[d], ul[d], kl[d]);
     } else {
-      for (int t = 0; t < N; t++) body(t, xl0, uo, kk);
+      for (int t = 0; t < N; t++) body(t, xl[0], ul[0], kl[0]);
     }
     cost = cost + terminal_cost(x, xT);
     return cost;
@@ -1832,9 +1852,18 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   // accepted steps re-roll them (a.defer), or it writes the candidate states over the nominal
   // ones in place (each x_t is loaded one step ahead of being overwritten) and rejected steps
   // re-roll the nominal ones; both re-rolls are bit-identical to what the rollout stored.
-  T* const X = v.rebase(a.X, n * (N + 1));
+  // THIS kernel runs launches of at most 512 workgroups, bound by the instruction stream of a step
+  // and not by HBM: with a second state buffer in the workspace (a.wsX; the host passes one up to
+  // 256 workgroups) the forward pass stores the candidate states there and an accepted lane swaps
+  // its state and input buffers — no re-roll (15 % of an iteration of the main wavefront at 16384
+  // problems against +6 % for the stores and the per-lane addresses, tools/stamp_run_lane.py;
+  // +3.5 % it/s at 8192 problems, +4 % at 12288 and 16384, +1 % at 20480, 0 at 24576, -3 % at
+  // 32768 where two workgroups share a CU's path to memory).
+  T* const X0 = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
+  const bool two = a.wsX != nullptr;
+  T *X = X0, *Xn = two ? v.rebase(a.wsX, n * (N + 1)) : X0;
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
   // iteration i (same inputs, same code), and unchanged after a rejected one: roll out once.
@@ -1849,14 +1878,13 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   if (role == 1) {
     // helper: its half of every backward pass the main wavefront announces (same lanes, same
     // problems; it never touches the gains, the candidate or the accept / reject state)
-    const T* const Xh = v.rebase(a.X, n * (N + 1));
-    const T* const Uh0 = v.rebase(a.U, m * N);
     const T* const Uh1 = v.rebase(a.wsU, m * N);
     for (;;) {
       __syncthreads();  // B0: the control words of this pass are written
       if (!ctl[64]) return;
-      w.template backward<true, false, 2>(Xh, ctl[l64] ? Uh1 : Uh0, xT, ob, lamb, nullptr, nullptr,
-                                          false);
+      const int sel = ctl[l64];  // bit 0: inputs in the workspace, bit 1: states in the workspace
+      w.template backward<true, false, 2>((sel & 2) ? Xn : X0, (sel & 1) ? Uh1 : U0, xT, ob, lamb,
+                                          nullptr, nullptr, false);
     }
   }
   if (a.stagger > 0 && ((blockIdx.x >> 9) & 1)) {  // see k_lane_iterate_rows
@@ -1869,7 +1897,7 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   while (it < a.n_iters && it0 + it < a.max_total) {
     // K_0 goes to HBM from the passes that can be this launch's last one for the problem
     const bool k0_out = a.early_exit || it + 1 >= a.n_iters || it0 + it + 1 >= a.max_total;
-    ctl[l64] = Uc != U0;  // which input buffer holds this lane's nominal inputs
+    ctl[l64] = (Uc != U0 ? 1 : 0) | (X != X0 ? 2 : 0);  // where this lane's nominal trajectory is
     ctl[64] = 1;
     __syncthreads();  // B0
     w.template backward<true, false, 1>(X, Uc, xT, ob, lamb, gK, gk, k0_out);
@@ -1880,12 +1908,16 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
     }
 #endif
     T cost_new;
-    if (a.defer) {
-      cost_new = a.reroll ? w.template forward<true, false>(X, Uc, gK, gk, X, Un, xT)
-                          : w.template forward<false, false>(X, Uc, gK, gk, X, Un, xT);
+    constexpr int FD = I2LQR_PAIR_FWD_DEPTH;
+    if (two) {
+      cost_new = a.reroll ? w.template forward<true, true, FD>(X, Uc, gK, gk, Xn, Un, xT)
+                          : w.template forward<false, true, FD>(X, Uc, gK, gk, Xn, Un, xT);
+    } else if (a.defer) {
+      cost_new = a.reroll ? w.template forward<true, false, FD>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false, false, FD>(X, Uc, gK, gk, X, Un, xT);
     } else {
-      cost_new = a.reroll ? w.template forward<true>(X, Uc, gK, gk, X, Un, xT)
-                          : w.template forward<false>(X, Uc, gK, gk, X, Un, xT);
+      cost_new = a.reroll ? w.template forward<true, true, FD>(X, Uc, gK, gk, X, Un, xT)
+                          : w.template forward<false, true, FD>(X, Uc, gK, gk, X, Un, xT);
     }
 #ifdef I2LQR_STAMPS
     {
@@ -1899,7 +1931,12 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
     // that accepted, in-place mode to the lanes that rejected.  If any lane of the wavefront needs
     // it, ALL of them re-roll and store (the others rewrite what is already there, bit for bit):
     // full 64-lane rows instead of masked partial ones, which cost a read-modify-write in HBM.
-    if (a.defer && a.merge) {
+    if (two) {
+      if (accepted) {
+        T* tp = Uc; Uc = Un; Un = tp;
+        tp = X; X = Xn; Xn = tp;
+      }
+    } else if (a.defer && a.merge) {
       // the current inputs stay in ONE buffer for the whole wavefront: accepted candidates are
       // merged into it during the re-roll (Uc == U0, Un == workspace throughout)
       if (__all(accepted)) {
@@ -1964,9 +2001,21 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
     if (ckpt) w.restore_states(X, Uc);  // the caller's X in full: one re-roll per launch
   }
   w.flush_gains(gK, gk);
-  if (Uc != U0) {  // the accepted inputs sit in the workspace: copy them out
-    for (int e = 0; e < m * N; e++) U0[(int64_t)e * v.Bs + v.bl] = Uc[(int64_t)e * v.Bs + v.bl];
-  }
+  // the accepted trajectory sits in the workspace: copy it out, 32 rows in flight at a time (one
+  // row per round trip to HBM was 44 us of a 0.46 ms launch)
+  auto copy_out = [&](T* dst, const T* src, const int rows) __attribute__((always_inline)) {
+    for (int e0 = 0; e0 < rows; e0 += 32) {
+      T tmp[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++)
+        if (e0 + j < rows) tmp[j] = src[(int64_t)(e0 + j) * v.Bs + v.bl];
+#pragma unroll
+      for (int j = 0; j < 32; j++)
+        if (e0 + j < rows) dst[(int64_t)(e0 + j) * v.Bs + v.bl] = tmp[j];
+    }
+  };
+  if (Uc != U0) copy_out(U0, Uc, m * N);
+  if (X != X0) copy_out(X0, X, n * (N + 1));
   a.lamb[b] = lamb;
   a.cost[b] = cost_ret;
   if (a.iters) a.iters[b] = it0 + it;

@@ -224,6 +224,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     of an iteration) a step ahead of the main wavefront, on a SIMD the launch
  *                     leaves idle; bit-identical.  Automatic: up to 512 workgroups (32768 problems):
  *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M.  0: one wavefront.
+ *   "state_buffers"   (the helper-wavefront form) 1: the forward pass stores the candidate states
+ *                     in a second state buffer of the workspace and an accepted problem swaps its
+ *                     buffers, instead of storing no candidate states and re-rolling the accepted
+ *                     ones (what the launches that sit on the HBM roof do); bit-identical.
+ *                     Automatic: up to 256 workgroups (16384 problems: 360 -> 374 M it/s; 32768:
+ *                     -3 %, two workgroups share a CU's path to memory).  0: off.
  *   "first_chunk", "chunk_step"  chunked solve only: length of the first chunk (automatic: 8) and
  *                     of the one behind it (automatic: 4) — hand-tuned schedules, there to measure
  *                     the automatic one against (tools/solve_bench.py).  Same results either way.

@@ -351,24 +351,28 @@ def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout
     travels through LDS unchanged, so fused iterations (with gains), the solve to termination
     (ragged exits: lanes leave the loop at different iterations while the pair keeps its barrier
     protocol) and the chunked solve equal the one-wavefront kernel bit for bit; automatic up to
-    32768 problems."""
+    32768 problems.  Its second state buffer ("state_buffers": the forward pass stores the candidate
+    states beside the nominal ones, an accepted lane swaps buffers instead of re-rolling) writes the
+    states the re-roll would have recomputed from the same inputs with the same code: same bits."""
     torch = torch_mod
     from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
     cfg = default_config(system, N, "f64", dt=dt, layout=layout)
     host = workloads.make_batch(cfg, B)
     host["lamb"] = 10.0 ** np.random.default_rng(3).integers(-3, 3, B).astype(float)
     outs = {}
-    for hw in (0, -1):
+    for hw, sb in ((0, -1), (-1, 0), (-1, 1), (-1, -1)):
         s = BatchedILQR(cfg)
         s.set_option("helper_wavefront", hw)
+        s.set_option("state_buffers", sb)
         assert s.iterate_kernel(B) == ("k_lane_iterate" if hw == 0 else "k_lane_iterate_pair")
         it = s.iterate(dev_batch(s, host), 7)
         so = s.solve(dev_batch(s, host))
         torch.cuda.synchronize()
-        outs[hw] = (it, so)
-    for a, b in zip(outs[0], outs[-1]):
-        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
-            assert torch.equal(a[key], b[key]), key
+        outs[hw, sb] = (it, so)
+    for other in ((-1, 0), (-1, 1), (-1, -1)):
+        for a, b in zip(outs[0, -1], outs[other]):
+            for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+                assert torch.equal(a[key], b[key]), (other, key)
     big = BatchedILQR(cfg)
     assert big.iterate_kernel(65536) == "k_lane_iterate" and big.iterate_kernel(32768) == "k_lane_iterate_pair"
     f32 = BatchedILQR(default_config(system, N, "f32", dt=dt, layout=layout))
