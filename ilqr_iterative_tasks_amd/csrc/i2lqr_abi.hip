@@ -507,8 +507,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // second state buffer of the helper-wavefront form: the states of the first compacted work
     // set, which no launch uses while a kernel iterates on other arrays (solve_compacting() hands
     // every chunk the states of the work set it does NOT run on)
-    a.wsX = h->opt_two_x != 0 && grid(B) <= (h->opt_two_x == 1 ? kPairMaxGrid : kTwoXMaxGrid) ? p
-                                                                                               : nullptr;
+    a.wsX = h->opt_two_x != 0 ? p : nullptr;
+    a.two_max = 64 * (int)(h->opt_two_x == 1 ? kPairMaxGrid : kTwoXMaxGrid);
+    a.count_lo = -1;
+    a.count_hi = 0x7fffffff;
     a.count = nullptr;
     a.resume = 0;
     a.max_total = 0x7fffffff;
@@ -601,26 +603,32 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
   static constexpr unsigned kPairMaxGrid = 512;
   static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU
-  static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
-    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
-      if (c.flags || a.ckpt || opt_pair == 0) return false;
-      return opt_pair == 1 ? true : grid(B) <= kPairMaxGrid;
-    }
+  static bool pair_built(const Cfg& c, const LaneArgs<T>& a, int opt_pair) {
+    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) return !c.flags && !a.ckpt && opt_pair != 0;
     return false;
+  }
+  static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
+    return pair_built(c, a, opt_pair) && (opt_pair == 1 || grid(B) <= kPairMaxGrid);
+  }
+  static size_t lane_lds(const LaneArgs<T>& a) {
+    return (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes + (a.ckpt ? kSegBytes : 0);
+  }
+  template <bool TL>
+  static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
+    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
+      using LW = LaneWorker<T, Sys, false, TL>;
+      const size_t lds_pair = lane_lds(a) + 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
+      hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128), lds_pair, s,
+                         c, a);
+    }
   }
   template <bool TL>
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s,
                              int opt_pair = 0) {
-    const size_t lds = (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes +
-                       (a.ckpt ? kSegBytes : 0);
-    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
-      if (use_pair(c, a, B, opt_pair)) {
-        using LW = LaneWorker<T, Sys, false, TL>;
-        const size_t lds_pair = lds + 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
-        hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(grid(B)), dim3(128), lds_pair, s,
-                           c, a);
-        return;
-      }
+    const size_t lds = lane_lds(a);
+    if (use_pair(c, a, B, opt_pair)) {
+      launch_pair<TL>(c, a, grid(B), s);
+      return;
     }
     if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
       bool launched = false;
@@ -767,7 +775,23 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       a.iters = w.iters; a.status = w.status;
       a.count = count; a.resume = 1; a.n_iters = len;
       if (a.wsX) a.wsX = cv.set[cur ^ 1].X;  // (consumed by the compaction in front of this chunk)
-      launch_iterate<false>(c, a, B, s, h->opt_pair);
+      // a batch too large for the helper-wavefront form as a whole: its survivors may not be.
+      // Both kernels are enqueued and the live count decides on the device which one runs (the
+      // other is an empty launch, ~3 us): 21000 survivors of 65536 problems iterate at 46
+      // instead of 67 us per iteration.  The pair's chunk takes the options of a launch of its
+      // size (no state checkpoints, no merge, no re-rolling forward pass: all bit-identical).
+      LaneArgs<T> ap = a;
+      ap.ckpt = 0;
+      ap.merge = h->opt_merge >= 0 ? h->opt_merge : 0;
+      ap.reroll = h->opt_reroll >= 0 ? h->opt_reroll : 0;
+      if (pair_built(c, ap, h->opt_pair) && h->opt_pair < 0 && grid(B) > kPairMaxGrid) {
+        ap.count_hi = 64 * (int)kPairMaxGrid;
+        launch_pair<false>(c, ap, kPairMaxGrid, s);
+        a.count_lo = ap.count_hi;
+        launch_iterate<false>(c, a, B, s, 0);
+      } else {
+        launch_iterate<false>(c, a, B, s, h->opt_pair);
+      }
       done += len;
       src = w;
       src_user = false;

@@ -63,6 +63,10 @@ template <class T> struct LaneArgs {
   // chunk ends gets status RUNNING unless it has reached max_total iterations
   const int32_t* count;
   int resume, max_total;
+  // chunks the DEVICE chooses between (two kernels enqueued, one of them runs): the launch is a
+  // no-op unless count_lo < *count <= count_hi
+  int count_lo, count_hi;
+  int two_max;  // k_lane_iterate_pair: the second state buffer is used up to this many live problems
   unsigned long long* dbg;  // diagnostic builds only: [B/64][8] phase cycle sums
   int defer;      // forward pass stores no states; an accepted step re-rolls them
   int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
@@ -1659,6 +1663,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
+  if (a.count && (live <= a.count_lo || live > a.count_hi)) return;  // the other kernel's chunk
   if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
   const int N = c.N;
   const LaneView<TILED> v(a.B);
@@ -1826,6 +1831,7 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   const int64_t b = (int64_t)blockIdx.x * 64 + l64;
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
+  if (a.count && (live <= a.count_lo || live > a.count_hi)) return;  // the other kernel's chunk
   if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
   const int N = c.N;
   const LaneView<TILED> v(a.B);
@@ -1862,7 +1868,7 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   T* const X0 = v.rebase(a.X, n * (N + 1));
   T* const U0 = v.rebase(a.U, m * N);
   T *Uc = U0, *Un = v.rebase(a.wsU, m * N);
-  const bool two = a.wsX != nullptr;
+  const bool two = a.wsX != nullptr && live <= a.two_max;
   T *X = X0, *Xn = two ? v.rebase(a.wsX, n * (N + 1)) : X0;
 
   // The nominal rollout of iteration i+1 is bit-identical to the forward rollout of an accepted
