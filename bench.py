@@ -228,7 +228,7 @@ def accepted_fraction(lamb, lamb0, iters, factor):
     return float((acc / iters).mean())
 
 
-def make_step_buffers(solver, host, n_sets, torch):
+def make_step_buffers(solver, host, n_sets, torch, want_gains=True):
     """n_sets independent copies of the in/out state (X, U, lamb) + shared read-only inputs and
     shared outputs, all resident in HBM before the timed region starts."""
     dev, dt = solver.device, solver.dtype
@@ -238,8 +238,8 @@ def make_step_buffers(solver, host, n_sets, torch):
         x_term=native(host["x_term"]),
         obs=native(host["obs"]),
         cost=torch.zeros(B, dtype=dt, device=dev),
-        K=torch.zeros(solver.shape("K", B), dtype=dt, device=dev),
-        k=torch.zeros(solver.shape("k", B), dtype=dt, device=dev),
+        K=torch.zeros(solver.shape("K", B), dtype=dt, device=dev) if want_gains else None,
+        k=torch.zeros(solver.shape("k", B), dtype=dt, device=dev) if want_gains else None,
         iters=torch.zeros(B, dtype=torch.int32, device=dev),
         status=torch.zeros(B, dtype=torch.int32, device=dev),
     )
@@ -597,7 +597,11 @@ def roofline_entry(cfg, B, iters, r, traffic):
     return out
 
 
-def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
+def run_solve(args, cfg, B, torch, reps=3, single_launch=False, want_gains=False):
+    """One solve to termination per rep, each on its own copy of the batch.  Outputs = what the
+    reference's ilqr() returns (uvar, xvar, lamb: control/iterative_ilqr.py:85) plus cost, iteration
+    count and status per problem; the gains of the last backward pass are an extra of this library
+    (want_gains: +0.05-0.09 ms at 65536 problems for their scatter to the caller's arrays)."""
     from ilqr_iterative_tasks_amd import BatchedILQR, workloads
     cfg = cfg.copy()
     layout = pick_layout(args, B, solve=True, cfg=cfg)
@@ -606,7 +610,7 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
     if single_launch:
         solver.set_compaction(0)
     host = workloads.make_batch(cfg, B)
-    sets = make_step_buffers(solver, host, reps + 1, torch)
+    sets = make_step_buffers(solver, host, reps + 1, torch, want_gains=want_gains)
     solver.solve(sets[0])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -623,7 +627,8 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False):
         kernel += " chunks + k_lane_compact + k_group_spec tail"
     solver.close()
     return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
-            "iterations_mean": executed / B, "iterations_max": int(it.max()), "kernel": kernel}
+            "iterations_mean": executed / B, "iterations_max": int(it.max()), "kernel": kernel,
+            "outputs": "U, X, lamb, cost, iters, status" + (", K, k" if want_gains else "")}
 
 
 def lib_sha256():
@@ -984,6 +989,9 @@ def run_rank(args) -> int:
         # 65536 problems against the fixed-count rate of the same batch; where the solve's time
         # goes by kernel comes from the kernel trace under profiles/ (same library only)
         rs = run_solve(args, workloads.config_for(args.workload, "f64"), 65536, torch, reps=5)
+        rs["ms_per_solve_with_gains_out"] = run_solve(
+            args, workloads.config_for(args.workload, "f64"), 65536, torch, reps=5,
+            want_gains=True)["ms_per_solve"]
         fixed = out["roofline_large_batch"]["B65536"]["iterations_per_s"]
         rs.update({"batch": 65536, "dtype": "f64", "fixed_count_iterations_per_s": fixed,
                    "frac_of_fixed_count_rate": rs["executed_iterations_per_s"] / fixed,

@@ -223,7 +223,10 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     (loads, sin / cos, Jacobian entries, barrier exponentials, obstacle term: 30 %
  *                     of an iteration) a step ahead of the main wavefront, on a SIMD the launch
  *                     leaves idle; bit-identical.  Automatic: up to 512 workgroups (32768 problems):
- *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M.  0: one wavefront.
+ *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M.  In the chunked solve
+ *                     of a larger batch every lane chunk behind the first is enqueued in both forms
+ *                     and the live count picks one on the device (<= 32768 survivors: this one).
+ *                     0: one wavefront everywhere.
  *   "state_buffers"   (the helper-wavefront form) 1: the forward pass stores the candidate states
  *                     in a second state buffer of the workspace and an accepted problem swaps its
  *                     buffers, instead of storing no candidate states and re-rolling the accepted

@@ -31,7 +31,9 @@ host = workloads.make_batch(cfg, args.batch)
 dev = lambda a: solver.to_native(torch.as_tensor(a).to(solver.device, solver.dtype))
 bufs = []
 for _ in range(args.launches):
-    buf = solver.alloc(args.batch)
+    # a solve returns what the reference's ilqr() returns (U, X, lamb) + cost / iters / status;
+    # the fixed-count launches also write the gains of their last backward pass
+    buf = solver.alloc(args.batch, want_gains=not args.solve)
     for key in ("X", "U", "x_term", "lamb"):
         buf[key].copy_(dev(host[key]))
     buf["obs"] = dev(host["obs"])

@@ -67,7 +67,9 @@ for d in sorted(glob.glob(f"{raw}/*_kstats")):
         tot = sum(fam.values())
         if tot:
             rec = {"kernels_ms_per_solve": tot / launches / 1e6,
-                   "kernel_time_shares": {k: v / tot for k, v in sorted(fam.items())}}
+                   "kernel_time_shares": {k: v / tot for k, v in sorted(fam.items())},
+                   "outputs": "U, X, lamb, cost, iters, status (no gains: what the reference's "
+                              "ilqr() returns)"}
             out[f"solve:f64:B{B}"] = rec
             full[f"solve:f64:B{B}"] = rec
             print(f"solve:f64:B{B}", json.dumps(rec))
