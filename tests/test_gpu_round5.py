@@ -377,3 +377,30 @@ def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout
     assert big.iterate_kernel(65536) == "k_lane_iterate" and big.iterate_kernel(32768) == "k_lane_iterate_pair"
     f32 = BatchedILQR(default_config(system, N, "f32", dt=dt, layout=layout))
     assert f32.iterate_kernel(B) == "k_lane_iterate"  # fp64 only
+
+
+def test_survivor_chunks_of_a_large_solve_pick_their_kernel_on_the_device(torch_mod):
+    """Chunked solve of a batch above 32768 problems: every lane chunk behind the first is enqueued
+    in both forms (k_lane_iterate_pair with count_hi = 32768, k_lane_iterate with count_lo = 32768)
+    and the live count the compaction left picks one on the device.  Whatever runs, the solve equals
+    the one with the helper-wavefront form switched off: iteration counts, statuses and lamb exactly,
+    trajectories bit for bit ("wave_tail" 0: the speculative tail sums in another order and is
+    compared at the solve tolerance elsewhere)."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+    cfg = default_config("bicycle6", 20, "f64", dt=0.25, layout=2)
+    for B, variant in ((40960, None), (49152, "far_targets")):
+        host = workloads.make_batch(cfg, B, variant=variant)
+        outs = []
+        for hw in (-1, 0):
+            s = BatchedILQR(cfg)
+            s.set_option("helper_wavefront", hw)
+            s.set_option("wave_tail", 0)
+            assert s.iterate_kernel(B) == "k_lane_iterate"  # the batch as a whole: one wavefront
+            so = s.solve(dev_batch(s, host))
+            torch.cuda.synchronize()
+            outs.append(so)
+        for key in ("X", "U", "lamb", "cost", "iters", "status"):
+            assert torch.equal(outs[0][key], outs[1][key]), (B, variant, key)
+        it = outs[0]["iters"]
+        assert int(it.max()) > 12 and int((it > 8).sum()) > 0  # chunks behind the first did run

@@ -55,9 +55,9 @@ def isa(tmp_path_factory):
     if not Path(HIPCC).exists():
         pytest.skip("hipcc not available")
     d = tmp_path_factory.mktemp("isa")
-    with ThreadPoolExecutor(2) as ex:
-        a, b = ex.map(lambda tu: _isa(tu, d), ["i2lqr_lane12", "i2lqr_group"])
-    return {"lane12": a, "group": b}
+    with ThreadPoolExecutor(3) as ex:
+        a, b, c = ex.map(lambda tu: _isa(tu, d), ["i2lqr_lane12", "i2lqr_group", "i2lqr_lanepair"])
+    return {"lane12": a, "group": b, "lanepair": c}
 
 
 def _counts_apply():
@@ -113,6 +113,24 @@ def test_headline_kernel_loops_are_clean(isa):
         assert not [i for i in ins if i.startswith(("global_", "buffer_"))], name  # state stays in LDS
         checked += 1
     assert checked >= 2  # the backward and the forward horizon loops at least
+
+
+def test_helper_wavefront_kernel_hands_its_record_over_in_lds_and_spills_to_registers_only(isa):
+    """k_lane_iterate_pair (round 5): the per-step barrier of the pair orders LDS traffic only
+    (s_waitcnt lgkmcnt(0) + s_barrier from the inline asm: no vmcnt drain in front of it), and the
+    horizon loops of both wavefronts keep their spills in accumulation registers, not in scratch."""
+    text = isa["lanepair"]
+    loops = _loops(text, "_ZN5i2lqr19k_lane_iterate_pairIdNS_8Bicycle6IdEELb1EEE")
+    assert loops
+    hot = {k: v for k, v in loops.items() if sum("f64" in i for i in v) > 100}
+    assert len(hot) >= 4, {k: len(v) for k, v in loops.items()}  # helper, main, forward, re-roll
+    for name, ins in hot.items():
+        assert not [i for i in ins if i.startswith(("scratch_", "flat_"))], name
+    lines = [l.strip() for l in text.split("\n")]
+    bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+    assert bars
+    asm_bars = [i for i in bars if lines[i - 1].startswith("s_waitcnt lgkmcnt(0)")]
+    assert len(asm_bars) >= 2, "the pair's LDS-only barrier is gone from the backward passes"
 
 
 def _lint():
