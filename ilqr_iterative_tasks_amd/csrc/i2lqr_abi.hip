@@ -549,6 +549,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (h->opt_reroll >= 0) a.reroll = h->opt_reroll;
     if (h->opt_defer >= 0) a.defer = h->opt_defer;
     if (h->opt_lds_steps >= 0 && h->opt_lds_steps < a.lds_steps) a.lds_steps = h->opt_lds_steps;
+    a.lds_grow = h->opt_lds_steps < 0 ? 1 : 0;
     finish_options(h, B, a);
     if (!cv) return;
     for (int q = 0; q < 2; q++) {
@@ -613,13 +614,35 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static size_t lane_lds(const LaneArgs<T>& a) {
     return (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes + (a.ckpt ? kSegBytes : 0);
   }
+  // A launch of the helper-wavefront form puts one or two workgroups on a CU, so each has 160 or 80
+  // KiB of LDS to itself where the one-wavefront kernel budgets 36 (four wavefronts per CU): the
+  // gains of that many more horizon steps stay in LDS between the backward and the forward pass
+  // (19 of 20 steps up to 256 workgroups at n = 6, m = 2; 8 up to 512) instead of going through HBM.
+  static constexpr unsigned kCUs = 256;                 // MI355X
+  static constexpr size_t kLdsPerCU = 160 * 1024;       // gfx950
   template <bool TL>
   static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
     if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
       using LW = LaneWorker<T, Sys, false, TL>;
-      const size_t lds_pair = lane_lds(a) + 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
-      hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128), lds_pair, s,
-                         c, a);
+      // more than 64 KiB of dynamic LDS per workgroup has to be asked for once per kernel
+      static const size_t max_dyn =
+          hipFuncSetAttribute((const void*)&k_lane_iterate_pair<T, Sys, TL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU) == hipSuccess
+              ? kLdsPerCU : (size_t)64 * 1024;
+      const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
+      LaneArgs<T> ap = a;
+      if (a.lds_grow && !a.ckpt) {
+        const unsigned per_cu = (workgroups + kCUs - 1) / kCUs;
+        size_t budget = kLdsPerCU / (per_cu ? per_cu : 1);
+        if (budget > max_dyn) budget = max_dyn;
+        const size_t per_step = (size_t)64 * m * (n + 1) * sizeof(T);
+        const size_t need0 = fixed + kK0Bytes + 1024;  // (1 KiB: allocation granularity)
+        int steps = budget > need0 ? (int)((budget - need0) / per_step) : 0;
+        if (steps > c.N - 1) steps = c.N - 1;
+        if (steps > ap.lds_steps) ap.lds_steps = steps;
+      }
+      hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128),
+                         lane_lds(ap) + fixed, s, c, ap);
     }
   }
   template <bool TL>

@@ -67,6 +67,7 @@ template <class T> struct LaneArgs {
   // no-op unless count_lo < *count <= count_hi
   int count_lo, count_hi;
   int two_max;  // k_lane_iterate_pair: the second state buffer is used up to this many live problems
+  int lds_grow;  // k_lane_iterate_pair: the launcher may keep more gain steps in LDS than lds_steps
   unsigned long long* dbg;  // diagnostic builds only: [B/64][8] phase cycle sums
   int defer;      // forward pass stores no states; an accepted step re-rolls them
   int lds_steps;  // horizon steps whose gains stay in LDS (dynamic LDS = 64 lds_steps m (n+1) words)
