@@ -614,33 +614,38 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static size_t lane_lds(const LaneArgs<T>& a) {
     return (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes + (a.ckpt ? kSegBytes : 0);
   }
-  // A launch of the helper-wavefront form puts one or two workgroups on a CU, so each has 160 or 80
-  // KiB of LDS to itself where the one-wavefront kernel budgets 36 (four wavefronts per CU): the
-  // gains of that many more horizon steps stay in LDS between the backward and the forward pass
-  // (19 of 20 steps up to 256 workgroups at n = 6, m = 2; 8 up to 512) instead of going through HBM.
+  // A launch of at most 256 / 512 workgroups puts one / two of them on a CU, so each has 160 / 80
+  // KiB of LDS to itself where a full launch budgets 36 (four wavefronts per CU): the gains of that
+  // many more horizon steps stay in LDS between the backward and the forward pass instead of going
+  // through HBM (fp64, n = 6, m = 2: 19 of 20 steps up to 256 workgroups, 8-10 up to 512).
   static constexpr unsigned kCUs = 256;                 // MI355X
   static constexpr size_t kLdsPerCU = 160 * 1024;       // gfx950
+  // lds_steps of a launch of `workgroups` workgroups with `fixed` bytes of other dynamic LDS each;
+  // max_dyn: what the kernel may be given (more than 64 KiB has to be asked for, once per kernel)
+  static int grown_lds_steps(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, size_t fixed,
+                             size_t max_dyn) {
+    if (!a.lds_grow || a.ckpt) return a.lds_steps;
+    const unsigned per_cu = (workgroups + kCUs - 1) / kCUs;
+    size_t budget = kLdsPerCU / (per_cu ? per_cu : 1);
+    if (budget > max_dyn) budget = max_dyn;
+    const size_t per_step = (size_t)64 * m * (n + 1) * sizeof(T);
+    const size_t need0 = fixed + kK0Bytes + 1024;  // (1 KiB: allocation granularity)
+    int steps = budget > need0 ? (int)((budget - need0) / per_step) : 0;
+    if (steps > c.N - 1) steps = c.N - 1;
+    return steps > a.lds_steps ? steps : a.lds_steps;
+  }
+  template <class K> static size_t max_dynamic_lds(K kernel) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)kLdsPerCU) == hipSuccess ? kLdsPerCU : (size_t)64 * 1024;
+  }
   template <bool TL>
   static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
     if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
       using LW = LaneWorker<T, Sys, false, TL>;
-      // more than 64 KiB of dynamic LDS per workgroup has to be asked for once per kernel
-      static const size_t max_dyn =
-          hipFuncSetAttribute((const void*)&k_lane_iterate_pair<T, Sys, TL>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU) == hipSuccess
-              ? kLdsPerCU : (size_t)64 * 1024;
+      static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate_pair<T, Sys, TL>);
       const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
       LaneArgs<T> ap = a;
-      if (a.lds_grow && !a.ckpt) {
-        const unsigned per_cu = (workgroups + kCUs - 1) / kCUs;
-        size_t budget = kLdsPerCU / (per_cu ? per_cu : 1);
-        if (budget > max_dyn) budget = max_dyn;
-        const size_t per_step = (size_t)64 * m * (n + 1) * sizeof(T);
-        const size_t need0 = fixed + kK0Bytes + 1024;  // (1 KiB: allocation granularity)
-        int steps = budget > need0 ? (int)((budget - need0) / per_step) : 0;
-        if (steps > c.N - 1) steps = c.N - 1;
-        if (steps > ap.lds_steps) ap.lds_steps = steps;
-      }
+      ap.lds_steps = grown_lds_steps(c, a, workgroups, fixed, max_dyn);
       hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128),
                          lane_lds(ap) + fixed, s, c, ap);
     }
@@ -648,7 +653,6 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   template <bool TL>
   static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s,
                              int opt_pair = 0) {
-    const size_t lds = lane_lds(a);
     if (use_pair(c, a, B, opt_pair)) {
       launch_pair<TL>(c, a, grid(B), s);
       return;
@@ -664,12 +668,18 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (!launched)
         hipLaunchKernelGGL((k_lane_iterate_rows<T, Sys, false, TL>), dim3(grid(B)), dim3(64), 0, s, c, a);
     } else {
-      if (c.flags)
-        hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64), lds, s, c,
-                           a);
-      else
-        hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64), lds, s, c,
-                           a);
+      LaneArgs<T> ag = a;
+      if (c.flags) {
+        static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate<T, Sys, true, TL>);
+        ag.lds_steps = grown_lds_steps(c, a, grid(B), 0, max_dyn);
+        hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64),
+                           lane_lds(ag), s, c, ag);
+      } else {
+        static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate<T, Sys, false, TL>);
+        ag.lds_steps = grown_lds_steps(c, a, grid(B), 0, max_dyn);
+        hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64),
+                           lane_lds(ag), s, c, ag);
+      }
     }
   }
 
