@@ -206,9 +206,9 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     law instead of reading them back.  Automatic: 1 from 32768 problems.
  *   "lds_gain_steps"  upper bound on the horizon steps 1, 2, ... whose gains stay in LDS between
  *                     the backward and the forward pass (automatic: what fits next to four
- *                     wavefronts per CU: 5 in fp64, 10 in fp32 at n = 6, m = 2; the helper-wavefront
- *                     form, whose launches put one or two workgroups on a CU: what fits 160 or 80
- *                     KiB — 19 of 20 steps up to 16384 problems, 8 up to 32768).  Step 0 always
+ *                     wavefronts per CU: 5 in fp64, 10 in fp32 at n = 6, m = 2; a launch of at most
+ *                     256 / 512 workgroups puts one / two of them on a CU: what fits 160 / 80 KiB
+ *                     then — in fp64 19 of 20 steps up to 16384 problems, 8-10 up to 32768).  Step 0 always
  *                     stays: the forward pass needs only its k_0 (x_0 is common to the nominal
  *                     and the candidate trajectory, K_0 multiplies zeros).
  *   "wave_tail"       chunked solve (i2lqr_set_compaction) only: once a compaction leaves at most
