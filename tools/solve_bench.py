@@ -7,6 +7,9 @@
                                       on three distributions of the workload: the bench's, every
                                       problem with the obstacle, targets twice as far
                                       (VERDICT r4 #3); JSON to gpurun_out/solve_schedule.json
+    solve_bench.py --ab opt=val [B...]  the automatic solve against the same solve with one option
+                                      set (e.g. helper_wavefront=0: one-wavefront chunks), same
+                                      process, alternating, on the three distributions
 """
 import json
 import sys
@@ -99,6 +102,32 @@ def plan_sweep(batches):
                   "  ".join(f"{k} {v / hand:5.3f}" for k, v in row.items() if not k.startswith("hand")),
                   flush=True)
 
+
+def ab_sweep(option, batches):
+    key, val = option.split("=")
+    for B in batches:
+        for variant in (None, "all_obstacle", "far_targets"):
+            cfg = workloads.config_for("config2", "f64")
+            cfg.layout = 2
+            host = workloads.make_batch(cfg, B, variant=variant)
+            res, its = {"auto": [], option: []}, {}
+            for _ in range(2):
+                for name in res:
+                    solver = BatchedILQR(cfg)
+                    if name != "auto":
+                        solver.set_option(key, int(val))
+                    ms, it = time_solve(solver, host, reps=7)
+                    res[name].append(ms)
+                    its[name] = it
+                    solver.close()
+            print(f"B={B:7d} {variant or 'bench':13s} auto {min(res['auto']):6.3f} ms   {option} "
+                  f"{min(res[option]):6.3f} ms   iteration counts equal: "
+                  f"{bool(torch.equal(its['auto'], its[option]))}", flush=True)
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--ab":
+    ab_sweep(sys.argv[2], [int(b) for b in sys.argv[3:]] or [49152, 65536, 131072])
+    sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == "--plans":
     plan_sweep([int(b) for b in sys.argv[2:]] or [16384, 65536, 262144])
