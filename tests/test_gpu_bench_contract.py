@@ -53,6 +53,33 @@ def test_bench_json_line_contract():
     assert c["reference_python"]["value"] == 756.0 and "BASELINE.md" in c["reference_python"]["provenance"]
 
 
+def test_default_bench_line_carries_the_claim_scalars_inside_roofline():
+    """the driver keeps `parsed.roofline`, so the figures the claims rest on are
+    scalars inside it (the full objects stay in roofline_large_batch / roofline_solve / extra)."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5",
+                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900,
+                         cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    for key in ("large_batch_B65536_f64_frac", "large_batch_B131072_f64_frac", "quad12_frac",
+                "quad12_iterations_per_s", "B16384_f64_iterations_per_s", "solve_B65536_ms",
+                "solve_frac_of_fixed_count_rate"):
+        assert isinstance(r[key], float) and r[key] > 0, key
+    assert 0.3 < r["large_batch_B65536_f64_frac"] < 1 and 0.2 < r["quad12_frac"] < 1
+    assert r["large_batch_B65536_f64_frac"] == d["roofline_large_batch"]["B65536"]["hbm_frac"]
+    assert r["solve_B65536_ms"] == d["roofline_solve"]["ms_per_solve"] < 3.0
+    curve = r["mid_batch_curve_f64_Mits"]
+    assert list(curve) == ["4096", "8192", "12288", "16384", "24576", "32768"]
+    # the range VERDICT r4 #4 asked about: the lane side (helper-wavefront kernel) carries it upward
+    assert curve["12288"] < curve["16384"] < curve["24576"] < curve["32768"]
+    assert d["extra"]["B16384_f64"]["kernel"] == "k_lane_iterate_pair"
+    assert "no gains" not in d["roofline_solve"]["outputs"] and "K" not in d["roofline_solve"]["outputs"]
+    assert d["roofline_solve"]["ms_per_solve_with_gains_out"] > 0
+
+
 def test_bench_under_torchrun_world_of_one_uses_the_native_rccl_exchange():
     """The driver's N > 1 command form with one rank (all this box has): RCCL process group,
     communicator created through the C-ABI, i2lqr_allgather_costs on the side stream, pick checked
