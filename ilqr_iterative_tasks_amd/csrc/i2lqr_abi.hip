@@ -620,8 +620,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // through HBM (fp64, n = 6, m = 2: 19 of 20 steps up to 256 workgroups, 8-10 up to 512).
   static constexpr unsigned kCUs = 256;                 // MI355X
   static constexpr size_t kLdsPerCU = 160 * 1024;       // gfx950
-  // lds_steps of a launch of `workgroups` workgroups with `fixed` bytes of other dynamic LDS each;
-  // max_dyn: what the kernel may be given (more than 64 KiB has to be asked for, once per kernel)
+  // lds_steps of a launch of `workgroups` workgroups with `fixed` bytes of other dynamic LDS each,
+  // at most max_dyn bytes of dynamic LDS per workgroup
   static int grown_lds_steps(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, size_t fixed,
                              size_t max_dyn) {
     if (!a.lds_grow || a.ckpt) return a.lds_steps;
@@ -634,18 +634,29 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (steps > c.N - 1) steps = c.N - 1;
     return steps > a.lds_steps ? steps : a.lds_steps;
   }
-  template <class K> static size_t max_dynamic_lds(K kernel) {
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)kLdsPerCU) == hipSuccess ? kLdsPerCU : (size_t)64 * 1024;
+  // More than 64 KiB of dynamic LDS per workgroup has to be asked for; the attribute belongs to
+  // the kernel ON THE CURRENT DEVICE, so it is set by every launch that needs it (a process may
+  // drive several devices) and a refusal falls back to what 64 KiB hold.
+  static constexpr size_t kDefaultDynLds = 64 * 1024;
+  template <class K>
+  static void grow_lds(K kernel, const Cfg& c, LaneArgs<T>& a, unsigned workgroups, size_t fixed) {
+    const int before = a.lds_steps;
+    a.lds_steps = grown_lds_steps(c, a, workgroups, fixed, kLdsPerCU);
+    if (lane_lds(a) + fixed <= kDefaultDynLds) return;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsPerCU) == hipSuccess)
+      return;
+    (void)hipGetLastError();
+    a.lds_steps = before;
+    a.lds_steps = grown_lds_steps(c, a, workgroups, fixed, kDefaultDynLds);
   }
   template <bool TL>
   static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
     if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
       using LW = LaneWorker<T, Sys, false, TL>;
-      static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate_pair<T, Sys, TL>);
       const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
       LaneArgs<T> ap = a;
-      ap.lds_steps = grown_lds_steps(c, a, workgroups, fixed, max_dyn);
+      grow_lds(&k_lane_iterate_pair<T, Sys, TL>, c, ap, workgroups, fixed);
       hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128),
                          lane_lds(ap) + fixed, s, c, ap);
     }
@@ -670,13 +681,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     } else {
       LaneArgs<T> ag = a;
       if (c.flags) {
-        static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate<T, Sys, true, TL>);
-        ag.lds_steps = grown_lds_steps(c, a, grid(B), 0, max_dyn);
+        grow_lds(&k_lane_iterate<T, Sys, true, TL>, c, ag, grid(B), 0);
         hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64),
                            lane_lds(ag), s, c, ag);
       } else {
-        static const size_t max_dyn = max_dynamic_lds(&k_lane_iterate<T, Sys, false, TL>);
-        ag.lds_steps = grown_lds_steps(c, a, grid(B), 0, max_dyn);
+        grow_lds(&k_lane_iterate<T, Sys, false, TL>, c, ag, grid(B), 0);
         hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64),
                            lane_lds(ag), s, c, ag);
       }
