@@ -404,3 +404,17 @@ def test_survivor_chunks_of_a_large_solve_pick_their_kernel_on_the_device(torch_
             assert torch.equal(outs[0][key], outs[1][key]), (B, variant, key)
         it = outs[0]["iters"]
         assert int(it.max()) > 12 and int((it > 8).sum()) > 0  # chunks behind the first did run
+
+
+def test_helper_wavefront_fuzz_sample():
+    """tools/fuzz_pair.py: random plants, horizons (1 ... 50), batch sizes, layouts, iteration counts
+    and option mixes — k_lane_iterate_pair equals k_lane_iterate bit for bit, fused iterations and
+    solves (a 550-case run is profiles/r05_fuzz_pair.txt)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "fuzz_pair.py"), "16", "7"],
+                         capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "16 cases, 0 mismatches" in out.stdout

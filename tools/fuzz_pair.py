@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Stress of the helper-wavefront kernel's barrier protocol: random plants / horizons / batch sizes /
+layouts / iteration counts / option mixes, fused iterations and solves, k_lane_iterate_pair against
+k_lane_iterate bit for bit (tests/test_gpu_round5.py holds four fixed cases of this).
+    python tools/fuzz_pair.py [cases, default 120] [seed]"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+
+from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(cases):
+    system = ["bicycle4", "bicycle6"][rng.integers(2)]
+    N = int(rng.choice([1, 2, 3, 6, 11, 20, 33, 50]))
+    tiled = bool(rng.integers(2))
+    B = int(rng.choice([64, 128, 640, 4096, 8192, 12288, 16384, 20480, 32768])) if tiled else \
+        int(rng.integers(1, 20000))
+    if N >= 33 and B > 16384:
+        B = 16384 if tiled else 9001
+    cfg = default_config(system, N, "f64", dt=float(rng.choice([0.1, 0.25, 0.5])), layout=2 if tiled else 1)
+    host = workloads.make_batch(cfg, B, variant=[None, "all_obstacle", "far_targets"][rng.integers(3)])
+    host["lamb"] = 10.0 ** rng.integers(-4, 3, B).astype(float)
+    iters = int(rng.integers(1, 9))
+    opts = {"state_buffers": int(rng.integers(-1, 2)), "lds_gain_steps": int(rng.choice([-1, 0, 3, 100])),
+            "reroll_nominal": int(rng.integers(-1, 2)), "defer_states": int(rng.integers(-1, 2))}
+    outs = []
+    for hw in (0, 1):
+        s = BatchedILQR(cfg)
+        s.set_option("helper_wavefront", hw)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        dev = lambda a: s.to_native(torch.as_tensor(a).to(s.device, s.dtype))
+        def fresh():
+            buf = s.alloc(B)
+            for key in ("X", "U", "x_term", "lamb"):
+                buf[key].copy_(dev(host[key]))
+            buf["obs"] = dev(host["obs"])
+            return buf
+        it = s.iterate(fresh(), iters)
+        so = s.solve(fresh())
+        torch.cuda.synchronize()
+        outs.append((it, so))
+        s.close()
+    ok = all(torch.equal(a[key], b[key]) for a, b in zip(outs[0], outs[1])
+             for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"))
+    bad += not ok
+    print(f"case {case:3d} {system} N={N:2d} B={B:6d} {'tiled' if tiled else 'minor'} iters={iters} {opts} "
+          f"{'ok' if ok else 'MISMATCH'}", flush=True)
+print(f"{cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
