@@ -25,7 +25,6 @@ sharded=ShardedRound(...)  (lamb_mode="independent") the multi-GPU calc_input: e
 """
 from __future__ import annotations
 
-from copy import deepcopy
 
 import numpy as np
 
