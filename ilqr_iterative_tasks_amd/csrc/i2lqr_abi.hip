@@ -599,13 +599,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (a.lds_steps > steps) a.lds_steps = steps;
     }
   }
-  // The helper-wavefront form (k_lane_iterate_pair; round 5): fp64 bicycles with Q = R = 0, states
-  // not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
+  // The helper-wavefront form (k_lane_iterate_pair; round 5): fp64 bicycles (stage weights: its HASQR
+  // instantiation), states not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
   // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
   static constexpr unsigned kPairMaxGrid = 512;
   static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU
   static bool pair_built(const Cfg& c, const LaneArgs<T>& a, int opt_pair) {
-    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) return !c.flags && !a.ckpt && opt_pair != 0;
+    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) return !a.ckpt && opt_pair != 0;
     return false;
   }
   static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
@@ -653,12 +653,20 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   template <bool TL>
   static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
     if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
-      using LW = LaneWorker<T, Sys, false, TL>;
-      const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
       LaneArgs<T> ap = a;
-      grow_lds(&k_lane_iterate_pair<T, Sys, TL>, c, ap, workgroups, fixed);
-      hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, TL>), dim3(workgroups), dim3(128),
-                         lane_lds(ap) + fixed, s, c, ap);
+      if (c.flags) {  // stage weights: the record carries 2 Q (x_t - xtarget) as well
+        using LW = LaneWorker<T, Sys, true, TL>;
+        const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
+        grow_lds(&k_lane_iterate_pair<T, Sys, true, TL>, c, ap, workgroups, fixed);
+        hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, true, TL>), dim3(workgroups), dim3(128),
+                           lane_lds(ap) + fixed, s, c, ap);
+      } else {
+        using LW = LaneWorker<T, Sys, false, TL>;
+        const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
+        grow_lds(&k_lane_iterate_pair<T, Sys, false, TL>, c, ap, workgroups, fixed);
+        hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, false, TL>), dim3(workgroups), dim3(128),
+                           lane_lds(ap) + fixed, s, c, ap);
+      }
     }
   }
   template <bool TL>
@@ -1504,12 +1512,9 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
   if (!h) return "";
   if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) {
     if (h->cfg.system_id == I2LQR_SYS_QUAD12) return "k_lane_iterate_rows";
-    // the helper-wavefront form: fp64, Q = R = 0, at most 512 workgroups (LaneLaunch::use_pair;
-    // states are checkpointed from 65536 problems only, i.e. never in that range)
-    bool weights = false;
-    for (int i = 0; i < I2LQR_MAX_N * I2LQR_MAX_N && !weights; i++) weights = h->cfg.Q[i] != 0.0;
-    for (int i = 0; i < I2LQR_MAX_M * I2LQR_MAX_M && !weights; i++) weights = h->cfg.R[i] != 0.0;
-    const bool pair = h->cfg.dtype == I2LQR_F64 && !weights && h->opt_pair != 0 &&
+    // the helper-wavefront form: fp64, at most 512 workgroups (LaneLaunch::use_pair; states are
+    // checkpointed from 65536 problems only, i.e. never in that range)
+    const bool pair = h->cfg.dtype == I2LQR_F64 && h->opt_pair != 0 &&
                       (h->opt_pair == 1 || (B + 63) / 64 <= 512) &&
                       !(early_exit && B >= 65536);
     return pair ? "k_lane_iterate_pair" : "k_lane_iterate";

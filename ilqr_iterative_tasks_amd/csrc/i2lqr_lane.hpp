@@ -604,15 +604,15 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // horizon step: helper  R(N-1) | R(N-2) | ... ,  main  | S(N-1) | S(N-2) ...  — the helper is a step
   // ahead and the shorter of the two, so the main wavefront does not wait.  Same operations on the
   // same operands as ROLE 0 (the record travels through LDS unchanged): bit-identical.
-  static constexpr int kRec = NV + 5 + 2 * m;  // jv, obstacle terms, l_u, l_uu (Q = R = 0)
+  static constexpr int kRec = NV + 5 + 2 * m + (HASQR ? n : 0);  // jv, obstacle terms, l_u, l_uu (+ 2 Q dx_t)
   lds_t* rec = nullptr;                        // [2][kRec][64], set by the kernel
   template <bool FASTBAR = false, bool CK = false, int ROLE = 0>
   __device__ __forceinline__ void backward(const T* X, const T* U, const T (&xT)[n],
                                            const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
                                            lds_t* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
-    static_assert(ROLE == 0 || (!CK && !DEEP && !HASQR && Sys::NBLK == 0),
-                  "the helper form is built for the plain fp64 pass with Q = R = 0");
+    static_assert(ROLE == 0 || (!CK && !DEEP && Sys::NBLK == 0),
+                  "the helper form is built for the plain fp64 pass of the bicycles");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
       __shared__ T lds_gains[kGainWords];
@@ -759,6 +759,10 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           r[(NV + 5 + a) * 64] = lu[a];
           r[(NV + 5 + m + a) * 64] = luu[a];
         }
+        if constexpr (HASQR) {
+#pragma unroll
+          for (int a = 0; a < n; a++) r[(NV + 5 + 2 * m + a) * 64] = lxq[a];
+        }
         pair_barrier();
         return;
       }
@@ -775,7 +779,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           luu[a] = r[(NV + 5 + m + a) * 64];
         }
 #pragma unroll
-        for (int a = 0; a < n; a++) lxq[a] = T(0);
+        for (int a = 0; a < n; a++) lxq[a] = HASQR ? T(r[(NV + 5 + 2 * m + a) * 64]) : T(0);
       }
 
       STAMP_END(0);
@@ -1821,12 +1825,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 // problems), and masked lanes do not issue faster.  What CAN run elsewhere is the part of the
 // backward pass that depends on the nominal trajectory only: workgroups of TWO wavefronts, the second
 // one computing every step's record a step ahead of the first (LaneWorker::backward<.., ROLE>).
-// fp64, Q = R = 0, states not checkpointed; same arguments, results bit-identical to k_lane_iterate.
-template <class T, class Sys, bool TILED>
+// fp64 (HASQR: stage weights, the record grows by l_x), states not checkpointed; same arguments, results bit-identical to k_lane_iterate.
+template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
     const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {
   constexpr int n = Sys::n, m = Sys::m;
-  constexpr bool HASQR = false;
   const int role = threadIdx.x >> 6;  // 0: main wavefront, 1: helper
   const unsigned l64 = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 64 + l64;

@@ -35,15 +35,17 @@ namespace i2lqr {
 
 // k_lane_iterate_pair (the bicycles' lane kernel with a helper wavefront, fp64): compiled in
 // i2lqr_lanepair.hip
-#define I2LQR_LANEPAIR_KERNELS(DECL)                                                              \
-  DECL void k_lane_iterate_pair<double, Bicycle4<double>, false>(const DevCfg<double, 4, 2>,      \
-                                                                 const LaneArgs<double>);         \
-  DECL void k_lane_iterate_pair<double, Bicycle4<double>, true>(const DevCfg<double, 4, 2>,       \
-                                                                const LaneArgs<double>);          \
-  DECL void k_lane_iterate_pair<double, Bicycle6<double>, false>(const DevCfg<double, 6, 2>,      \
-                                                                 const LaneArgs<double>);         \
-  DECL void k_lane_iterate_pair<double, Bicycle6<double>, true>(const DevCfg<double, 6, 2>,       \
-                                                                const LaneArgs<double>);
+#define I2LQR_LANEPAIR_KERNELS_(DECL, QR)                                                         \
+  DECL void k_lane_iterate_pair<double, Bicycle4<double>, QR, false>(const DevCfg<double, 4, 2>,  \
+                                                                     const LaneArgs<double>);     \
+  DECL void k_lane_iterate_pair<double, Bicycle4<double>, QR, true>(const DevCfg<double, 4, 2>,   \
+                                                                    const LaneArgs<double>);      \
+  DECL void k_lane_iterate_pair<double, Bicycle6<double>, QR, false>(const DevCfg<double, 6, 2>,  \
+                                                                     const LaneArgs<double>);     \
+  DECL void k_lane_iterate_pair<double, Bicycle6<double>, QR, true>(const DevCfg<double, 6, 2>,   \
+                                                                    const LaneArgs<double>);
+#define I2LQR_LANEPAIR_KERNELS(DECL) \
+  I2LQR_LANEPAIR_KERNELS_(DECL, false) I2LQR_LANEPAIR_KERNELS_(DECL, true)
 #ifndef I2LQR_LANEPAIR_DEFINE
 I2LQR_LANEPAIR_KERNELS(extern template __global__)
 #endif

@@ -220,7 +220,7 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     settle an accept / reject tie the other way and stop at a different
  *                     iteration).  0: off; automatic: 12288 with the speculative kernel, 2048 with
  *                     the one-problem-per-wavefront kernel.
- *   "helper_wavefront"  (fp64 bicycles, Q = R = 0) 1: workgroups of TWO wavefronts — a helper forms
+ *   "helper_wavefront"  (fp64 bicycles, with or without stage weights) 1: workgroups of TWO wavefronts — a helper forms
  *                     the part of every backward step that depends on the nominal trajectory only
  *                     (loads, sin / cos, Jacobian entries, barrier exponentials, obstacle term: 30 %
  *                     of an iteration) a step ahead of the main wavefront, on a SIMD the launch

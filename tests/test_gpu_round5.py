@@ -343,9 +343,11 @@ def test_quad12_fp32_on_the_lane_layouts_tracks_the_fp64_oracle(torch_mod, layou
     assert (st == ref_so["status"]).mean() >= 0.9
 
 
-@pytest.mark.parametrize("system,N,dt,layout,B", [("bicycle6", 20, 0.25, 2, 16384), ("bicycle6", 20, 0.25, 1, 1000),
-                                                ("bicycle4", 6, 1.0, 2, 64), ("bicycle4", 50, 0.25, 1, 777)])
-def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout, B):
+@pytest.mark.parametrize("system,N,dt,layout,B,weights", [
+    ("bicycle6", 20, 0.25, 2, 16384, False), ("bicycle6", 20, 0.25, 1, 1000, False),
+    ("bicycle4", 6, 1.0, 2, 64, False), ("bicycle4", 50, 0.25, 1, 777, False),
+    ("bicycle6", 20, 0.25, 2, 8192, True), ("bicycle4", 6, 1.0, 1, 3000, True)])
+def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout, B, weights):
     """k_lane_iterate_pair (round 5): workgroups of two wavefronts, the helper forming
     every backward step's trajectory-dependent half a step ahead of the main wavefront.  The record
     travels through LDS unchanged, so fused iterations (with gains), the solve to termination
@@ -357,6 +359,14 @@ def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout
     torch = torch_mod
     from ilqr_iterative_tasks_amd import BatchedILQR, default_config, workloads
     cfg = default_config(system, N, "f64", dt=dt, layout=layout)
+    if weights:  # stage weights Q, R != 0: the record carries 2 Q (x_t - xtarget) as well
+        wr = np.random.default_rng(11)
+        A = wr.normal(0, 0.1, (cfg.n, cfg.n))
+        cfg.set_matrix("Q", A @ A.T + np.diag(wr.uniform(0.0, 0.1, cfg.n)))
+        Bm = wr.normal(0, 0.05, (cfg.m, cfg.m))
+        cfg.set_matrix("R", Bm @ Bm.T + np.diag(wr.uniform(0.02, 0.1, cfg.m)))
+        cfg.xtarget[:cfg.n] = wr.normal(0, 0.2, cfg.n)
+        cfg.max_iter = 12  # (see tools/parity_campaign.py: with Q != 0 no solve of the reference converges)
     host = workloads.make_batch(cfg, B)
     host["lamb"] = 10.0 ** np.random.default_rng(3).integers(-3, 3, B).astype(float)
     outs = {}
@@ -375,6 +385,8 @@ def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout
                 assert torch.equal(a[key], b[key]), (other, key)
     big = BatchedILQR(cfg)
     assert big.iterate_kernel(65536) == "k_lane_iterate" and big.iterate_kernel(32768) == "k_lane_iterate_pair"
+    if weights:
+        return
     f32 = BatchedILQR(default_config(system, N, "f32", dt=dt, layout=layout))
     assert f32.iterate_kernel(B) == "k_lane_iterate"  # fp64 only
 
@@ -409,7 +421,7 @@ def test_survivor_chunks_of_a_large_solve_pick_their_kernel_on_the_device(torch_
 def test_helper_wavefront_fuzz_sample():
     """tools/fuzz_pair.py: random plants, horizons (1 ... 50), batch sizes, layouts, iteration counts
     and option mixes — k_lane_iterate_pair equals k_lane_iterate bit for bit, fused iterations and
-    solves (a 550-case run is profiles/r05_fuzz_pair.txt)."""
+    solves, with and without stage weights (a 600-case run is profiles/r05_fuzz_pair.txt)."""
     import subprocess
     import sys
     from pathlib import Path

@@ -120,7 +120,7 @@ def test_helper_wavefront_kernel_hands_its_record_over_in_lds_and_spills_to_regi
     (s_waitcnt lgkmcnt(0) + s_barrier from the inline asm: no vmcnt drain in front of it), and the
     horizon loops of both wavefronts keep their spills in accumulation registers, not in scratch."""
     text = isa["lanepair"]
-    loops = _loops(text, "_ZN5i2lqr19k_lane_iterate_pairIdNS_8Bicycle6IdEELb1EEE")
+    loops = _loops(text, "_ZN5i2lqr19k_lane_iterate_pairIdNS_8Bicycle6IdEELb0ELb1EEE")
     assert loops
     hot = {k: v for k, v in loops.items() if sum("f64" in i for i in v) > 100}
     assert len(hot) >= 4, {k: len(v) for k, v in loops.items()}  # helper, main, forward, re-roll

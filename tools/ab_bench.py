@@ -19,6 +19,8 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--cold", action="store_true", help="every timed launch runs on its own copy of "
                 "the batch, filled before the first launch (no restore copy right before a launch "
                 "leaves its inputs warm in the 256 MB Infinity Cache): what bench.py measures")
+ap.add_argument("--weights", action="store_true", help="stage weights Q, R != 0 (seeded random "
+                "positive semi-definite Q, positive definite R, a target off the origin)")
 args = ap.parse_args()
 
 LAY = {"wave": 0, "lane": 1, "tiled": 2}
@@ -32,6 +34,13 @@ for v in args.variants.split(","):
     B = int(B)
     cfg = workloads.config_for(args.workload, dtype)
     cfg.layout = LAY[layout]
+    if args.weights:
+        wr = np.random.default_rng(11)
+        A = wr.normal(0, 0.1, (cfg.n, cfg.n))
+        cfg.set_matrix("Q", A @ A.T + np.diag(wr.uniform(0.0, 0.1, cfg.n)))
+        Bm = wr.normal(0, 0.05, (cfg.m, cfg.m))
+        cfg.set_matrix("R", Bm @ Bm.T + np.diag(wr.uniform(0.02, 0.1, cfg.m)))
+        cfg.xtarget[:cfg.n] = wr.normal(0, 0.2, cfg.n)
     solver = BatchedILQR(cfg, lib_path=lib_path)
     for key, val in opts.items():
         solver.set_option(key, int(val))

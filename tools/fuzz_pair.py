@@ -24,6 +24,14 @@ for case in range(cases):
     if N >= 33 and B > 16384:
         B = 16384 if tiled else 9001
     cfg = default_config(system, N, "f64", dt=float(rng.choice([0.1, 0.25, 0.5])), layout=2 if tiled else 1)
+    weights = bool(rng.random() < 0.3)
+    if weights:  # stage weights Q, R != 0 (as tools/parity_campaign.py draws them)
+        A = rng.normal(0, 0.1, (cfg.n, cfg.n))
+        cfg.set_matrix("Q", A @ A.T + np.diag(rng.uniform(0.0, 0.1, cfg.n)))
+        Bm = rng.normal(0, 0.05, (cfg.m, cfg.m))
+        cfg.set_matrix("R", Bm @ Bm.T + np.diag(rng.uniform(0.02, 0.1, cfg.m)))
+        cfg.xtarget[:cfg.n] = rng.normal(0, 0.2, cfg.n)
+        cfg.max_iter = 12
     host = workloads.make_batch(cfg, B, variant=[None, "all_obstacle", "far_targets"][rng.integers(3)])
     host["lamb"] = 10.0 ** rng.integers(-4, 3, B).astype(float)
     iters = int(rng.integers(1, 9))
@@ -50,7 +58,7 @@ for case in range(cases):
     ok = all(torch.equal(a[key], b[key]) for a, b in zip(outs[0], outs[1])
              for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"))
     bad += not ok
-    print(f"case {case:3d} {system} N={N:2d} B={B:6d} {'tiled' if tiled else 'minor'} iters={iters} {opts} "
+    print(f"case {case:3d} {system} N={N:2d} B={B:6d} {'tiled' if tiled else 'minor'} {'Q,R ' if weights else ''}iters={iters} {opts} "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
