@@ -605,7 +605,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   static constexpr unsigned kPairMaxGrid = 512;
   static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU
   static bool pair_built(const Cfg& c, const LaneArgs<T>& a, int opt_pair) {
-    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) return !a.ckpt && opt_pair != 0;
+    if constexpr (Sys::NBLK == 0) return !a.ckpt && opt_pair != 0;
     return false;
   }
   static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
@@ -652,7 +652,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   }
   template <bool TL>
   static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
-    if constexpr (sizeof(T) == 8 && Sys::NBLK == 0) {
+    if constexpr (Sys::NBLK == 0) {
       LaneArgs<T> ap = a;
       if (c.flags) {  // stage weights: the record carries 2 Q (x_t - xtarget) as well
         using LW = LaneWorker<T, Sys, true, TL>;
@@ -1387,16 +1387,17 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
 //   quad12 (fp64): the sixteen-lane kernel 13 M it/s at any size, k_lane_iterate_rows 25 M at
 //   8192 and 73 M at 65536.
 struct LaneFrom { int64_t iterate, solve; };
-// (the fp64 columns re-measured with the helper-wavefront form of the lane kernel, which moved the
-// bicycle6 N = 20 crossover from 12289 to 8193: profiles/r05_threshold_sweep5.json)
+// (re-measured with the helper-wavefront form of the lane kernel, which moved the bicycle6 N = 20
+// crossover from 12289 to 8193 in fp64 and from 16385 to 12289 in fp32: profiles/
+// r05_threshold_sweep5.json ... 9.json)
 constexpr LaneFrom kLaneFrom[2][3][2] = {
     // bicycle4:          fp64              fp32
-    /* N ~ 6  */ {{{8193, 10241}, {12289, 10241}},
+    /* N ~ 6  */ {{{8193, 10241}, {8193, 10241}},
     /* N ~ 20 */  {{8193, 4096}, {8193, 10241}},
     /* N ~ 50 */  {{4097, 4096}, {8193, 5121}}},
     // bicycle6
     /* N ~ 6  */ {{{8193, 6145}, {8193, 20481}},
-    /* N ~ 20 */  {{8193, 10241}, {16385, 12289}},
+    /* N ~ 20 */  {{8193, 10241}, {12289, 12289}},
     /* N ~ 50 */  {{3073, 4096}, {8193, 5121}}},
 };
 inline LaneFrom lane_from(const i2lqr_config& cfg) {
@@ -1514,7 +1515,7 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
     if (h->cfg.system_id == I2LQR_SYS_QUAD12) return "k_lane_iterate_rows";
     // the helper-wavefront form: fp64, at most 512 workgroups (LaneLaunch::use_pair; states are
     // checkpointed from 65536 problems only, i.e. never in that range)
-    const bool pair = h->cfg.dtype == I2LQR_F64 && h->opt_pair != 0 &&
+    const bool pair = h->opt_pair != 0 &&
                       (h->opt_pair == 1 || (B + 63) / 64 <= 512) &&
                       !(early_exit && B >= 65536);
     return pair ? "k_lane_iterate_pair" : "k_lane_iterate";

@@ -611,8 +611,8 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
                                            const T (&ob)[6], T lamb, T* gK, T* gk, bool k0_out,
                                            lds_t* seg = nullptr) const {
     static_assert(!(CK && DEEP), "checkpointed states are built for the fp64 kernels");
-    static_assert(ROLE == 0 || (!CK && !DEEP && Sys::NBLK == 0),
-                  "the helper form is built for the plain fp64 pass of the bicycles");
+    static_assert(ROLE == 0 || (!CK && Sys::NBLK == 0),
+                  "the helper form is built for the plain pass of the bicycles");
     if constexpr (Sys::NBLK > 0) {
       static_assert(!CK, "the row-block form has no checkpointed variant");
       __shared__ T lds_gains[kGainWords];
@@ -900,7 +900,7 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     };
     if constexpr (DEEP) {
       T xq[n], uq[m];  // the second buffer: x_{N-2}, u_{N-2}
-      if (N >= 2) {
+      if (N >= 2 && ROLE != 1) {
 #pragma unroll
         for (int i = 0; i < n; i++) xq[i] = at(X, rx(i, N - 2));
 #pragma unroll

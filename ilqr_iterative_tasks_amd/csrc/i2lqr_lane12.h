@@ -35,17 +35,18 @@ namespace i2lqr {
 
 // k_lane_iterate_pair (the bicycles' lane kernel with a helper wavefront, fp64): compiled in
 // i2lqr_lanepair.hip
-#define I2LQR_LANEPAIR_KERNELS_(DECL, QR)                                                         \
-  DECL void k_lane_iterate_pair<double, Bicycle4<double>, QR, false>(const DevCfg<double, 4, 2>,  \
-                                                                     const LaneArgs<double>);     \
-  DECL void k_lane_iterate_pair<double, Bicycle4<double>, QR, true>(const DevCfg<double, 4, 2>,   \
-                                                                    const LaneArgs<double>);      \
-  DECL void k_lane_iterate_pair<double, Bicycle6<double>, QR, false>(const DevCfg<double, 6, 2>,  \
-                                                                     const LaneArgs<double>);     \
-  DECL void k_lane_iterate_pair<double, Bicycle6<double>, QR, true>(const DevCfg<double, 6, 2>,   \
-                                                                    const LaneArgs<double>);
-#define I2LQR_LANEPAIR_KERNELS(DECL) \
-  I2LQR_LANEPAIR_KERNELS_(DECL, false) I2LQR_LANEPAIR_KERNELS_(DECL, true)
+#define I2LQR_LANEPAIR_KERNELS_(DECL, REAL, QR)                                                   \
+  DECL void k_lane_iterate_pair<REAL, Bicycle4<REAL>, QR, false>(const DevCfg<REAL, 4, 2>,        \
+                                                                 const LaneArgs<REAL>);           \
+  DECL void k_lane_iterate_pair<REAL, Bicycle4<REAL>, QR, true>(const DevCfg<REAL, 4, 2>,         \
+                                                                const LaneArgs<REAL>);            \
+  DECL void k_lane_iterate_pair<REAL, Bicycle6<REAL>, QR, false>(const DevCfg<REAL, 6, 2>,        \
+                                                                 const LaneArgs<REAL>);           \
+  DECL void k_lane_iterate_pair<REAL, Bicycle6<REAL>, QR, true>(const DevCfg<REAL, 6, 2>,         \
+                                                                const LaneArgs<REAL>);
+#define I2LQR_LANEPAIR_KERNELS(DECL)                                                    \
+  I2LQR_LANEPAIR_KERNELS_(DECL, double, false) I2LQR_LANEPAIR_KERNELS_(DECL, double, true) \
+  I2LQR_LANEPAIR_KERNELS_(DECL, float, false) I2LQR_LANEPAIR_KERNELS_(DECL, float, true)
 #ifndef I2LQR_LANEPAIR_DEFINE
 I2LQR_LANEPAIR_KERNELS(extern template __global__)
 #endif

@@ -220,12 +220,12 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *                     settle an accept / reject tie the other way and stop at a different
  *                     iteration).  0: off; automatic: 12288 with the speculative kernel, 2048 with
  *                     the one-problem-per-wavefront kernel.
- *   "helper_wavefront"  (fp64 bicycles, with or without stage weights) 1: workgroups of TWO wavefronts — a helper forms
+ *   "helper_wavefront"  (the bicycles: fp64 and fp32, with or without stage weights) 1: workgroups of TWO wavefronts — a helper forms
  *                     the part of every backward step that depends on the nominal trajectory only
  *                     (loads, sin / cos, Jacobian entries, barrier exponentials, obstacle term: 30 %
  *                     of an iteration) a step ahead of the main wavefront, on a SIMD the launch
  *                     leaves idle; bit-identical.  Automatic: up to 512 workgroups (32768 problems):
- *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M.  In the chunked solve
+ *                     16384 problems 302 -> 360 M it/s, 32768: 543 -> 649 M (fp32: 460 -> 595, 865 -> 1035 M).  In the chunked solve
  *                     of a larger batch every lane chunk behind the first is enqueued in both forms
  *                     and the live count picks one on the device (<= 32768 survivors: this one).
  *                     0: one wavefront everywhere.

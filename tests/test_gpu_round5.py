@@ -387,8 +387,18 @@ def test_helper_wavefront_form_is_bit_identical(torch_mod, system, N, dt, layout
     assert big.iterate_kernel(65536) == "k_lane_iterate" and big.iterate_kernel(32768) == "k_lane_iterate_pair"
     if weights:
         return
-    f32 = BatchedILQR(default_config(system, N, "f32", dt=dt, layout=layout))
-    assert f32.iterate_kernel(B) == "k_lane_iterate"  # fp64 only
+    # fp32: the same kernel (its backward pass alternates two register sets; the record is the same)
+    c32 = default_config(system, N, "f32", dt=dt, layout=layout)
+    o32 = []
+    for hw in (0, -1):
+        s = BatchedILQR(c32)
+        s.set_option("helper_wavefront", hw)
+        assert s.iterate_kernel(B) == ("k_lane_iterate" if hw == 0 else "k_lane_iterate_pair")
+        o32.append((s.iterate(dev_batch(s, host), 7), s.solve(dev_batch(s, host))))
+        torch.cuda.synchronize()
+    for a, b in zip(*o32):
+        for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"):
+            assert torch.equal(a[key], b[key]), ("f32", key)
 
 
 def test_survivor_chunks_of_a_large_solve_pick_their_kernel_on_the_device(torch_mod):
@@ -421,7 +431,7 @@ def test_survivor_chunks_of_a_large_solve_pick_their_kernel_on_the_device(torch_
 def test_helper_wavefront_fuzz_sample():
     """tools/fuzz_pair.py: random plants, horizons (1 ... 50), batch sizes, layouts, iteration counts
     and option mixes — k_lane_iterate_pair equals k_lane_iterate bit for bit, fused iterations and
-    solves, with and without stage weights (a 600-case run is profiles/r05_fuzz_pair.txt)."""
+    solves, with and without stage weights in fp64 and fp32 (a 600-case run is profiles/r05_fuzz_pair.txt)."""
     import subprocess
     import sys
     from pathlib import Path

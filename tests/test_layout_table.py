@@ -62,8 +62,9 @@ def test_horizon_buckets_and_precision_are_read():
     # long horizons leave the problem-major kernels early (LDS: 1024 problems per round at N = 50)
     assert rec(default_config("bicycle6", 50, "f64", dt=0.25), 8192) == _abi.LAYOUT_BATCH_TILED
     assert rec(default_config("bicycle6", 20, "f64", dt=0.25), 8192) == _abi.LAYOUT_PROBLEM_MAJOR
-    # fp32 stays on the sixteen-lane kernel longer at N = 20 (no helper-wavefront form in fp32)
-    assert rec(default_config("bicycle6", 20, "f32", dt=0.25), 14336) == _abi.LAYOUT_PROBLEM_MAJOR
+    # fp32 stays on the sixteen-lane kernel longer at N = 20 (half the LDS per problem: rounds of 8192)
+    assert rec(default_config("bicycle6", 20, "f32", dt=0.25), 12288) == _abi.LAYOUT_PROBLEM_MAJOR
+    assert rec(default_config("bicycle6", 20, "f32", dt=0.25), 14336) == _abi.LAYOUT_BATCH_TILED
     assert rec(default_config("bicycle6", 20, "f64", dt=0.25), 10240) == _abi.LAYOUT_BATCH_TILED
     # the reference's shape
     assert rec(default_config("bicycle4", 6, "f64"), 8192) == _abi.LAYOUT_PROBLEM_MAJOR

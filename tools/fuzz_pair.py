@@ -23,7 +23,8 @@ for case in range(cases):
         int(rng.integers(1, 20000))
     if N >= 33 and B > 16384:
         B = 16384 if tiled else 9001
-    cfg = default_config(system, N, "f64", dt=float(rng.choice([0.1, 0.25, 0.5])), layout=2 if tiled else 1)
+    dtype = "f32" if rng.random() < 0.3 else "f64"
+    cfg = default_config(system, N, dtype, dt=float(rng.choice([0.1, 0.25, 0.5])), layout=2 if tiled else 1)
     weights = bool(rng.random() < 0.3)
     if weights:  # stage weights Q, R != 0 (as tools/parity_campaign.py draws them)
         A = rng.normal(0, 0.1, (cfg.n, cfg.n))
@@ -58,7 +59,7 @@ for case in range(cases):
     ok = all(torch.equal(a[key], b[key]) for a, b in zip(outs[0], outs[1])
              for key in ("X", "U", "K", "k", "lamb", "cost", "iters", "status"))
     bad += not ok
-    print(f"case {case:3d} {system} N={N:2d} B={B:6d} {'tiled' if tiled else 'minor'} {'Q,R ' if weights else ''}iters={iters} {opts} "
+    print(f"case {case:3d} {system} {dtype} N={N:2d} B={B:6d} {'tiled' if tiled else 'minor'} {'Q,R ' if weights else ''}iters={iters} {opts} "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
