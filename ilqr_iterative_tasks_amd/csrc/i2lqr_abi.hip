@@ -599,8 +599,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (a.lds_steps > steps) a.lds_steps = steps;
     }
   }
-  // The helper-wavefront form (k_lane_iterate_pair; round 5): fp64 bicycles (stage weights: its HASQR
-  // instantiation), states not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
+  // The helper-wavefront form (k_lane_iterate_pair; round 5): the bicycles in fp64 and fp32 (stage
+  // weights: its HASQR instantiations), states not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
   // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
   static constexpr unsigned kPairMaxGrid = 512;
   static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU

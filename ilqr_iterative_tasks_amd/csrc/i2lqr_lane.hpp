@@ -1825,7 +1825,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
 // problems), and masked lanes do not issue faster.  What CAN run elsewhere is the part of the
 // backward pass that depends on the nominal trajectory only: workgroups of TWO wavefronts, the second
 // one computing every step's record a step ahead of the first (LaneWorker::backward<.., ROLE>).
-// fp64 (HASQR: stage weights, the record grows by l_x), states not checkpointed; same arguments, results bit-identical to k_lane_iterate.
+// fp64 and fp32 (HASQR: stage weights, the record grows by l_x), states not checkpointed; same
+// arguments, results bit-identical to k_lane_iterate.
 template <class T, class Sys, bool HASQR, bool TILED>
 __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
     const DevCfg<T, Sys::n, Sys::m> c, const LaneArgs<T> a) {

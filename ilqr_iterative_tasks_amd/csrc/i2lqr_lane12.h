@@ -33,7 +33,7 @@ namespace i2lqr {
       const DevCfg<REAL, 12, 4>, int64_t, const REAL*, const REAL*, const REAL*,          \
       const REAL*, const REAL*, REAL*, REAL*, REAL*);
 
-// k_lane_iterate_pair (the bicycles' lane kernel with a helper wavefront, fp64): compiled in
+// k_lane_iterate_pair (the bicycles' lane kernel with a helper wavefront): compiled in
 // i2lqr_lanepair.hip
 #define I2LQR_LANEPAIR_KERNELS_(DECL, REAL, QR)                                                   \
   DECL void k_lane_iterate_pair<REAL, Bicycle4<REAL>, QR, false>(const DevCfg<REAL, 4, 2>,        \
