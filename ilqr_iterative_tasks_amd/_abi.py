@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-ABI_VERSION = 2  # 2: i2lqr_argmin / i2lqr_iterate_pick take workspace_bytes
+ABI_VERSION = 3  # 2: i2lqr_argmin / i2lqr_iterate_pick take workspace_bytes; 3: i2lqr_round
 MAX_N = 12
 MAX_M = 4
 MAX_HORIZON = 64
@@ -84,6 +84,39 @@ class I2lqrConfig(C.Structure):
     @property
     def np_dtype(self):
         return np.float64 if self.dtype == F64 else np.float32
+
+
+class I2lqrRound(C.Structure):
+    """`i2lqr_round` (include/i2lqr.h): one sharded control round as ONE call
+    (i2lqr_sharded_round_flat).  Field order and types must match the header."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("n_iters", C.c_int32),
+        ("B", C.c_int64),
+        ("total", C.c_int64),
+        ("world", C.c_int32),
+        ("rank", C.c_int32),
+        ("outer_iter", C.c_int32),
+        ("max_relax_iter", C.c_int32),
+        ("guard_previous", C.c_int32),
+        ("loopback", C.c_int32),
+        ("X", C.c_void_p), ("U", C.c_void_p), ("x_term", C.c_void_p), ("lamb", C.c_void_p),
+        ("obs", C.c_void_p), ("cost", C.c_void_p), ("K", C.c_void_p), ("k", C.c_void_p),
+        ("iters", C.c_void_p), ("status", C.c_void_p), ("qfun", C.c_void_p),
+        ("cost_it", C.c_void_p),
+        ("local_best", C.c_void_p),
+        ("local_best_cost", C.c_void_p),
+        ("pick_ws", C.c_void_p), ("pick_ws_bytes", C.c_int64),
+        ("pack_local", C.c_void_p),
+        ("cost_padded", C.c_void_p),
+        ("cost_all", C.c_void_p),
+        ("pack_all", C.c_void_p),
+        ("side_ws", C.c_void_p), ("side_ws_bytes", C.c_int64),
+        ("best_cost", C.c_void_p),
+        ("winner", C.c_void_p),
+        ("best_global", C.c_void_p),
+    ]
 
 
 def default_config(system="bicycle4", num_horizon=6, dtype="f64", dt=1.0,
@@ -178,6 +211,9 @@ EXPORTS = {
     "i2lqr_pack_problem": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "i2lqr_round_winner": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P,
                                      _P, _P]),
+    "i2lqr_sharded_round_flat": (C.c_int, [_P, _P, C.POINTER(I2lqrRound), _P, _P]),
+    "i2lqr_round_pick": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P,
+                                   _P, _P, C.c_int64, _P]),
 }
 
 _lib = None

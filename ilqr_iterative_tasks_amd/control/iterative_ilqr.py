@@ -97,7 +97,8 @@ class HipCandidateSolver:
 
     def sharded_round(self, cfg, x0, x_terms_local, qfun_local, lamb0, exchange, total,
                       obs_rec=None, n_iters=None, outer_iter=0, max_relax_iter=55, lexi=None,
-                      prepared=None, bufs=None, exchange_stream=None, on_phase=None):
+                      prepared=None, bufs=None, exchange_stream=None, on_phase=None, plan=None,
+                      host_driven=False):
         """ONE sharded control round, device-resident end to end (the loops
         utils/base.py:391-455 sharded, the pick and the hand-off :462-471): this rank holds the
         candidates [lo, hi) = dist.shard_range(total, rank, world) of the round — x_terms_local
@@ -110,11 +111,20 @@ class HipCandidateSolver:
             cost_all   the gathered costs
         Two forms of the pick:
           lexi=None    the flat arg-min (first index wins).  No host round trip: every rank packs
-                       its LOCAL winner (i2lqr_pack_problem) and the packs ride with the costs in
-                       one grouped all-gather (i2lqr_allgather_round); i2lqr_argmin +
-                       i2lqr_round_winner then select on the gathered data.  best_idx is a device
-                       int64[2] = (index, owner rank), cost_all is padded per rank to the largest
-                       shard with +inf.  (dist.flat_round)
+                       its LOCAL winner and the packs ride with the costs in one grouped
+                       all-gather; the pick and the owner's pack are then selected on the gathered
+                       data.  best_idx is a device int64[2] = (index, owner rank), cost_all is
+                       padded per rank to the largest shard with +inf.  Over the library's own
+                       communicator (and in a world of one) the whole round is ONE C-ABI call,
+                       i2lqr_sharded_round_flat (round 6): the launch stream carries the shard's
+                       solve only and everything else is enqueued on the exchange stream from C.
+                       Over torch.distributed (gloo in the CPU tests, torch's NCCL group as the
+                       fallback of a failed native bring-up), or with host_driven=True, the same
+                       steps are driven from Python (dist.flat_round: i2lqr_pack_problem,
+                       exchange.allgather_round, i2lqr_argmin, i2lqr_round_winner) — results are
+                       bit-identical.  A rank WITHOUT candidates (total < world) contributes +inf
+                       costs and a pack of zeros: no rank raises while the others sit in the
+                       collective; total == 0 raises on every rank.
           lexi=(L, k)  the reference's list-of-lists order over L laps of k candidates
                        (i2lqr_pick_best on the gathered vector); the index is read back — the
                        controller's bookkeeping is host state and a broadcast needs its root on the
@@ -124,18 +134,24 @@ class HipCandidateSolver:
                        list-of-lists pick on the gathered costs).
         prepared = (solver, buf, qfun, cost_it): buffers already resident and initialised (bench.py:
         the timed step starts with its inputs in HBM); bufs: preallocated exchange buffers
-        (pack_local, padded, cost_all, pack_all, winner, best_global).  exchange_stream: the
+        (BatchedILQR.round_buffers); plan: a BatchedILQR.plan_round() made from both (the
+        argument block of the one-call form, built once per buffer set).  exchange_stream: the
         exchange and everything behind it is enqueued THERE, behind an event recorded after the
         shard's solve — the next round's solve can then run on the current stream beside it (the
-        results are valid on exchange_stream).  on_phase(name): "solved" on the current stream
-        behind the shard's solve, then see dist.flat_round / lexi_round."""
+        results are valid on exchange_stream).  Without `bufs` / `plan` the round runs on buffers
+        cached per batch size and starts behind the previous round's exchange (guard_previous):
+        reusing them is safe whatever the streams.  on_phase(name): "solved" on the current stream
+        behind the shard's solve, then (host-driven form) see dist.flat_round / lexi_round."""
         from .. import dist as idist
         import torch
-        empty_shard = prepared is None and int(x_terms_local.shape[0]) == 0
-        if empty_shard:  # more ranks than candidates: this rank only takes part in the exchange
-            if lexi is None:
-                raise ValueError("the flat round needs a candidate on every rank (its local "
-                                 "winner rides in the all-gather): use fewer ranks or lexi=")
+        if int(total) < 1:  # (every rank knows `total`: all raise together, before any collective)
+            raise ValueError("a sharded round needs at least one candidate over all ranks")
+        on_phase = on_phase or (lambda name: None)
+        empty_shard = plan is None and prepared is None and int(x_terms_local.shape[0]) == 0
+        if plan is not None:
+            solver, buf, cost_it = plan["solver"], plan["keep"][0], plan["cost_local"]
+            qfun = plan["keep"][1]
+        elif empty_shard:  # more ranks than candidates: this rank only takes part in the exchange
             solver = self._solver(cfg)
             buf, qfun = None, None
             cost_it = torch.zeros(0, dtype=solver.dtype, device=solver.device)
@@ -146,7 +162,6 @@ class HipCandidateSolver:
             solver, buf, qfun, cost_it = prepared
         P = solver.m * solver.N + solver.n * (solver.N + 1)
         import contextlib
-        on_phase = on_phase or (lambda name: None)
 
         def side():  # the exchange's stream: behind everything enqueued so far on the current one
             if exchange_stream is None:
@@ -156,19 +171,53 @@ class HipCandidateSolver:
             exchange_stream.wait_event(ready)
             return torch.cuda.stream(exchange_stream)
 
+        if plan is not None and (lexi is not None or host_driven or
+                                 not idist.native_comm(exchange)[1]):
+            raise ValueError("plan= belongs to the one-call form of the flat round (lexi None, the "
+                             "library's own communicator or a world of one)")
         if lexi is None:
-            lidx, _ = self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
-                                           max_relax_iter, True)
-            on_phase("solved")
-            pack_local = solver.pack_problem(buf, lidx, bufs["pack_local"] if bufs else None)
-            with side():
-                res = idist.flat_round(
-                    exchange, cost_it, pack_local, total,
-                    lambda cost_all: solver.argmin(cost_all, side=True),  # (its own workspace)
-                    lambda width, tot, best, pack_all: solver.round_winner(
-                        exchange.world, width, tot, best, pack_all,
-                        bufs["winner"] if bufs else None, bufs["best_global"] if bufs else None),
-                    bufs, on_phase)
+            comm, one_call = idist.native_comm(exchange)
+            if one_call and not host_driven:
+                if plan is None:
+                    own = bufs is None
+                    if own:  # cached per (solver, shard size, split): reused round after round
+                        key = (id(solver), cost_it.numel(), int(total), exchange.world)
+                        cache = self.__dict__.setdefault("_xbufs", {})
+                        if len(cache) > 8 and key not in cache:
+                            cache.clear()
+                        bufs = cache.setdefault(key, {})
+                    plan = solver.plan_round(buf, qfun, cost_it, total, exchange.world,
+                                             exchange.rank, n_iters, outer_iter, max_relax_iter,
+                                             bufs=bufs, guard_previous=own)
+                solver.round_flat(plan, comm, exchange_stream)
+                if hasattr(exchange, "collectives"):
+                    exchange.collectives += 1
+                on_phase("solved")
+                res = dict(cost_all=plan["cost_all"], best_idx=plan["best_global"],
+                           best_cost=plan["best_cost"], pack=plan["winner"], width=plan["width"])
+            else:
+                if empty_shard:
+                    pack_local = (bufs["pack_local"].zero_() if bufs else
+                                  torch.zeros(P, dtype=solver.dtype, device=solver.device))
+                else:
+                    lidx, _ = self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
+                                                   max_relax_iter, True)
+                on_phase("solved")
+                if not empty_shard:
+                    pack_local = solver.pack_problem(buf, lidx, bufs["pack_local"] if bufs else None)
+                with side():
+                    if exchange_stream is not None:
+                        # handed across streams: the caching allocator must not recycle them for
+                        # the launch stream while the exchange is still queued
+                        for t in (pack_local, cost_it):
+                            t.record_stream(exchange_stream)
+                    res = idist.flat_round(
+                        exchange, cost_it, pack_local, total,
+                        lambda cost_all: solver.argmin(cost_all, side=True),  # (its own workspace)
+                        lambda width, tot, best, pack_all: solver.round_winner(
+                            exchange.world, width, tot, best, pack_all,
+                            bufs["winner"] if bufs else None, bufs["best_global"] if bufs else None),
+                        bufs, on_phase)
         else:
             if not empty_shard:
                 self._solve_and_cost(solver, buf, qfun, cost_it, n_iters, outer_iter,
@@ -183,6 +232,8 @@ class HipCandidateSolver:
                     a, c = (int(v) for v in solver.pick_index(L, k, cost_all).cpu())
                     return a * k + c
             with side():
+                if exchange_stream is not None:
+                    cost_it.record_stream(exchange_stream)
                 res = idist.lexi_round(
                     exchange, cost_it, total, pick,
                     lambda loc: solver.pack_problem(

@@ -150,6 +150,10 @@ struct i2lqr_handle {
   static constexpr unsigned kTickets = 16;
   unsigned* ticket;
   std::atomic<unsigned> ticket_next;
+  // i2lqr_sharded_round_flat: the event that orders the side stream behind the shard's solve and
+  // the one a later round waits for before it reuses the buffers (created on first use)
+  hipEvent_t ev_ready, ev_side_done;
+  bool side_pending;  // ev_side_done has been recorded at least once
 };
 
 namespace {
@@ -1113,6 +1117,83 @@ __global__ __launch_bounds__(256) void k_argmin_final(int nparts, const MinPair<
   }
 }
 
+// ---- sharded round (i2lqr_sharded_round_flat) --------------------------------------------------
+// What a rank contributes to the exchange, ONE launch: workgroup 0 packs the trajectory of the
+// shard's pick (k_pack_problem's gather; zeros for a rank without candidates), and — ragged split
+// only (padded non-null) — all workgroups copy the B costs into the `width` slots every rank
+// gathers and fill the rest with +inf, which never wins the pick.
+template <class T>
+__global__ __launch_bounds__(256) void k_round_prepare(int64_t B, int n, int m, int N, int layout,
+                                                       const T* X, const T* U, const int64_t* idx,
+                                                       T* pack, int64_t width, const T* cost_it,
+                                                       T* padded) {
+  if (padded)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < width; i += (int64_t)gridDim.x * 256)
+      padded[i] = i < B ? cost_it[i] : (T)INFINITY;
+  if (blockIdx.x != 0) return;
+  const int nu = m * N, nx = n * (N + 1);
+  if (B <= 0) {
+    for (int e = threadIdx.x; e < nu + nx; e += 256) pack[e] = T(0);
+    return;
+  }
+  int64_t b = idx[0];
+  if (b < 0) b = 0;
+  if (b >= B) b = B - 1;
+  auto fetch = [&](const T* A, int comps, int T_, int c, int t) -> T {
+    if (layout == 0) return A[(b * comps + c) * T_ + t];
+    if (layout == 1) return A[((int64_t)t * comps + c) * B + b];
+    return A[(((b >> 6) * T_ + t) * comps + c) * 64 + (b & 63)];
+  };
+  for (int e = threadIdx.x; e < nu; e += 256) pack[e] = fetch(U, m, N, e / N, e % N);
+  for (int e = threadIdx.x; e < nx; e += 256)
+    pack[nu + e] = fetch(X, n, N + 1, e / (N + 1), e % (N + 1));
+}
+
+// The pick over the gathered costs and the winner's hand-off in ONE workgroup: k_argmin_partial<T,
+// true> (same total order: the flat arg-min with first-index tie-break, NaN never wins) followed by
+// k_round_winner's translation and copy.
+template <class T>
+__global__ __launch_bounds__(256) void k_round_pick(int world, int64_t width, int64_t total,
+                                                    int64_t pack_count, const T* cost_all,
+                                                    const T* pack_all, T* best_cost, T* winner,
+                                                    int64_t* best_global) {
+  __shared__ T sv[256];
+  __shared__ int64_t si[256];
+  const int64_t G = (int64_t)world * width;
+  T bv = T(0);
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < G; i += 256) {
+    const T v = cost_all[i];
+    if (better(v, i, bv, bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const T ov = sv[threadIdx.x + s];
+      const int64_t oi = si[threadIdx.x + s];
+      if (oi >= 0 && better(ov, oi, sv[threadIdx.x], si[threadIdx.x])) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t p = si[0];
+  const int64_t q = p < 0 ? 0 : p;
+  const int64_t owner = q / width, loc = q - owner * width;
+  const int64_t base = total / world, rem = total - base * world;
+  const int64_t lo = owner * base + (owner < rem ? owner : rem);
+  if (threadIdx.x == 0) {
+    *best_cost = p >= 0 ? sv[0] : (T)INFINITY;
+    best_global[0] = p < 0 ? -1 : lo + loc;
+    best_global[1] = owner;
+  }
+  for (int64_t e = threadIdx.x; e < pack_count; e += 256)
+    winner[e] = pack_all[owner * pack_count + e];
+}
+
 // ---- RCCL, bound at run time ---------------------------------------------------------------
 // The one collective of the path is an all-gather of the candidates' terminal
 // costs.  libi2lqr_hip.so does not link librccl: a process that already carries a copy (PyTorch
@@ -1301,6 +1382,8 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->opt_two_x = -1;
   h->ticket = nullptr;
   h->ticket_next.store(0);
+  h->ev_ready = h->ev_side_done = nullptr;
+  h->side_pending = false;
   constexpr size_t kTicketBytes = i2lqr_handle::kTickets * sizeof(unsigned);
   if (hipGetDevice(&h->device) != hipSuccess ||
       hipMalloc((void**)&h->ticket, kTicketBytes) != hipSuccess ||
@@ -1334,6 +1417,8 @@ int i2lqr_destroy(i2lqr_handle* h) {
                   (void*)h);
   }
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
   delete h;
   return I2LQR_OK;
 }
@@ -1935,6 +2020,151 @@ int i2lqr_broadcast_winner(i2lqr_handle* h, void* comm, void* buf, int64_t count
   RCCL_TRY(api, api.Broadcast(buf, buf, (size_t)count, dt, root, (ncclComm_t)comm,
                               (hipStream_t)stream));
   return I2LQR_OK;
+}
+
+int i2lqr_round_pick(i2lqr_handle* h, int32_t world, int64_t width, int64_t total,
+                     int64_t pack_count, const void* cost_all, const void* pack_all,
+                     void* best_cost, void* winner, int64_t* best_global, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (world < 1 || width < 1 || total < 0 || total > (int64_t)world * width || pack_count < 0)
+    return fail(I2LQR_ERR_INVALID, "need world >= 1, width >= 1, 0 <= total <= world * width, "
+                "pack_count >= 0");
+  const int64_t G = (int64_t)world * width;
+  if (G > (int64_t)0x7fffffff) return fail(I2LQR_ERR_INVALID, "%lld gathered costs", (long long)G);
+  if (!cost_all || !best_cost || !best_global || (pack_count > 0 && (!pack_all || !winner)))
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (G <= kArgminSingle) {
+    if (h->cfg.dtype == I2LQR_F64)
+      hipLaunchKernelGGL((k_round_pick<double>), dim3(1), dim3(256), 0, s, world, width, total,
+                         pack_count, (const double*)cost_all, (const double*)pack_all,
+                         (double*)best_cost, (double*)winner, best_global);
+    else
+      hipLaunchKernelGGL((k_round_pick<float>), dim3(1), dim3(256), 0, s, world, width, total,
+                         pack_count, (const float*)cost_all, (const float*)pack_all,
+                         (float*)best_cost, (float*)winner, best_global);
+    HIP_TRY(hipGetLastError());
+    return I2LQR_OK;
+  }
+  // large gathers: the two-level arg-min, its index parked behind the partial minima
+  const int64_t need = i2lqr_argmin_workspace_bytes(G) + 16;
+  if (!workspace || workspace_bytes < need)
+    return fail(I2LQR_ERR_INVALID, "round-pick workspace of %lld bytes, %lld gathered costs need "
+                "i2lqr_argmin_workspace_bytes + 16 = %lld", (long long)workspace_bytes, (long long)G,
+                (long long)need);
+  int64_t* best_padded = (int64_t*)((char*)workspace + i2lqr_argmin_workspace_bytes(G));
+  if (int rc = i2lqr_argmin(h, G, cost_all, best_padded, best_cost, workspace,
+                            i2lqr_argmin_workspace_bytes(G), stream)) return rc;
+  return i2lqr_round_winner(h, world, width, total, pack_count, best_padded, pack_all, winner,
+                            best_global, stream);
+}
+
+int i2lqr_sharded_round_flat(i2lqr_handle* h, void* comm, const i2lqr_round* r, void* side_stream,
+                             void* stream) {
+  if (!h) return fail(I2LQR_ERR_INVALID, "null handle");
+  if (!r) return fail(I2LQR_ERR_INVALID, "null round");
+  if (r->struct_size != (int32_t)sizeof(i2lqr_round))
+    return fail(I2LQR_ERR_INVALID, "round struct_size %d, library expects %zu", r->struct_size,
+                sizeof(i2lqr_round));
+  if (int rc = check_common(h, r->B)) return rc;
+  if (r->world < 1 || r->rank < 0 || r->rank >= r->world)
+    return fail(I2LQR_ERR_INVALID, "need 0 <= rank < world (got rank %d, world %d)", r->rank, r->world);
+  if (r->total < 1)
+    return fail(I2LQR_ERR_INVALID, "a round needs at least one candidate over all ranks (total %lld)",
+                (long long)r->total);
+  if (!comm && r->world != 1 && !r->loopback)
+    return fail(I2LQR_ERR_INVALID, "a world of %d ranks needs a communicator", r->world);
+  // the contiguous split every rank derives from (total, world): dist.shard_range
+  const int64_t base = r->total / r->world, rem = r->total - base * r->world;
+  const int64_t mine = base + (r->rank < rem ? 1 : 0);
+  const int64_t width = base + (rem ? 1 : 0);
+  if (r->B != mine)
+    return fail(I2LQR_ERR_INVALID, "rank %d of %d owns %lld of %lld candidates, the round says %lld",
+                r->rank, r->world, (long long)mine, (long long)r->total, (long long)r->B);
+  if (width * r->world > (int64_t)0x7fffffff)
+    return fail(I2LQR_ERR_INVALID, "%lld gathered costs", (long long)(width * r->world));
+  const int n = h->cfg.n, m = h->cfg.m, N = h->cfg.N;
+  const int64_t P = (int64_t)m * N + (int64_t)n * (N + 1);
+  if (!r->pack_local || !r->cost_all || !r->pack_all || !r->best_cost || !r->winner ||
+      !r->best_global || (r->B > 0 && (!r->cost_it || !r->local_best || !r->local_best_cost)))
+    return fail(I2LQR_ERR_INVALID, "null buffer");
+  if (r->B != width && !r->cost_padded)
+    return fail(I2LQR_ERR_INVALID, "a ragged split (%lld of width %lld) needs cost_padded",
+                (long long)r->B, (long long)width);
+  if (width * r->world > kArgminSingle &&
+      (!r->side_ws || r->side_ws_bytes < i2lqr_argmin_workspace_bytes(width * r->world) + 16))
+    return fail(I2LQR_ERR_INVALID, "side workspace of %lld bytes, %lld gathered costs need %lld",
+                (long long)r->side_ws_bytes, (long long)(width * r->world),
+                (long long)(i2lqr_argmin_workspace_bytes(width * r->world) + 16));
+  if (h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED && (r->B & 63))
+    return fail(I2LQR_ERR_INVALID, "the batch-tiled layout needs a batch that is a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  hipStream_t ss = side_stream ? (hipStream_t)side_stream : s;
+  const bool two = ss != s;
+  if (two && !h->ev_ready) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+  }
+  if (r->guard_previous && h->side_pending) HIP_TRY(hipStreamWaitEvent(s, h->ev_side_done, 0));
+  // -- the shard (launch stream) -------------------------------------------------------------------
+  if (r->B > 0) {
+    if (r->n_iters >= 0) {
+      if (int rc = i2lqr_iterate_pick(h, r->B, r->n_iters, r->X, r->U, r->x_term, r->lamb, r->obs,
+                                      r->cost, r->K, r->k, r->iters, r->status, r->qfun,
+                                      r->outer_iter, r->max_relax_iter, r->cost_it, r->local_best,
+                                      r->local_best_cost, r->pick_ws, r->pick_ws_bytes, stream))
+        return rc;
+    } else {
+      if (!r->qfun) return fail(I2LQR_ERR_INVALID, "null buffer");
+      if (int rc = i2lqr_solve(h, r->B, r->X, r->U, r->x_term, r->lamb, r->obs, r->cost, r->K, r->k,
+                               r->iters, r->status, stream)) return rc;
+      if (int rc = i2lqr_relax_cost(h, r->B, r->X, r->x_term, r->qfun, r->outer_iter,
+                                    r->max_relax_iter, r->cost_it, stream)) return rc;
+      if (int rc = i2lqr_argmin(h, r->B, r->cost_it, r->local_best, r->local_best_cost, r->pick_ws,
+                                r->pick_ws_bytes, stream)) return rc;
+    }
+  }
+  if (two) {
+    HIP_TRY(hipEventRecord(h->ev_ready, s));
+    HIP_TRY(hipStreamWaitEvent(ss, h->ev_ready, 0));
+  }
+  // -- the exchange (side stream) ------------------------------------------------------------------
+  const bool ragged = r->B != width;
+  {
+    int64_t padblocks = ragged ? (width + 255) / 256 : 1;
+    if (padblocks > 64) padblocks = 64;
+    if (h->cfg.dtype == I2LQR_F64)
+      hipLaunchKernelGGL((k_round_prepare<double>), dim3((unsigned)padblocks), dim3(256), 0, ss, r->B,
+                         n, m, N, (int)h->cfg.layout, (const double*)r->X, (const double*)r->U,
+                         r->local_best, (double*)r->pack_local, width, (const double*)r->cost_it,
+                         ragged ? (double*)r->cost_padded : (double*)nullptr);
+    else
+      hipLaunchKernelGGL((k_round_prepare<float>), dim3((unsigned)padblocks), dim3(256), 0, ss, r->B,
+                         n, m, N, (int)h->cfg.layout, (const float*)r->X, (const float*)r->U,
+                         r->local_best, (float*)r->pack_local, width, (const float*)r->cost_it,
+                         ragged ? (float*)r->cost_padded : (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  const void* src = ragged ? r->cost_padded : r->cost_it;
+  if (comm && !r->loopback) {
+    if (int rc = i2lqr_allgather_round(h, comm, src, r->cost_all, width, r->pack_local, r->pack_all,
+                                       P, (void*)ss)) return rc;
+  } else {  // a world of one without RCCL, or one process playing rank after rank: own slots only
+    const size_t item = h->cfg.dtype == I2LQR_F64 ? 8 : 4;
+    char* ca = (char*)r->cost_all + (size_t)r->rank * (size_t)width * item;
+    char* pa = (char*)r->pack_all + (size_t)r->rank * (size_t)P * item;
+    HIP_TRY(hipMemcpyAsync(ca, src, (size_t)width * item, hipMemcpyDeviceToDevice, ss));
+    HIP_TRY(hipMemcpyAsync(pa, r->pack_local, (size_t)P * item, hipMemcpyDeviceToDevice, ss));
+  }
+  if (int rc = i2lqr_round_pick(h, r->world, width, r->total, P, r->cost_all, r->pack_all,
+                                r->best_cost, r->winner, r->best_global, r->side_ws,
+                                r->side_ws_bytes, (void*)ss)) return rc;
+  if (two) {
+    HIP_TRY(hipEventRecord(h->ev_side_done, ss));
+    h->side_pending = true;
+  }
+  return debug_check(I2LQR_OK, (void*)ss);
 }
 
 }  // extern "C"

@@ -429,6 +429,19 @@ class TorchExchange:
         pass
 
 
+def native_comm(exchange):
+    """(communicator, usable) for the one-call form of the flat round (i2lqr_sharded_round_flat):
+    the library's own RCCL communicator of a CostExchange (also behind a ShardedRound), or
+    (None, True) for a world of one over torch.distributed (the gathers become device copies);
+    (None, False) for every other exchange — those rounds are driven from Python (flat_round)."""
+    ex = getattr(exchange, "exchange", exchange)  # ShardedRound -> what it wraps
+    if isinstance(ex, CostExchange):
+        return ex._comm, ex._comm is not None
+    if isinstance(ex, TorchExchange) and ex.world == 1:
+        return None, True
+    return None, False
+
+
 def padded_width(total: int, world: int) -> int:
     """Largest shard of shard_range(total, ., world): what every rank pads its costs to."""
     return (total + world - 1) // world

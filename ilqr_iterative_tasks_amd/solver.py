@@ -406,6 +406,116 @@ class BatchedILQR:
                 self._ptr(best_global, (2,), torch.int64, name="best_global"), self._stream()))
         return winner, best_global
 
+    # -- one sharded round as ONE C-ABI call (i2lqr_sharded_round_flat) -------------------------
+    def round_buffers(self, B: int, total: int, world: int, bufs: dict | None = None) -> dict:
+        """Exchange buffers of one sharded round in flight (see plan_round): the local winner's
+        pack, the padded cost vector of a ragged split, the gathered costs and packs, the two pick
+        workspaces and the outputs.  `bufs`: a partly filled dict, completed in place."""
+        P = self.m * self.N + self.n * (self.N + 1)
+        width = (total + world - 1) // world
+        z = lambda *shape, dtype=None: torch.zeros(*shape, dtype=dtype or self.dtype,
+                                                   device=self.device)
+        ws = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        make = dict(
+            pack_local=lambda: z(P), cost_all=lambda: z(world * width), pack_all=lambda: z(world, P),
+            winner=lambda: z(P), best_global=lambda: z(2, dtype=torch.int64),
+            best_cost=lambda: z(1), local_best=lambda: z(1, dtype=torch.int64),
+            local_best_cost=lambda: z(1),
+            pick_ws=lambda: ws(self.lib.i2lqr_argmin_workspace_bytes(max(B, 1))),
+            side_ws=lambda: ws(self.lib.i2lqr_argmin_workspace_bytes(world * width) + 16))
+        if B != width:
+            make["padded"] = lambda: z(width)
+        bufs = {} if bufs is None else bufs
+        for key, fn in make.items():
+            if bufs.get(key) is None:
+                bufs[key] = fn()
+        return bufs
+
+    def plan_round(self, buf: dict | None, qfun, cost_it, total: int, world: int, rank: int,
+                   n_iters: int | None, outer_iter: int = 0, max_relax_iter: int = 55,
+                   bufs: dict | None = None, guard_previous: bool = True,
+                   loopback: bool = False) -> dict:
+        """The argument block of i2lqr_sharded_round_flat for this rank's shard `buf` (None: a rank
+        without candidates) — built once for a buffer set, enqueued with round_flat() as often as
+        the round is run on it.  Returns the plan: the ctypes struct, the tensors it points to (kept
+        alive) and the round's outputs `best_global` int64[2] = (index, owner), `best_cost`,
+        `winner` [P], `cost_all` [world x width]."""
+        B = self.batch_of(buf["X"]) if buf is not None else 0
+        if buf is not None:
+            self.ensure_workspace(B)
+        bufs = self.round_buffers(B, total, world, bufs)
+        width = (total + world - 1) // world
+        P = self.m * self.N + self.n * (self.N + 1)
+        r = _abi.I2lqrRound()
+        r.struct_size = C.sizeof(_abi.I2lqrRound)
+        r.n_iters = -1 if n_iters is None else int(n_iters)
+        r.B, r.total, r.world, r.rank = B, int(total), int(world), int(rank)
+        r.outer_iter, r.max_relax_iter = int(outer_iter), int(max_relax_iter)
+        r.guard_previous = 1 if guard_previous else 0
+        r.loopback = 1 if loopback else 0  # (tests: one process plays the ranks one after the other)
+        val = lambda p: p.value  # c_void_p -> int or None
+        if buf is not None:
+            X, U, xt, lamb, obs, cost, K, k, iters, status = (val(p) for p in self._iter_args(buf, B))
+            r.X, r.U, r.x_term, r.lamb, r.obs, r.cost = X, U, xt, lamb, obs, cost
+            r.K, r.k, r.iters, r.status = K, k, iters, status
+            r.qfun = val(self._ptr(qfun, (B,), torch.int32, name="qfun"))
+            r.cost_it = val(self._ptr(cost_it, (B,), name="cost_it"))
+        r.local_best = bufs["local_best"].data_ptr()
+        r.local_best_cost = bufs["local_best_cost"].data_ptr()
+        r.pick_ws, r.pick_ws_bytes = bufs["pick_ws"].data_ptr(), bufs["pick_ws"].numel()
+        r.pack_local = val(self._ptr(bufs["pack_local"], (P,), name="pack_local"))
+        if bufs.get("padded") is not None:
+            r.cost_padded = val(self._ptr(bufs["padded"], (width,), name="padded"))
+        r.cost_all = val(self._ptr(bufs["cost_all"], (world * width,), name="cost_all"))
+        r.pack_all = val(self._ptr(bufs["pack_all"].reshape(world, P), (world, P), name="pack_all"))
+        r.side_ws, r.side_ws_bytes = bufs["side_ws"].data_ptr(), bufs["side_ws"].numel()
+        r.best_cost = val(self._ptr(bufs["best_cost"], (1,), name="best_cost"))
+        r.winner = val(self._ptr(bufs["winner"], (P,), name="winner"))
+        r.best_global = val(self._ptr(bufs["best_global"], (2,), torch.int64, name="best_global"))
+        return dict(round=r, ref=C.byref(r), solver=self, keep=(buf, qfun, cost_it, bufs), bufs=bufs,
+                    width=width,
+                    best_global=bufs["best_global"], best_cost=bufs["best_cost"],
+                    winner=bufs["winner"], cost_all=bufs["cost_all"], cost_local=cost_it)
+
+    def round_flat(self, plan: dict, comm=None, side_stream=None, device_is_current: bool = False):
+        """Enqueue ONE sharded round (i2lqr_sharded_round_flat): the shard's solve + relaxed costs +
+        local pick on the current stream; the local winner's pack, the grouped all-gather of costs
+        and packs over `comm` (an RCCL communicator as c_void_p, None: a world of one) and the pick
+        + hand-off on `side_stream` (None: the current stream too).  The outputs are the tensors of
+        the plan.  device_is_current: skip the device guard (hot loops that set the device once)."""
+        main = torch.cuda.current_stream(self.device).cuda_stream
+        side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else C.c_void_p(None)
+        if device_is_current:
+            rc = self.lib.i2lqr_sharded_round_flat(self._handle, comm, plan["ref"], side,
+                                                   C.c_void_p(main))
+        else:
+            with torch.cuda.device(self.device):
+                rc = self.lib.i2lqr_sharded_round_flat(self._handle, comm, plan["ref"], side,
+                                                       C.c_void_p(main))
+        self._check(rc)
+        return plan
+
+    def round_pick(self, world: int, width: int, total: int, cost_all, pack_all, best_cost=None,
+                   winner=None, best_global=None, workspace=None):
+        """i2lqr_round_pick: the pick over the world x width gathered costs and the owner's pack in
+        one call (one launch up to 16384 gathered costs)."""
+        P = pack_all.numel() // world
+        best_cost = self.empty(1) if best_cost is None else best_cost
+        winner = self.empty(P) if winner is None else winner
+        best_global = self.empty(2, dtype=torch.int64) if best_global is None else best_global
+        if workspace is None:
+            workspace = torch.empty(int(self.lib.i2lqr_argmin_workspace_bytes(world * width)) + 16,
+                                    dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_round_pick(
+                self._handle, int(world), int(width), int(total), P,
+                self._ptr(cost_all, (world * width,), name="cost_all"),
+                self._ptr(pack_all.reshape(world, P), (world, P), name="pack_all"),
+                self._ptr(best_cost, (1,), name="best_cost"), self._ptr(winner, (P,), name="winner"),
+                self._ptr(best_global, (2,), torch.int64, name="best_global"),
+                C.c_void_p(workspace.data_ptr()), C.c_int64(workspace.numel()), self._stream()))
+        return best_cost, winner, best_global
+
     def _argmin_workspace(self, B: int, side: bool = False) -> tuple:
         """(pointer, bytes) of the pick's device scratch, grown to i2lqr_argmin_workspace_bytes(B);
         the size travels with the pointer and the library refuses a workspace that is too small.

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define I2LQR_ABI_VERSION 2
+#define I2LQR_ABI_VERSION 3
 #define I2LQR_MAX_N 12
 #define I2LQR_MAX_M 4
 #define I2LQR_MAX_HORIZON 64
@@ -476,6 +476,78 @@ int i2lqr_allgather_round(i2lqr_handle* h, void* comm, const void* cost_local, v
 int i2lqr_round_winner(i2lqr_handle* h, int32_t world, int64_t width, int64_t total,
                        int64_t pack_count, const int64_t* best_padded, const void* pack_all,
                        void* winner, int64_t* best_global, void* stream);
+
+/*
+ * ONE sharded control round with the flat pick as ONE call (round 6): what a rank does
+ * for utils/base.py:391-471 — the candidate loops over its shard, the pick over all ranks' costs and
+ * "go on with the winner's trajectory" — enqueued from C without a host step between the launches:
+ *
+ *   on `stream`       [guard_previous: wait for the side stream of the previous round on this handle]
+ *                     n_iters >= 0: i2lqr_iterate_pick(B, n_iters, ..., cost_it, local_best, ...)
+ *                     n_iters <  0: i2lqr_solve + i2lqr_relax_cost + i2lqr_argmin
+ *                     event record
+ *   on `side_stream`  wait for that event; pack of the LOCAL winner (i2lqr_pack_problem) and, for a
+ *                     ragged split, the +inf padding of the costs to `width` = ceil(total / world)
+ *                     (one launch); the grouped all-gather of costs and packs
+ *                     (i2lqr_allgather_round); the pick over the world x width gathered costs and
+ *                     the winner's hand-off (i2lqr_round_pick); event record.
+ *
+ * With side_stream != stream the launch stream carries the shard's solve only — the same single
+ * launch per round as the unsharded i2lqr_iterate_pick — and the exchange of round i runs beside
+ * the solve of round i + 1.  side_stream NULL (or == stream): everything on `stream`.
+ * comm NULL is a world of one without RCCL (the gathers become device copies), or any world with
+ * round->loopback set (see there).
+ * A rank with B == 0 (more ranks than candidates) takes part in the exchange with `width` costs of
+ * +inf and a pack of zeros: no rank raises while the others wait in the collective.
+ * Buffers: every pointer of i2lqr_round is device memory owned by the caller and must stay valid
+ * and UNTOUCHED by other work until the side stream has passed this round.  A caller that reuses
+ * one buffer set round after round sets guard_previous = 1: the round then starts behind the
+ * previous round's side stream (handle-owned event) instead of racing it; a caller that gives
+ * every round in flight its own buffers (bench.py) sets 0 and keeps the overlap.
+ * Outputs, identical on every rank: best_global[2] = {index of the winner in the unpadded batch of
+ * `total` candidates (-1: nothing can win), owner rank}, best_cost[1], winner[P] = the winner's
+ * (U[m][N], X[n][N+1]), P = m N + n (N + 1); cost_all[world * width] (padded with +inf per rank).
+ * Results are bit-identical to the five separate calls (tests/test_gpu_round6.py).
+ *
+ * i2lqr_round_pick — i2lqr_argmin over cost_all[world * width] followed by i2lqr_round_winner, as
+ *   ONE launch up to 16384 gathered costs (two + one above); `workspace` as for i2lqr_argmin over
+ *   world * width elements plus 16 bytes.
+ */
+typedef struct i2lqr_round {
+  int32_t struct_size;      /* = sizeof(i2lqr_round) */
+  int32_t n_iters;          /* fused iterations per candidate; < 0: solve to termination */
+  int64_t B;                /* candidates of THIS rank: shard_range(total, rank, world) */
+  int64_t total;            /* candidates of the round over all ranks (>= 1) */
+  int32_t world, rank;      /* of `comm` */
+  int32_t outer_iter, max_relax_iter; /* as i2lqr_relax_cost */
+  int32_t guard_previous;   /* 1: start behind the previous round's side stream (see above) */
+  int32_t loopback;         /* 0; 1: NO collective — this rank's costs and pack are copied into
+                               ITS slots of cost_all / pack_all and the other slots stay as the
+                               caller left them: one process can play the ranks of a world one
+                               after the other on shared gather buffers (tests; comm unused) */
+  /* the shard: as i2lqr_iterate_pick (all NULL-able ones may be NULL; all unused when B == 0) */
+  void* X; void* U; const void* x_term; void* lamb; const void* obs; void* cost;
+  void* K; void* k; int32_t* iters; int32_t* status; const int32_t* qfun;
+  void* cost_it;            /* [B] out */
+  int64_t* local_best;      /* [1] out: the shard's pick */
+  void* local_best_cost;    /* [1] out */
+  void* pick_ws; int64_t pick_ws_bytes;   /* >= i2lqr_argmin_workspace_bytes(B) */
+  /* the exchange */
+  void* pack_local;         /* [P] */
+  void* cost_padded;        /* [width]; may be NULL when B == width */
+  void* cost_all;           /* [world * width] out */
+  void* pack_all;           /* [world * P] */
+  void* side_ws; int64_t side_ws_bytes;   /* >= i2lqr_argmin_workspace_bytes(world * width) + 16 */
+  void* best_cost;          /* [1] out */
+  void* winner;             /* [P] out */
+  int64_t* best_global;     /* [2] out */
+} i2lqr_round;
+int i2lqr_sharded_round_flat(i2lqr_handle* h, void* comm, const i2lqr_round* round,
+                             void* side_stream, void* stream);
+int i2lqr_round_pick(i2lqr_handle* h, int32_t world, int64_t width, int64_t total,
+                     int64_t pack_count, const void* cost_all, const void* pack_all,
+                     void* best_cost, void* winner, int64_t* best_global, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 
 /*
  * Controller round on the device (problem-major layout).

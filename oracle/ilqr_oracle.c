@@ -714,6 +714,7 @@ void orc_quu_inverse_reg(int m, const double* Quu, double lamb, double* inv) {
   quu_inverse_reg(m, Quu, lamb, inv);
 }
 int orc_config_size(void) { return (int)sizeof(cfg_t); }
+int orc_round_size(void) { return (int)sizeof(i2lqr_round); }  /* tests/test_abi.py: ctypes mirror */
 
 /* Threads used by orc_ilqr_batch (OpenMP); 0 restores the runtime default.  Returns the count in
  * effect. */

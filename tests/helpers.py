@@ -84,7 +84,7 @@ class OracleCandidateSolver:
 
     def sharded_round(self, cfg, x0, x_terms_local, qfun_local, lamb0, exchange, total,
                       obs_rec=None, n_iters=None, outer_iter=0, max_relax_iter=55, lexi=None,
-                      prepared=None, bufs=None):
+                      prepared=None, bufs=None, **_unused):
         """The double of HipCandidateSolver.sharded_round on CPU tensors: the shard's solves and
         relaxed costs from the oracle, the exchange through the SAME dist.lexi_round /
         dist.flat_round the product runs (gloo process group)."""
@@ -108,7 +108,12 @@ class OracleCandidateSolver:
             return torch.as_tensor(np.concatenate([out["U"][loc].ravel(), out["X"][loc].ravel()]))
 
         if lexi is None:
-            lidx, _ = idist.select_best_flat(cost_t)
+            if int(total) < 1:
+                raise ValueError("a sharded round needs at least one candidate over all ranks")
+            # a rank without candidates contributes +inf costs (flat_round pads) and a zero pack,
+            # as HipCandidateSolver.sharded_round does: nobody raises while the others gather
+            local_pack = pack_of(idist.select_best_flat(cost_t)[0]) if n_local else \
+                torch.zeros(nu + nx, dtype=torch.float64)
 
             def argmin(c):
                 i, v = idist.select_best_flat(c)
@@ -119,7 +124,7 @@ class OracleCandidateSolver:
                 lo, _ = idist.shard_range(tot, owner, exchange.world)
                 return pack_all[owner].clone(), torch.tensor([lo + loc, owner])
 
-            res = idist.flat_round(exchange, cost_t, pack_of(lidx), total, argmin, round_winner)
+            res = idist.flat_round(exchange, cost_t, local_pack, total, argmin, round_winner)
         else:
             if callable(lexi):
                 pick = lexi

@@ -35,6 +35,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_config_struct_matches_the_header():
     from oracle import oracle as orc  # compiled against include/i2lqr.h: sizeof() from the C side
     assert orc.lib().orc_config_size() == C.sizeof(_abi.I2lqrConfig)
+    orc.lib().orc_round_size.restype = C.c_int
+    assert orc.lib().orc_round_size() == C.sizeof(_abi.I2lqrRound)  # i2lqr_round (round 6)
     for macro, val in (("I2LQR_MAX_N", _abi.MAX_N), ("I2LQR_MAX_M", _abi.MAX_M),
                        ("I2LQR_MAX_HORIZON", _abi.MAX_HORIZON), ("I2LQR_OBS_WORDS", _abi.OBS_WORDS)):
         assert int(re.search(rf"#define {macro} (\d+)", HEADER).group(1)) == val

@@ -363,13 +363,14 @@ def _flat_round_worker(rank, world, port, total, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [12, 13])
+@pytest.mark.parametrize("total", [12, 13, 1])
 def test_flat_sharded_round_world2_hands_the_winner_over_inside_the_all_gather(tmp_path, total):
     """dist.flat_round (what HipCandidateSolver.sharded_round and bench.py --gpus N run) on two
     ranks, gloo, oracle-backed double: every rank packs its LOCAL winner, ONE exchange carries the
     costs and the packs, and both ranks end with the index of the global first-index arg-min and
     ITS trajectory — equal to what one process finds over all candidates.  13 candidates: ragged
-    shards (7 + 6), the short one padded with +inf."""
+    shards (7 + 6), the short one padded with +inf.  ONE candidate: rank 1 owns none and takes part
+    with +inf and a pack of zeros (it used to raise while rank 0 waited in the gather)."""
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent))
