@@ -17,6 +17,7 @@
 
 #include "../../include/i2lqr.h"
 #include "i2lqr_devcfg.hpp"
+#include "i2lqr_geometry.hpp"
 #include "i2lqr_group.h"
 #include "i2lqr_lane.hpp"
 #include "i2lqr_select.hpp"
@@ -48,6 +49,47 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 namespace i2lqr {
+// hipDeviceGetAttribute once per device; I2LQR_FAKE_CUS=<n> (a debug override, parity tests of the
+// derived thresholds on the full chip) replaces the CU count.
+const DeviceGeometry& device_geometry() {
+  constexpr int kMaxDev = 64;
+  static DeviceGeometry table[kMaxDev];
+  static std::once_flag once[kMaxDev];
+  static const DeviceGeometry fallback{};  // no device visible: the MI355X figures
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+    (void)hipGetLastError();
+    return fallback;
+  }
+  std::call_once(once[dev], [dev] {
+    DeviceGeometry g;
+    int v = 0;
+    bool ok = true;
+    auto attr = [&](hipDeviceAttribute_t a) {
+      v = 0;
+      const bool got = hipDeviceGetAttribute(&v, a, dev) == hipSuccess && v > 0;
+      if (!got) (void)hipGetLastError();
+      return got;
+    };
+    if (attr(hipDeviceAttributeMultiprocessorCount)) g.cus = v; else ok = false;
+    if (attr(hipDeviceAttributeWarpSize)) g.wave = v; else ok = false;
+    if (attr(hipDeviceAttributeMaxSharedMemoryPerMultiprocessor)) g.lds_per_cu = (size_t)v; else ok = false;
+    // what one workgroup can be given: the whole CU's LDS on CDNA (opt-in above the default)
+    g.max_dyn_lds = g.lds_per_cu;
+    if (attr(hipDeviceAttributeMaxSharedMemoryPerBlock)) {
+      g.default_dyn_lds = (size_t)v < g.lds_per_cu ? (size_t)v : g.lds_per_cu;
+      if (g.default_dyn_lds > 64 * 1024) g.default_dyn_lds = 64 * 1024;  // opt-in needed above 64 KiB
+    }
+    g.queried = ok ? 1 : 0;
+    if (const char* e = getenv("I2LQR_FAKE_CUS")) {
+      const long f = strtol(e, nullptr, 10);
+      if (f >= 1 && f <= 4096) { g.cus = (int)f; g.faked = 1; }
+    }
+    table[dev] = g;
+  });
+  return table[dev];
+}
+
 #ifdef I2LQR_DEBUG
 unsigned long long* debug_trap_word() {
   constexpr int kMaxDev = 64;
@@ -122,7 +164,7 @@ struct i2lqr_handle {
   // scheduling options of the one-problem-per-lane kernels (i2lqr_set_option); -1 = automatic
   int opt_defer, opt_reroll, opt_lds_steps, opt_merge, opt_ckpt, opt_stagger;
   int wave_tail;  // chunked solve: finish <= this many survivors with one problem per wavefront (0: off, -1: automatic)
-  int opt_pair;  // bicycles' lane kernel, fp64: workgroups of two wavefronts (main + helper); -1 = automatic
+  int opt_pair;  // bicycles' lane kernel (fp64 and fp32, with or without stage weights): workgroups of two wavefronts (main + helper); -1 = automatic
   int opt_two_x;  // ... its second state buffer (no re-roll of accepted steps); -1 = automatic
   int opt_chunk_step;  // chunked solve: length of the chunk that follows the first (automatic: 4); a schedule to measure against
   int opt_first_chunk;  // chunked solve: pinned length of the first chunk, no extension chunks (a hand-tuned schedule to measure the data-driven one against); -1 = automatic
@@ -154,6 +196,7 @@ struct i2lqr_handle {
   // the one a later round waits for before it reuses the buffers (created on first use)
   hipEvent_t ev_ready, ev_side_done;
   bool side_pending;  // ev_side_done has been recorded at least once
+  DeviceGeometry geo;  // of h->device, queried in i2lqr_create (i2lqr_geometry.hpp)
 };
 
 namespace {
@@ -165,6 +208,7 @@ namespace {
 // Which fused kernel a problem-major call runs on: ONE function, used by the launchers and by
 // i2lqr_iterate_kernel / i2lqr_solve_kernel (what bench.py labels its results with).
 enum FusedKernel { K_WAVE, K_GROUP, K_GROUP16, K_GROUP_WS, K_SPEC, K_SPEC16, K_QUAD, K_INVALID };
+// (measured on the 256-CU chip; DeviceGeometry::scaled() elsewhere)
 constexpr int64_t kAutoGroupBatch = 1024;  // eight-lane kernel from here (automatic)
 constexpr int64_t kAutoSpecBatch = 12288;  // speculative form for solves up to here (automatic)
 
@@ -183,7 +227,7 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     const bool can = group_supported(h->cfg);
     if (h->opt_group == 8 && !can) {
       *why = "\"group_lanes\" = 8 needs a bicycle plant with Q = R = 0 and a horizon whose eight "
-             "problem slices fit the 160 KiB of LDS";
+             "problem slices fit a CU's LDS";
       return K_INVALID;
     }
     // Speculative form (k_group_spec): two or three wavefronts per eight problems run the
@@ -200,12 +244,12 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     const bool can_spec = spec16 ? can_spec16 : can_spec8;
     if (h->opt_spec == 1 && !can_spec) {
       *why = "\"speculate\" = 1 needs the eight- / sixteen-lane kernel and a horizon whose speculative "
-             "buffers fit the 160 KiB of LDS";
+             "buffers fit a CU's LDS";
       return K_INVALID;
     }
     if (can_spec && h->opt_group != 64 &&
         (h->opt_spec == 1 ||
-         (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= kAutoSpecBatch)))
+         (h->opt_spec < 0 && h->opt_group < 0 && early_exit && B <= h->geo.scaled(kAutoSpecBatch))))
       return spec16 ? K_SPEC16 : K_SPEC;
     // Sixteen lanes per problem (one problem per DPP row; GroupWorker::backward_row / forward_row):
     // no LDS round trip in the serial chains.  Four problems per wavefront: automatic for every
@@ -216,7 +260,7 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     const bool can16 = group16_supported(h->cfg);  // (four slices: longer horizons than `can`)
     if (h->opt_group == 16 && !can16) {
       *why = "\"group_lanes\" = 16 needs a bicycle plant with Q = R = 0 and a horizon whose four "
-             "problem slices fit the 160 KiB of LDS";
+             "problem slices fit a CU's LDS";
       return K_INVALID;
     }
     // Beyond one round of 1024 wavefronts the sixteen-lane kernel runs in rounds (0.168 ms per 4096
@@ -225,11 +269,11 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
     // workspace registered.
     const int64_t need = can ? group_workspace_bytes(h->cfg, B) : 0;
     const bool have_ws = need > 0 && h->ws && h->ws_bytes >= need;
-    const bool ws_range = B > kGroupWsBatch && B <= group_ws_top(h->cfg);
+    const bool ws_range = B > h->geo.scaled(kGroupWsBatch) && B <= h->geo.scaled(group_ws_top(h->cfg));
     if (h->opt_group == 16 ||
         (h->opt_group < 0 && can16 && h->opt_group_ws != 1 && !(ws_range && can && have_ws)))
       return K_GROUP16;
-    if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= kAutoGroupBatch)) {
+    if (h->opt_group == 8 || (h->opt_group < 0 && can && B >= h->geo.scaled(kAutoGroupBatch))) {
       // "group_workspace" 0 / 1 pins the choice of the eight-lane form
       if (h->opt_group_ws == 1 && !have_ws) {
         *why = "\"group_workspace\" = 1 needs a registered workspace of i2lqr_workspace_bytes() "
@@ -237,7 +281,7 @@ FusedKernel select_fused(const i2lqr_handle* h, int64_t B, bool early_exit, cons
         return K_INVALID;
       }
       if (have_ws && (h->opt_group_ws == 1 ||
-                      (h->opt_group_ws < 0 && (ws_range || (h->opt_group == 8 && B > kGroupWsBatch)))))
+                      (h->opt_group_ws < 0 && (ws_range || (h->opt_group == 8 && B > h->geo.scaled(kGroupWsBatch))))))
         return K_GROUP_WS;
       return K_GROUP;
     }
@@ -273,16 +317,15 @@ template <class T, class Sys> struct Launch {
     return (size_t)Layout<Sys>(N, true).total * sizeof(T) * (64 / LANES);
   }
   static constexpr bool kHasFstep = Sys::n <= 6;  // the bicycles; quad12's F is 1.5 KB per step
-  static constexpr int kCUs = 256;
   static unsigned grid(int64_t B) { return (unsigned)((B + (64 / LANES) - 1) / (64 / LANES)); }
 
   static int prepare(i2lqr_handle* h) {
     h->lanes = LANES;
     h->lds_bytes = lds_bytes(h->cfg.N);
-    if (h->lds_bytes > 160 * 1024)
-      return fail(I2LQR_ERR_UNSUPPORTED, "horizon %d needs %zu B of LDS per wavefront (> 160 KiB)",
-                  h->cfg.N, h->lds_bytes);
-    if (h->lds_bytes > 64 * 1024) {
+    if (h->lds_bytes > h->geo.max_dyn_lds)
+      return fail(I2LQR_ERR_UNSUPPORTED, "horizon %d needs %zu B of LDS per wavefront (> %zu KiB)",
+                  h->cfg.N, h->lds_bytes, h->geo.max_dyn_lds / 1024);
+    if (h->lds_bytes > h->geo.default_dyn_lds) {
       const int bytes = (int)h->lds_bytes;
       HIP_TRY(hipFuncSetAttribute((const void*)k_iterate<T, Sys, LANES, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -384,9 +427,10 @@ template <class T, class Sys> struct Launch {
     // Jacobian refresh) double the LDS slice: taken when every wavefront of the launch still fits
     // on the chip at once, i.e. in the latency-bound regime this variant exists for.
     const size_t lds_f = fstep_lds_bytes(h->cfg.N);
-    const int64_t waves_per_cu = (grid(B) + kCUs - 1) / kCUs;
-    const bool fstep = kHasFstep && lds_f <= 64 * 1024 &&
-                       (h->opt_fstep >= 0 ? h->opt_fstep != 0 : waves_per_cu * lds_f <= 150 * 1024);
+    const int64_t waves_per_cu = (grid(B) + h->geo.cus - 1) / h->geo.cus;
+    const bool fstep = kHasFstep && lds_f <= h->geo.default_dyn_lds &&
+                       (h->opt_fstep >= 0 ? h->opt_fstep != 0
+                                          : waves_per_cu * lds_f <= h->geo.lds_per_cu - 10 * 1024);
     if constexpr (kHasFstep) {
       if (fstep) {
         if (c.flags)
@@ -408,6 +452,7 @@ template <class T, class Sys> struct Launch {
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
   }
+  static int names_pair(i2lqr_handle*, int64_t, int) { return 0; }
   static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      hipStream_t s) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
@@ -453,6 +498,7 @@ template <class T, class Sys> struct Launch {
 
 // Batch-minor / batch-tiled layouts: one problem per lane (i2lqr_lane.hpp).
 template <class T, class Sys, bool TILED> struct LaneLaunch {
+  // (measured on the 256-CU chip: DeviceGeometry::scaled() where they are used)
   static constexpr int kAutoWaveTail = 2048;
   static constexpr int kAutoSpecTail = 12288;  // (round 5: 8192; tools/solve_bench.py --plans)
   static constexpr int64_t kAutoCompactBatch = 4096;
@@ -504,7 +550,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   };
   static void carve(i2lqr_handle* h, int64_t B, LaneArgs<T>& a, Carved* cv = nullptr) {
     const int N = h->cfg.N;
-    T* p = (T*)h->ws;
+    // (no workspace registered: names_pair() carves on scratch arguments that are never launched —
+    // a non-null base keeps the pointer arithmetic defined)
+    static char no_ws[16];
+    T* p = (T*)(h->ws ? h->ws : (void*)no_ws);
     a.wsU = p; p += B * (int64_t)(m * N);
     a.wsK = p; p += B * (int64_t)(m * n * N);
     a.wsk = p; p += B * (int64_t)(m * N);
@@ -512,7 +561,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // set, which no launch uses while a kernel iterates on other arrays (solve_compacting() hands
     // every chunk the states of the work set it does NOT run on)
     a.wsX = h->opt_two_x != 0 ? p : nullptr;
-    a.two_max = 64 * (int)(h->opt_two_x == 1 ? kPairMaxGrid : kTwoXMaxGrid);
+    a.two_max = 64 * (int)(h->opt_two_x == 1 ? pair_max_grid(h->geo) : two_x_max_grid(h->geo));
     a.count_lo = -1;
     a.count_hi = 0x7fffffff;
     a.count = nullptr;
@@ -522,9 +571,12 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // of wavefronts per CU (one per SIMD, four per CU) resident in the 160 KiB: 36 KiB each, i.e.
     // 5 steps in fp64 and 10 in fp32 at n=6, m=2.
     const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-    a.lds_steps = (36 * 1024 - kK0Bytes) / per_step;  // steps 1..lds_steps; k_0 sits behind them
+    a.lds_steps = ((int)h->geo.lds_per_simd_wave() - kK0Bytes) / per_step;  // steps 1..lds_steps; k_0 sits behind them
+    if (a.lds_steps < 0) a.lds_steps = 0;
     if (a.lds_steps > N - 1) a.lds_steps = N - 1;
-    a.reroll = B >= 32768 ? 1 : 0;  // pays only where the kernel sits on the HBM roof
+    // (batch sizes in units of the chip: full = one wavefront per SIMD, 65536 problems on 256 CUs)
+    const int64_t full = h->geo.full_batch();
+    a.reroll = B >= full / 2 ? 1 : 0;  // pays only where the kernel sits on the HBM roof (32768)
     a.defer = 1;  // the forward pass stores no states; accepted steps re-roll them (see i2lqr_lane.hpp)
     // ... and merge the accepted candidate inputs into the one input buffer.  fp64 (HBM-bound):
     // 7.56 -> 7.23 KB per problem-iteration, +4.8 % it/s at 2^20 problems; fp32 (instruction-bound):
@@ -532,14 +584,14 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // ~40000 problems the fp64 kernel is instruction-bound as well (one or two wavefronts per CU):
     // 226 -> 237 M it/s at 12800 problems without the merge, 411 -> 426 at 24576, 528 -> 545 at
     // 32768, +-0 from 40960 to 57344, 811 -> 846 WITH it at 65536.
-    a.merge = sizeof(T) == 8 && B > 32768 ? 1 : 0;
+    a.merge = sizeof(T) == 8 && B > full / 2 ? 1 : 0;
     if (h->opt_merge >= 0) a.merge = h->opt_merge;
     a.ckpt = 0;  // decided in finish_options() once the other options are final
     a.stagger = 0;
     if constexpr (Sys::NBLK > 0) {
       // automatic where the launch fills the chip (one wavefront per SIMD: 65536 problems)
-      a.stagger = B >= 65536 ? 45 : 0;
-    } else if (sizeof(T) == 8 && B > 960 * 64 && B <= 1280 * 64) {
+      a.stagger = B >= full ? 45 : 0;
+    } else if (sizeof(T) == 8 && B > full * 15 / 16 && B <= full * 5 / 4) {
       // bicycles, fp64, a launch of about one wavefront per SIMD: +3 % (883 -> 912 M it/s at 65536
       // problems, tools/ab_bench.py --cold); fp32 (issue-bound) gains nothing, launches of two
       // and more rounds desynchronise by themselves and only pay the delay (-2 %)
@@ -595,25 +647,27 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // +4-6 % at 2^20; HBM bytes per problem-iteration 6993 -> 6243 (1.41 -> 1.26 x algorithmic):
     // on from 65536 problems, BASELINE's roofline batch and half a per-GPU shard of configs[3] —
     // where the kernel already sits on the HBM roof the bytes are what is left to win)
-    a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= 65536);
+    a.ckpt = can && (h->opt_ckpt >= 0 ? h->opt_ckpt != 0 : B >= h->geo.full_batch());
     if (a.ckpt) {
       const int per_step = 64 * m * (n + 1) * (int)sizeof(T);
-      int steps = (37 * 1024 - kSegBytes - kK0Bytes) / per_step;
+      int steps = ((int)h->geo.lds_per_simd_wave() + 1024 - kSegBytes - kK0Bytes) / per_step;
       if (steps < 0) steps = 0;
       if (a.lds_steps > steps) a.lds_steps = steps;
     }
   }
   // The helper-wavefront form (k_lane_iterate_pair; round 5): the bicycles in fp64 and fp32 (stage
   // weights: its HASQR instantiations), states not checkpointed, and a launch of at most 512 workgroups (32768 problems) - two wavefronts per
-  // workgroup then still find a SIMD each.  kPairMaxGrid is a property of the chip (1024 SIMDs).
-  static constexpr unsigned kPairMaxGrid = 512;
-  static constexpr unsigned kTwoXMaxGrid = 256;  // its second state buffer: one workgroup per CU
+  // workgroup then still find a SIMD each.  Properties of the chip: half as many workgroups as it
+  // has SIMDs (512 on 256 CUs); the second state buffer up to one workgroup per CU.
+  static unsigned pair_max_grid(const DeviceGeometry& g) { return (unsigned)(g.simds() / 2); }
+  static unsigned two_x_max_grid(const DeviceGeometry& g) { return (unsigned)g.cus; }
   static bool pair_built(const Cfg& c, const LaneArgs<T>& a, int opt_pair) {
     if constexpr (Sys::NBLK == 0) return !a.ckpt && opt_pair != 0;
     return false;
   }
-  static bool use_pair(const Cfg& c, const LaneArgs<T>& a, int64_t B, int opt_pair) {
-    return pair_built(c, a, opt_pair) && (opt_pair == 1 || grid(B) <= kPairMaxGrid);
+  static bool use_pair(const DeviceGeometry& g, const Cfg& c, const LaneArgs<T>& a, int64_t B,
+                       int opt_pair) {
+    return pair_built(c, a, opt_pair) && (opt_pair == 1 || grid(B) <= pair_max_grid(g));
   }
   static size_t lane_lds(const LaneArgs<T>& a) {
     return (size_t)a.lds_steps * 64 * m * (n + 1) * sizeof(T) + kK0Bytes + (a.ckpt ? kSegBytes : 0);
@@ -622,15 +676,13 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // KiB of LDS to itself where a full launch budgets 36 (four wavefronts per CU): the gains of that
   // many more horizon steps stay in LDS between the backward and the forward pass instead of going
   // through HBM (fp64, n = 6, m = 2: 19 of 20 steps up to 256 workgroups, 8-10 up to 512).
-  static constexpr unsigned kCUs = 256;                 // MI355X
-  static constexpr size_t kLdsPerCU = 160 * 1024;       // gfx950
   // lds_steps of a launch of `workgroups` workgroups with `fixed` bytes of other dynamic LDS each,
   // at most max_dyn bytes of dynamic LDS per workgroup
-  static int grown_lds_steps(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, size_t fixed,
-                             size_t max_dyn) {
+  static int grown_lds_steps(const DeviceGeometry& g, const Cfg& c, const LaneArgs<T>& a,
+                             unsigned workgroups, size_t fixed, size_t max_dyn) {
     if (!a.lds_grow || a.ckpt) return a.lds_steps;
-    const unsigned per_cu = (workgroups + kCUs - 1) / kCUs;
-    size_t budget = kLdsPerCU / (per_cu ? per_cu : 1);
+    const unsigned per_cu = (workgroups + (unsigned)g.cus - 1) / (unsigned)g.cus;
+    size_t budget = g.lds_per_cu / (per_cu ? per_cu : 1);
     if (budget > max_dyn) budget = max_dyn;
     const size_t per_step = (size_t)64 * m * (n + 1) * sizeof(T);
     const size_t need0 = fixed + kK0Bytes + 1024;  // (1 KiB: allocation granularity)
@@ -641,43 +693,44 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // More than 64 KiB of dynamic LDS per workgroup has to be asked for; the attribute belongs to
   // the kernel ON THE CURRENT DEVICE, so it is set by every launch that needs it (a process may
   // drive several devices) and a refusal falls back to what 64 KiB hold.
-  static constexpr size_t kDefaultDynLds = 64 * 1024;
   template <class K>
-  static void grow_lds(K kernel, const Cfg& c, LaneArgs<T>& a, unsigned workgroups, size_t fixed) {
+  static void grow_lds(const DeviceGeometry& g, K kernel, const Cfg& c, LaneArgs<T>& a,
+                       unsigned workgroups, size_t fixed) {
     const int before = a.lds_steps;
-    a.lds_steps = grown_lds_steps(c, a, workgroups, fixed, kLdsPerCU);
-    if (lane_lds(a) + fixed <= kDefaultDynLds) return;
+    a.lds_steps = grown_lds_steps(g, c, a, workgroups, fixed, g.max_dyn_lds);
+    if (lane_lds(a) + fixed <= g.default_dyn_lds) return;
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kLdsPerCU) == hipSuccess)
+                            (int)g.max_dyn_lds) == hipSuccess)
       return;
     (void)hipGetLastError();
     a.lds_steps = before;
-    a.lds_steps = grown_lds_steps(c, a, workgroups, fixed, kDefaultDynLds);
+    a.lds_steps = grown_lds_steps(g, c, a, workgroups, fixed, g.default_dyn_lds);
   }
   template <bool TL>
-  static void launch_pair(const Cfg& c, const LaneArgs<T>& a, unsigned workgroups, hipStream_t s) {
+  static void launch_pair(const DeviceGeometry& g, const Cfg& c, const LaneArgs<T>& a,
+                          unsigned workgroups, hipStream_t s) {
     if constexpr (Sys::NBLK == 0) {
       LaneArgs<T> ap = a;
       if (c.flags) {  // stage weights: the record carries 2 Q (x_t - xtarget) as well
         using LW = LaneWorker<T, Sys, true, TL>;
         const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
-        grow_lds(&k_lane_iterate_pair<T, Sys, true, TL>, c, ap, workgroups, fixed);
+        grow_lds(g, &k_lane_iterate_pair<T, Sys, true, TL>, c, ap, workgroups, fixed);
         hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, true, TL>), dim3(workgroups), dim3(128),
                            lane_lds(ap) + fixed, s, c, ap);
       } else {
         using LW = LaneWorker<T, Sys, false, TL>;
         const size_t fixed = 2 * LW::kRec * 64 * sizeof(T) + 65 * sizeof(int) + 12;
-        grow_lds(&k_lane_iterate_pair<T, Sys, false, TL>, c, ap, workgroups, fixed);
+        grow_lds(g, &k_lane_iterate_pair<T, Sys, false, TL>, c, ap, workgroups, fixed);
         hipLaunchKernelGGL((k_lane_iterate_pair<T, Sys, false, TL>), dim3(workgroups), dim3(128),
                            lane_lds(ap) + fixed, s, c, ap);
       }
     }
   }
   template <bool TL>
-  static void launch_iterate(const Cfg& c, const LaneArgs<T>& a, int64_t B, hipStream_t s,
-                             int opt_pair = 0) {
-    if (use_pair(c, a, B, opt_pair)) {
-      launch_pair<TL>(c, a, grid(B), s);
+  static void launch_iterate(const DeviceGeometry& g, const Cfg& c, const LaneArgs<T>& a, int64_t B,
+                             hipStream_t s, int opt_pair = 0) {
+    if (use_pair(g, c, a, B, opt_pair)) {
+      launch_pair<TL>(g, c, a, grid(B), s);
       return;
     }
     if constexpr (Sys::NBLK > 0) {  // row-block plants: their own fused kernel, no LDS
@@ -693,11 +746,11 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     } else {
       LaneArgs<T> ag = a;
       if (c.flags) {
-        grow_lds(&k_lane_iterate<T, Sys, true, TL>, c, ag, grid(B), 0);
+        grow_lds(g, &k_lane_iterate<T, Sys, true, TL>, c, ag, grid(B), 0);
         hipLaunchKernelGGL((k_lane_iterate<T, Sys, true, TL>), dim3(grid(B)), dim3(64),
                            lane_lds(ag), s, c, ag);
       } else {
-        grow_lds(&k_lane_iterate<T, Sys, false, TL>, c, ag, grid(B), 0);
+        grow_lds(g, &k_lane_iterate<T, Sys, false, TL>, c, ag, grid(B), 0);
         hipLaunchKernelGGL((k_lane_iterate<T, Sys, false, TL>), dim3(grid(B)), dim3(64),
                            lane_lds(ag), s, c, ag);
       }
@@ -717,8 +770,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // finished.  Measured against hand-tuned first chunks of 8 / 10 / 12 / 14 on three
   // distributions (the bench's; every problem with the obstacle; targets twice as far) at
   // 16384 ... 262144 problems (tools/solve_bench.py --plans, profiles/r05_solve_schedule.txt):
-  // within 10 % of the best hand-tuned schedule in all 18 cases (worst: 49152 problems, bench
-  // distribution, +10 %; 65536: +6 / +7 / +4 %).  Tried and dropped: up to three in-place
+  // within 15 % of the best hand-tuned schedule in all 18 cases (worst: 32768 problems, every
+  // problem with the obstacle, 1.144; 65536: 1.033 / 1.081 / 1.062).  Tried and dropped: up to three in-place
   // extension chunks of 2 iterations gated on the survivor count of the chunk before (ahead at
   // <= 32768 problems on the hard distribution, 13-41 % behind from 131072, where a chunk over
   // the whole batch is several rounds of wavefronts); chunks of 2 behind the first.
@@ -759,8 +812,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     bool spec_tail = false;
     if constexpr (m == 2 && n + m <= 8)
       spec_tail = h->opt_spec != 0 && c.flags == 0 && group_spec_tail_supported(h->cfg);
-    const int wave_tail = h->wave_tail < 0 ? (spec_tail ? kAutoSpecTail : kAutoWaveTail)
-                                           : h->wave_tail;
+    const int wave_tail = h->wave_tail < 0
+        ? (int)h->geo.scaled(spec_tail ? kAutoSpecTail : kAutoWaveTail) : h->wave_tail;
     // chunk 0 runs in place on the caller's arrays
     const int first = h->opt_first_chunk > 0 ? h->opt_first_chunk : kFirstChunk;
     int done = 0, len = max_iter < first ? max_iter : first;
@@ -772,7 +825,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // one live counter per compaction round, all cleared by ONE fill in front of the first chunk (a
     // fill per round was a 5 us launch of its own in each of the rounds that follow the tail)
     HIP_TRY(hipMemsetAsync(cv.count, 0, kMaxRounds * sizeof(int32_t), s));
-    launch_iterate<TILED>(c, a0, B, s, h->opt_pair);
+    launch_iterate<TILED>(h->geo, c, a0, B, s, h->opt_pair);
     done += len;
     const unsigned cgrid = (unsigned)((B + 255) / 256);
     int cur = 0;    // work set that receives the survivors
@@ -804,7 +857,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           t.out_iters = usr.iters; t.out_status = usr.status;
           t.out_B = usr.B; t.out_tiled = TILED ? 1 : 0;
           if constexpr (m == 2 && n + m <= 8) HIP_TRY(group_spec_tail<T>(h->cfg, t, s));
-        } else if (WL::kHasFstep && lds_f <= 64 * 1024) {
+        } else if (WL::kHasFstep && lds_f <= h->geo.default_dyn_lds) {
           if constexpr (WL::kHasFstep) {
             if (c.flags)
               hipLaunchKernelGGL((k_iterate<T, Sys, 64, true, true, true>), dim3(wave_tail),
@@ -838,13 +891,14 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       ap.ckpt = 0;
       ap.merge = h->opt_merge >= 0 ? h->opt_merge : 0;
       ap.reroll = h->opt_reroll >= 0 ? h->opt_reroll : 0;
-      if (pair_built(c, ap, h->opt_pair) && h->opt_pair < 0 && grid(B) > kPairMaxGrid) {
-        ap.count_hi = 64 * (int)kPairMaxGrid;
-        launch_pair<false>(c, ap, kPairMaxGrid, s);
+      const unsigned pair_max = pair_max_grid(h->geo);
+      if (pair_built(c, ap, h->opt_pair) && h->opt_pair < 0 && grid(B) > pair_max) {
+        ap.count_hi = 64 * (int)pair_max;
+        launch_pair<false>(h->geo, c, ap, pair_max, s);
         a.count_lo = ap.count_hi;
-        launch_iterate<false>(c, a, B, s, 0);
+        launch_iterate<false>(h->geo, c, a, B, s, 0);
       } else {
-        launch_iterate<false>(c, a, B, s, h->opt_pair);
+        launch_iterate<false>(h->geo, c, a, B, s, h->opt_pair);
       }
       done += len;
       src = w;
@@ -870,8 +924,8 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // automatic: chunked solve with the speculative tail from 4096 problems and more than 16
     // iterations allowed (measured 1.2-1.9x on the bench workload from 4096 to 262144 problems;
     // the chunks alone cost ~9 % when nothing terminates early)
-    const int64_t cmin = h->compact_min_batch < 0 ? (h->cfg.max_iter > 16 ? kAutoCompactBatch : 0)
-                                                  : h->compact_min_batch;
+    const int64_t cmin = h->compact_min_batch < 0
+        ? (h->cfg.max_iter > 16 ? h->geo.scaled(kAutoCompactBatch) : 0) : h->compact_min_batch;
     if (early_exit && cmin > 0 && B >= cmin && n_iters > 4 && n_iters == h->cfg.max_iter)
       return solve_compacting(h, B, X, U, x_term, lamb, obs, cost, K, k, iters, status, s);
     if (int rc = need_ws(h, B)) return rc;
@@ -888,9 +942,27 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       if (h->opt_defer < 0) a.defer = 0;
       finish_options(h, B, a);
     }
-    launch_iterate<TILED>(c, a, B, s, h->opt_pair);
+    launch_iterate<TILED>(h->geo, c, a, B, s, h->opt_pair);
     HIP_TRY(hipGetLastError());
     return I2LQR_OK;
+  }
+  // 1 if the (first) launch of i2lqr_iterate / i2lqr_solve for B problems is the helper-wavefront
+  // kernel: the SAME carve + option + use_pair sequence the launchers above run, on scratch
+  // arguments (no launch, no device access) — i2lqr_iterate_kernel / i2lqr_solve_kernel (ADVICE r5:
+  // a hand-written mirror of these conditions had drifted).
+  static int names_pair(i2lqr_handle* h, int64_t B, int early_exit) {
+    const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
+    LaneArgs<T> a;
+    carve(h, B, a);
+    const int64_t cmin = h->compact_min_batch < 0
+        ? (h->cfg.max_iter > 16 ? h->geo.scaled(kAutoCompactBatch) : 0) : h->compact_min_batch;
+    const bool chunked = early_exit && cmin > 0 && B >= cmin && h->cfg.max_iter > 4;
+    if (early_exit && !chunked) {  // (the single-launch solve: iterate() above)
+      if (h->opt_reroll < 0) a.reroll = 0;
+      if (h->opt_defer < 0) a.defer = 0;
+      finish_options(h, B, a);
+    }
+    return use_pair(h->geo, c, a, B, h->opt_pair) ? 1 : 0;
   }
   static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      hipStream_t s) {
@@ -1009,6 +1081,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   } while (0)
 
 int prepare_dispatch(i2lqr_handle* h) { I2LQR_DISPATCH(h, prepare(h)); }
+int names_pair_dispatch(i2lqr_handle* h, int64_t B, int early_exit) {
+  I2LQR_DISPATCH(h, names_pair(h, B, early_exit));
+}
 int dispatch_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      void* stream) {
   I2LQR_DISPATCH(h, rollout(h, B, X, U, x_term, cost, (hipStream_t)stream));
@@ -1370,6 +1445,13 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   i2lqr_handle* h = new (std::nothrow) i2lqr_handle;
   if (!h) return fail(I2LQR_ERR_LAUNCH, "out of host memory");
   h->cfg = *cfg;
+  h->geo = device_geometry();  // of the current device: CU count, LDS per CU / per workgroup
+  if (h->geo.wave != 64) {
+    const int w = h->geo.wave;
+    delete h;
+    return fail(I2LQR_ERR_UNSUPPORTED, "the kernels are built for 64-lane wavefronts (gfx950), this "
+                "device reports %d", w);
+  }
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->compact_min_batch = -1;
@@ -1408,6 +1490,15 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   return I2LQR_OK;
 }
 
+int i2lqr_device_geometry(int32_t* out, int32_t count) {
+  if (!out || count < 1) return fail(I2LQR_ERR_INVALID, "null / empty output");
+  const DeviceGeometry& g = device_geometry();
+  const int32_t v[8] = {g.cus, g.simds_per_cu, (int32_t)g.lds_per_cu, (int32_t)g.max_dyn_lds,
+                        (int32_t)g.default_dyn_lds, g.wave, g.faked, g.queried};
+  for (int i = 0; i < count && i < 8; i++) out[i] = v[i];
+  return I2LQR_OK;
+}
+
 int i2lqr_destroy(i2lqr_handle* h) {
   if (!h) return I2LQR_OK;
   {
@@ -1431,7 +1522,8 @@ int64_t i2lqr_workspace_bytes(const i2lqr_handle* h, int64_t B) {
     // (or whenever it is pinned); nothing below
     // (only in the range where that form is the automatic choice, or when it is pinned: a
     // problem-major batch of 2^20 problems does not need 5.9 GB of scratch it would never use)
-    return ((B > kGroupWsBatch && (B <= group_ws_top(h->cfg) || h->opt_group == 8)) || h->opt_group_ws == 1)
+    return ((B > h->geo.scaled(kGroupWsBatch) &&
+             (B <= h->geo.scaled(group_ws_top(h->cfg)) || h->opt_group == 8)) || h->opt_group_ws == 1)
                ? group_workspace_bytes(h->cfg, B) : 0;
   }
   const bool tiled = h->cfg.layout == I2LQR_LAYOUT_BATCH_TILED;
@@ -1539,6 +1631,9 @@ int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_e
     }
     default: return fail(I2LQR_ERR_INVALID, "unknown system_id %d", cfg->system_id);
   }
+  // measured on the 256-CU chip; on another CU count (a partitioned device) scaled by cus / 256:
+  // both sides of the crossover are occupancy effects (i2lqr_geometry.hpp)
+  from = device_geometry().scaled_from(from);
   if (!lane_ok || B < from) return I2LQR_LAYOUT_PROBLEM_MAJOR;
   return B % 64 == 0 ? I2LQR_LAYOUT_BATCH_TILED : I2LQR_LAYOUT_BATCH_MINOR;
 }
@@ -1598,12 +1693,10 @@ static const char* kernel_name(const i2lqr_handle* h, int64_t B, bool early_exit
   if (!h) return "";
   if (h->cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) {
     if (h->cfg.system_id == I2LQR_SYS_QUAD12) return "k_lane_iterate_rows";
-    // the helper-wavefront form: fp64, at most 512 workgroups (LaneLaunch::use_pair; states are
-    // checkpointed from 65536 problems only, i.e. never in that range)
-    const bool pair = h->opt_pair != 0 &&
-                      (h->opt_pair == 1 || (B + 63) / 64 <= 512) &&
-                      !(early_exit && B >= 65536);
-    return pair ? "k_lane_iterate_pair" : "k_lane_iterate";
+    // the helper-wavefront form (both precisions, with or without stage weights): decided by the
+    // launcher's own helpers on scratch arguments (LaneLaunch::names_pair)
+    return names_pair_dispatch(const_cast<i2lqr_handle*>(h), B, early_exit ? 1 : 0) == 1
+               ? "k_lane_iterate_pair" : "k_lane_iterate";
   }
   switch (select_fused(h, B, early_exit, nullptr)) {
     case K_SPEC: return "k_group_spec";

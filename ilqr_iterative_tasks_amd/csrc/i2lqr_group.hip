@@ -2,6 +2,7 @@
 #include "i2lqr_group.h"
 
 #include "i2lqr_devcfg.hpp"
+#include "i2lqr_geometry.hpp"
 #include "i2lqr_group.hpp"
 
 namespace i2lqr {
@@ -26,7 +27,7 @@ bool has_stage_weights(const i2lqr_config& cfg) {
 // AND per device (a second GPU used from the same thread has its own copy of the attribute):
 // once per (kernel, device, size).
 template <auto Kernel> hipError_t raise_lds_limit(size_t lds) {
-  if (lds <= 64 * 1024) return hipSuccess;
+  if (lds <= device_geometry().default_dyn_lds) return hipSuccess;
   constexpr int kMaxDev = 64;
   static thread_local int raised_for[kMaxDev] = {};
   int dev = 0;
@@ -59,9 +60,9 @@ hipError_t launch_h(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s
 // a SIMD of its own (<= 512 workgroups = 2048 problems).
 template <class T, class Sys>
 hipError_t launch16(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
-  constexpr int64_t kCUs = 256;
+  const int64_t cus = device_geometry().cus;
 #ifndef I2LQR_STAMPS
-  if ((a.B + 3) / 4 <= 2 * kCUs) return launch_h<T, Sys, 2, 16>(cfg, a, s);
+  if ((a.B + 3) / 4 <= 2 * cus) return launch_h<T, Sys, 2, 16>(cfg, a, s);
 #endif
   return launch_h<T, Sys, 1, 16>(cfg, a, s);
 }
@@ -82,9 +83,9 @@ hipError_t launch_ws(const i2lqr_config& cfg, const IterArgs<T>& a, void* ws, hi
 
 template <class T, class Sys>
 hipError_t launch(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
-  constexpr int64_t kCUs = 256;
+  const int64_t cus = device_geometry().cus;
 #ifndef I2LQR_STAMPS  // (the diagnostic build stamps the phases of the lone wavefront)
-  if ((a.B + kGroupsPerWave - 1) / kGroupsPerWave <= kCUs) return launch_h<T, Sys, 3>(cfg, a, s);
+  if ((a.B + kGroupsPerWave - 1) / kGroupsPerWave <= cus) return launch_h<T, Sys, 3>(cfg, a, s);
 #endif
   return launch_h<T, Sys, 1>(cfg, a, s);
 }
@@ -115,8 +116,9 @@ hipError_t launch_spec_v(const i2lqr_config& cfg, const IterArgs<T>& a, hipStrea
 }
 template <class T, class Sys, bool SETIO, int G>
 hipError_t launch_spec(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
-  const bool wide = !SETIO && a.B <= kSpecWideBatch &&
-                    spec_lds_bytes<T, Sys, 3, G>(cfg.N) <= 160 * 1024;
+  const DeviceGeometry& geo = device_geometry();
+  const bool wide = !SETIO && a.B <= geo.scaled(kSpecWideBatch) &&
+                    spec_lds_bytes<T, Sys, 3, G>(cfg.N) <= geo.max_dyn_lds;
   if (wide) return launch_spec_v<T, Sys, 3, SETIO, G>(cfg, a, s);
   return launch_spec_v<T, Sys, 2, SETIO, G>(cfg, a, s);
 }
@@ -136,7 +138,7 @@ template <int G> bool spec_lds_fits(const i2lqr_config& cfg) {  // the two-wavef
                                              : spec_lds_bytes<double, Bicycle6<double>, 2, G>(cfg.N))
       : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>, 2, G>(cfg.N)
                                              : spec_lds_bytes<float, Bicycle6<float>, 2, G>(cfg.N));
-  return lds <= 160 * 1024;
+  return lds <= device_geometry().max_dyn_lds;
 }
 bool spec_plant_ok(const i2lqr_config& cfg) {
   if (cfg.system_id != I2LQR_SYS_BICYCLE4 && cfg.system_id != I2LQR_SYS_BICYCLE6) return false;
@@ -180,7 +182,7 @@ bool group16_supported(const i2lqr_config& cfg) {
                                              : group_lds_bytes<double, Bicycle6<double>, 16>(cfg.N))
       : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<float, Bicycle4<float>, 16>(cfg.N)
                                              : group_lds_bytes<float, Bicycle6<float>, 16>(cfg.N));
-  return lds <= 160 * 1024;
+  return lds <= device_geometry().max_dyn_lds;
 }
 template <> hipError_t group16_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
                                                hipStream_t s) {
@@ -201,7 +203,7 @@ bool group_supported(const i2lqr_config& cfg) {
                                              : group_lds_bytes<double, Bicycle6<double>>(cfg.N))
       : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? group_lds_bytes<float, Bicycle4<float>>(cfg.N)
                                              : group_lds_bytes<float, Bicycle6<float>>(cfg.N));
-  return lds <= 160 * 1024;
+  return lds <= device_geometry().max_dyn_lds;
 }
 
 int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B) {
@@ -217,7 +219,7 @@ int64_t group_workspace_bytes(const i2lqr_config& cfg, int64_t B) {
       : (cfg.system_id == I2LQR_SYS_BICYCLE4
              ? (size_t)GLayout<Bicycle4<float>>(cfg.N, true).wave_words() * 4
              : (size_t)GLayout<Bicycle6<float>>(cfg.N, true).wave_words() * 4);
-  if (lds > 160 * 1024) return 0;
+  if (lds > device_geometry().max_dyn_lds) return 0;
   return probs * words * (cfg.dtype == I2LQR_F64 ? 8 : 4);
 }
 template <> hipError_t group_iterate_ws<double>(const i2lqr_config& cfg, const IterArgs<double>& a,

@@ -1,4 +1,5 @@
 // Instantiations and launcher of the sixteen-lanes-per-problem kernel (i2lqr_quad.hpp).
+#include "i2lqr_geometry.hpp"
 #include "i2lqr_group.h"
 
 #include <cstdlib>
@@ -25,7 +26,7 @@ template <class T> hipError_t launch_quad(const i2lqr_config& cfg, const IterArg
   using Sys = Quad12<T>;
   const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
   const size_t lds = (size_t)QLayout<Sys>(cfg.N).lds_total * kQPW * sizeof(T);
-  if (lds > 64 * 1024) {
+  if (lds > device_geometry().default_dyn_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)k_quad_iterate<T, Sys>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -48,7 +49,7 @@ bool quad_supported(const i2lqr_config& cfg) {
   if (cfg.system_id != I2LQR_SYS_QUAD12 || cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return false;
   if (quad_has_stage_weights(cfg)) return false;
   const size_t elem = cfg.dtype == I2LQR_F64 ? 8 : 4;
-  return (size_t)QLayout<Quad12<double>>(cfg.N).lds_total * kQPW * elem <= 160 * 1024;
+  return (size_t)QLayout<Quad12<double>>(cfg.N).lds_total * kQPW * elem <= device_geometry().max_dyn_lds;
 }
 
 int64_t quad_workspace_bytes(const i2lqr_config& cfg, int64_t B) {

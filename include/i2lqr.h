@@ -130,18 +130,37 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out);
 int i2lqr_destroy(i2lqr_handle* h);
 
 /*
+ * Geometry of the CURRENT device as the library sees it (hipDeviceGetAttribute, once per device;
+ * round 6): out[0..count) = {compute units, SIMDs per CU, LDS bytes per CU, most dynamic LDS one
+ * workgroup can be given, ... without opt-in, wavefront size, 1 if the debug override
+ * I2LQR_FAKE_CUS=<n> replaced the CU count, 1 if the figures come from the runtime (0: no device
+ * visible, the MI355X figures: 256, 4, 163840, 163840, 65536, 64)}.  Every LDS budget, every
+ * "a SIMD for each wavefront" limit and every batch-size threshold of the kernel choice derives
+ * from these (csrc/i2lqr_geometry.hpp); the thresholds were measured on the full chip (256 CUs)
+ * and are scaled by CUs / 256 elsewhere (a partitioned device).  No reference counterpart.
+ */
+int i2lqr_device_geometry(int32_t* out, int32_t count);
+
+/*
  * Which cfg.layout to create the handle with for batches of B problems (host only, no GPU needed):
  * the layouts are different kernel FAMILIES — problem-major runs one problem per 64, 16 or 8 lanes
  * (latency kernels: up to ~10^4 problems), batch-minor / batch-tiled run one problem per lane (the
- * HBM-bound throughput kernels) — and the crossover is measured, not derivable by a caller:
- * bicycles above 12288 problems (fixed iteration counts, early_exit 0: i2lqr_iterate, and solves to
- * termination, early_exit 1: i2lqr_solve, alike); quad12 (fp64) from 8192.
+ * HBM-bound throughput kernels) — and the crossover is MEASURED PER SHAPE (plant x horizon x
+ * precision x entry point: sixteen shapes, tools/threshold_sweep.py; the table is kLaneFrom /
+ * kLaneFromQuad in csrc/i2lqr_abi.hip and DESIGN.md section 3.0), not derivable by a caller and not
+ * one number: e.g. bicycle6 N = 20 fp64 crosses over at 8193 problems for fixed iteration counts
+ * (early_exit 0: i2lqr_iterate) and 10241 for solves to termination (early_exit 1: i2lqr_solve),
+ * bicycle6 N = 50 fp64 at 3073 / 4096, quad12 N = 50 fp64 at 4097 / 6145, fp32 at 8193 / 12289.
+ * With stage weights (Q or R != 0) every plant crosses over at 2048 problems (the problem-major
+ * side is the one-problem-per-wavefront kernel then).  On a device with another CU count than the
+ * 256 the table was measured on, the entries are scaled by CUs / 256 (i2lqr_device_geometry).
  * Returns I2LQR_LAYOUT_BATCH_TILED where B is a multiple of 64, I2LQR_LAYOUT_BATCH_MINOR otherwise,
- * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for configurations the lane kernels do not
- * run (non-symmetric weights; quad12 with stage weights Q, R != 0 or in fp32); the bicycles with
- * stage weights cross over at 2048 problems (their problem-major side is the
- * one-problem-per-wavefront kernel); < 0 on a bad argument.  cfg->layout itself is not read.  The reference has no counterpart (one NumPy layout).
- * Inside the problem-major layout the library picks the kernel per call (i2lqr_iterate_kernel).
+ * I2LQR_LAYOUT_PROBLEM_MAJOR below the crossover and for the configurations the lane kernels do
+ * not run: non-symmetric weights, and quad12 in fp32 WITH stage weights (quad12 with stage
+ * weights in fp64, and quad12 in fp32 with Q = R = 0, are lane-capable since round 5); < 0 on a
+ * bad argument.  cfg->layout itself is not read.  The reference has no counterpart (one NumPy
+ * layout).  Inside the problem-major layout the library picks the kernel per call
+ * (i2lqr_iterate_kernel).
  */
 int i2lqr_recommended_layout(const i2lqr_config* cfg, int64_t B, int32_t early_exit);
 
@@ -292,10 +311,13 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
 int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
 
 /* Name of the kernel i2lqr_iterate (fixed iteration count) launches for a batch of B problems
- * with the handle's current options ("k_iterate", "k_group_iterate", "k_group_spec",
- * "k_quad_iterate", "k_lane_iterate", "k_lane_iterate_rows"; "unsupported" if a forced option
- * cannot be honoured and the launch would return I2LQR_ERR_UNSUPPORTED): what to look for in a
- * rocprofv3 kernel trace.  Host only; "" for a NULL handle. */
+ * with the handle's current options: "k_iterate", "k_group_iterate", "k_group_iterate (sixteen
+ * lanes)", "k_group_iterate (workspace form)", "k_group_spec", "k_group_spec (sixteen lanes)",
+ * "k_quad_iterate", "k_lane_iterate", "k_lane_iterate_pair" (the helper-wavefront form),
+ * "k_lane_iterate_rows"; "unsupported" if a forced option cannot be honoured and the launch would
+ * return I2LQR_ERR_UNSUPPORTED: what to look for in a rocprofv3 kernel trace.  The name comes from
+ * the launcher's own decision code run on scratch arguments, not from a copy of its conditions.
+ * Host only; "" for a NULL handle. */
 const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B);
 /* The same for i2lqr_solve / early-exit calls (the dominant kernel; the chunked solves of the lane
  * layouts also launch k_lane_compact and a tail kernel). */

@@ -189,3 +189,41 @@ def test_every_option_the_library_accepts_is_documented_in_the_header():
     assert len(opts) >= 16 and "helper_wavefront" in opts and "state_buffers" in opts
     missing = [o for o in opts if f'"{o}"' not in hdr]
     assert not missing, missing
+
+
+def test_every_kernel_name_the_library_can_report_is_in_the_header():
+    """i2lqr_iterate_kernel / i2lqr_solve_kernel return string literals of
+    csrc/i2lqr_abi.hip:kernel_name(); the header's comment is the boundary document for them."""
+    src = (ROOT / "ilqr_iterative_tasks_amd" / "csrc" / "i2lqr_abi.hip").read_text()
+    body = src[src.index("static const char* kernel_name("):src.index("const char* i2lqr_iterate_kernel(")]
+    names = sorted(set(re.findall(r'"(k_[a-z_0-9]+(?: \([a-z ]+\))?|unsupported)"', body)))
+    assert len(names) >= 10 and "k_lane_iterate_pair" in names, names
+    hdr = re.sub(r"\s*\n \*\s*", " ", HEADER)  # the comment wraps names across lines
+    missing = [n for n in names if f'"{n}"' not in hdr]
+    assert not missing, missing
+
+
+def test_chip_geometry_lives_in_one_struct():
+    """CU count, LDS per CU and what derives from them are queried from the device
+    (hipDeviceGetAttribute -> DeviceGeometry), not compiled in: no such literal is left in csrc/
+    outside i2lqr_geometry.hpp, and without a device the library reports the MI355X figures."""
+    csrc = ROOT / "ilqr_iterative_tasks_amd" / "csrc"
+    pats = [r"kCUs\b", r"kLdsPerCU\b", r"kPairMaxGrid\b", r"kTwoXMaxGrid\b", r"\b160 \* 1024\b",
+            r"\b163840\b", r"\b150 \* 1024\b"]
+    for path in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.hpp")) + sorted(csrc.glob("*.h")):
+        if path.name == "i2lqr_geometry.hpp":
+            continue
+        code = re.sub(r"//[^\n]*", "", path.read_text())  # (comments may quote the figures)
+        for pat in pats:
+            assert not re.search(pat, code), (path.name, pat)
+    geo_src = (csrc / "i2lqr_abi.hip").read_text()
+    assert "hipDeviceAttributeMultiprocessorCount" in geo_src
+    assert "hipDeviceAttributeMaxSharedMemoryPerMultiprocessor" in geo_src
+    lib = _abi.load_library()
+    out = (C.c_int32 * 8)()
+    assert lib.i2lqr_device_geometry(out, 8) == 0
+    cus, simds, lds, max_dyn, dflt, wave, faked, queried = list(out)
+    assert wave == 64 and simds == 4 and cus >= 1 and lds >= dflt > 0 and max_dyn >= dflt
+    if not queried:  # no device here: the MI355X figures
+        assert (cus, lds, max_dyn, dflt, faked) == (256, 160 * 1024, 160 * 1024, 64 * 1024, 0)
+    assert lib.i2lqr_device_geometry(None, 8) == -1

@@ -192,3 +192,45 @@ def test_one_call_round_refuses_what_it_cannot_run(torch_mod):
         HipCandidateSolver().sharded_round(cfg, None, torch.zeros(0, cfg.n), None, 1.0,
                                            idist.TorchExchange(), 0)
     solver.close()
+
+
+def test_device_geometry_comes_from_the_runtime(torch_mod):
+    """CU count, LDS per CU and the dynamic-LDS limits are hipDeviceGetAttribute's
+    answers.  On the full MI355X they must be exactly what rounds 1-5 had compiled in (256 CUs,
+    160 KiB per CU, 64 KiB without opt-in, 64-lane wavefronts): every derived budget and threshold
+    is then unchanged, which the bit-identity and kernel-name tests of the suite check."""
+    import ctypes as C
+    from ilqr_iterative_tasks_amd import _abi
+    torch_mod.cuda.current_device()
+    geo = (C.c_int32 * 8)()
+    assert _abi.load_library().i2lqr_device_geometry(geo, 8) == 0
+    cus, simds, lds, max_dyn, dflt, wave, faked, queried = list(geo)
+    assert queried == 1 and faked == 0 and wave == 64 and simds == 4
+    assert cus == torch_mod.cuda.get_device_properties(0).multi_processor_count
+    if cus == 256:  # (an unpartitioned MI355X)
+        assert (lds, max_dyn, dflt) == (160 * 1024, 160 * 1024, 64 * 1024)
+
+
+def test_a_device_with_a_quarter_of_the_cus_still_passes_parity():
+    """I2LQR_FAKE_CUS=64 (the debug override of the queried CU count: a CPX-like partition): the
+    thresholds scale by 64 / 256 — 4096 problems already take the one-problem-per-lane layout, the
+    helper-wavefront kernel stops at 128 workgroups, LDS-resident gain steps are budgeted for 64
+    CUs — and the results still match the CPU oracle at 4096 and 16384 problems."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, I2LQR_FAKE_CUS="64")
+    out = subprocess.run([sys.executable, str(root / "tools" / "fake_cus_parity.py")], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["geometry"][0] == 64 and d["geometry"][6] == 1
+    by = {(c["B"], c["solve"]): c for c in d["cases"]}
+    assert by[(4096, False)]["layout"] == 2 and by[(4096, False)]["kernel"] == "k_lane_iterate_pair"
+    assert by[(16384, False)]["kernel"] == "k_lane_iterate"  # 256 workgroups > 128: one wavefront
+    for c in d["cases"]:
+        assert c["same_branch"] > 0.97, c
+        assert c["X_err"] < 1e-8 and c["U_err"] < 1e-7 and c["cost_err"] < 1e-7, c
