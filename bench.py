@@ -312,7 +312,8 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             # to torch.distributed's all-gather together and the JSON line says so
             poisoned = False
             try:  # (raises on every rank or on none: CostExchange agrees on each bring-up step)
-                exchange = dist_mod.CostExchange(solver)
+                with quiet_stdout():
+                    exchange = dist_mod.CostExchange(solver)
                 ok = 1
             except dist_mod.CostExchangePoisoned as e:
                 native_error, ok, poisoned = f"{type(e).__name__}: {e}", 0, True
@@ -610,6 +611,28 @@ def time_candidate_round(args, B, torch, rounds=20, warmup=3):
             "round": "initial state in the chosen layout + i2lqr_iterate_pick + winner gather"}
 
 
+class quiet_stdout:
+    """RCCL prints a version banner to the C stdout when a communicator comes up (buffered: it
+    would land BEHIND the JSON line when stdout is a file).  Around a bring-up: fd 1 points at
+    stderr, the C buffers are flushed inside, fd 1 comes back — stdout carries the JSON line only."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4):
     """Per-rank cost of the SHARDED step beside the unsharded one, in ONE process on ONE GPU
     (the only evidence for the >= 6x-at-8-GPUs target obtainable without the node —
@@ -639,7 +662,8 @@ def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4):
               torch.zeros(1, dtype=solver.dtype, device=solver.device)) for _ in range(steps)]
     path, err = "native (RCCL world of one)", None
     try:
-        xch = dist_mod.CostExchange(solver)
+        with quiet_stdout():
+            xch = dist_mod.CostExchange(solver)
     except Exception as e:  # noqa: BLE001
         xch, path, err = dist_mod.TorchExchange(), "device copies (no RCCL)", f"{type(e).__name__}: {e}"
     xbufs = [solver.round_buffers(B, B, 1) for _ in range(steps)]
@@ -1260,6 +1284,8 @@ def run_rank(args) -> int:
                 head.update(claims)
         out["roofline"] = head
     if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # (anything a library left in the C stdout buffer goes first)
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
