@@ -167,6 +167,8 @@ struct i2lqr_handle {
   int opt_pair;  // bicycles' lane kernel (fp64 and fp32, with or without stage weights): workgroups of two wavefronts (main + helper); -1 = automatic
   int opt_two_x;  // ... its second state buffer (no re-roll of accepted steps); -1 = automatic
   int opt_chunk_step;  // chunked solve: length of the chunk that follows the first (automatic: 4); a schedule to measure against
+  int opt_fuse;  // chunked solve: compaction folded into the chunk kernels' exit (round 6); 0: k_lane_compact launches; -1 = automatic (on)
+  int opt_final_round;  // chunked solve: the round whose tail kernel takes every survivor and ends the schedule; 0: never; -1 = automatic
   int opt_first_chunk;  // chunked solve: pinned length of the first chunk, no extension chunks (a hand-tuned schedule to measure the data-driven one against); -1 = automatic
   int opt_fstep;  // one-problem-per-wavefront kernel: per-step Jacobian matrices in LDS; -1 = automatic
   int opt_group;  // problem-major layout: lanes per problem of the fused kernels: 8, 64; -1 = automatic
@@ -509,10 +511,15 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // the chunked solve two compacted work sets, scratch iters/status and one counter per round.
   static constexpr int kMaxRounds = 24;  // compaction rounds of the chunked solve (one counter each)
   static constexpr int kFirstChunk = 8;
+  static constexpr int kFinalRound = 3;  // chunked solve: the round (at 24 iterations) whose tail takes everything
   static int64_t set_words(int N) { return (int64_t)(n * (N + 1) + m * N + n + 6 + 2); }
   static int64_t ws_bytes(int N, int64_t B) {
     const int64_t Bp = TILED ? (B + 63) / 64 * 64 : B;
-    const int64_t words = lane_workspace_words<Sys>(N, Bp) + 2 * set_words(N) * Bp;
+    // (+ the second state buffer of the helper-wavefront form: its own rows since round 6 — the
+    // chunks' exits pack survivors into the work set the chunk does not run on, which used to lend
+    // its states)
+    const int64_t words = lane_workspace_words<Sys>(N, Bp) + 2 * set_words(N) * Bp +
+                          Bp * (int64_t)(n * (N + 1));
     return words * (int64_t)sizeof(T) + (2 * 3 + 2) * Bp * 4 + 16 + kMaxRounds * 4;
   }
   static int prepare(i2lqr_handle* h) {
@@ -557,10 +564,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     a.wsU = p; p += B * (int64_t)(m * N);
     a.wsK = p; p += B * (int64_t)(m * n * N);
     a.wsk = p; p += B * (int64_t)(m * N);
-    // second state buffer of the helper-wavefront form: the states of the first compacted work
-    // set, which no launch uses while a kernel iterates on other arrays (solve_compacting() hands
-    // every chunk the states of the work set it does NOT run on)
+    // second state buffer of the helper-wavefront form (rows of its own behind the gains scratch)
     a.wsX = h->opt_two_x != 0 ? p : nullptr;
+    p += B * (int64_t)(n * (N + 1));
     a.two_max = 64 * (int)(h->opt_two_x == 1 ? pair_max_grid(h->geo) : two_x_max_grid(h->geo));
     a.count_lo = -1;
     a.count_hi = 0x7fffffff;
@@ -588,6 +594,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     if (h->opt_merge >= 0) a.merge = h->opt_merge;
     a.ckpt = 0;  // decided in finish_options() once the other options are final
     a.stagger = 0;
+    std::memset(&a.cp, 0, sizeof(a.cp));  // plain exit; solve_compacting() fills it per chunk
     if constexpr (Sys::NBLK > 0) {
       // automatic where the launch fills the chip (one wavefront per SIMD: 65536 problems)
       a.stagger = B >= full ? 45 : 0;
@@ -825,19 +832,50 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
     // one live counter per compaction round, all cleared by ONE fill in front of the first chunk (a
     // fill per round was a 5 us launch of its own in each of the rounds that follow the tail)
     HIP_TRY(hipMemsetAsync(cv.count, 0, kMaxRounds * sizeof(int32_t), s));
+    // Round 6: the compaction is folded into the chunk kernels' EXIT (LaneCompact: a wavefront that
+    // has finished its chunk packs its survivors into the next work set and scatters what
+    // terminated, one atomic add per wavefront, while the other wavefronts still iterate) — the
+    // k_lane_compact launch between every two chunks and the final scatter pass are gone
+    // ("fused_compaction" 0 brings them back: the A/B and the fallback).
+    const bool fused = h->opt_fuse != 0;
+    auto plan_exit = [&](LaneArgs<T>& a, bool src_user, const int32_t* orig, LaneSet<T>* dst,
+                         int32_t* count_out) {
+      std::memset(&a.cp, 0, sizeof(a.cp));
+      if (!fused) return;
+      a.cp.on = 1;
+      a.cp.src_is_user = src_user ? 1 : 0;
+      a.cp.user_tiled = TILED ? 1 : 0;
+      a.cp.orig = orig;
+      if (dst) a.cp.dst = *dst;
+      a.cp.count_out = count_out;
+      a.cp.usr = usr;
+    };
+    int round = 0;  // counter of the work set the NEXT compaction fills
+    int cur = 0;    // ... and its index
+    const bool only_chunk = len >= max_iter;  // (max_iter <= first chunk: nothing survives it)
+    plan_exit(a0, true, nullptr, only_chunk ? nullptr : &cv.set[cur], cv.count + round);
     launch_iterate<TILED>(h->geo, c, a0, B, s, h->opt_pair);
     done += len;
     const unsigned cgrid = (unsigned)((B + 255) / 256);
-    int cur = 0;    // work set that receives the survivors
-    int round = 0;  // its counter
     bool src_user = true;
     const int32_t* count_in = nullptr;
     LaneSet<T> src = usr;
+    // The LAST round (automatic: the one at 24 iterations; "final_round"): its tail kernel takes
+    // whatever is left, however many, and runs it to termination — no lane chunk, no further
+    // round is enqueued behind it.  Every round after the one whose tail ran used to be three or
+    // four empty launches (14-19 us each round; 65536 problems of the bench workload: the rounds at
+    // 24, 48 and 96 iterations).  What survives 24 iterations are the long accept / reject chains
+    // the speculative kernel is built for, and their iteration counts spread over 25 ... 150: a
+    // lane chunk would idle on its slowest lane.
+    const int final_round = (!spec_tail || wave_tail <= 0) ? 0
+        : (h->opt_final_round >= 0 ? h->opt_final_round : kFinalRound);
     while (done < max_iter) {
       int32_t* const count = cv.count + round;
-      hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
-                         src_user ? 1 : 0, count_in, cv.set[cur], count, usr, c.trap);
+      if (!fused)
+        hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src,
+                           src_user ? 1 : 0, count_in, cv.set[cur], count, usr, c.trap);
       const LaneSet<T>& w = cv.set[cur];
+      const bool last_round = final_round > 0 && round + 1 >= final_round;
       if (wave_tail > 0 && done >= 4) {
         using WL = Launch<T, Sys>;
         const size_t lds_f = WL::fstep_lds_bytes(N);
@@ -846,7 +884,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
         t.X = w.X; t.U = w.U; t.x_term = w.x_term; t.lamb = w.lamb; t.obs = w.obs;
         t.cost = w.cost; t.K = w.K; t.k = w.k; t.iters = w.iters; t.status = w.status;
         t.dbg = nullptr;
-        t.count = count; t.count_max = wave_tail; t.max_total = max_iter;
+        t.count = count; t.count_max = last_round ? (int)B : wave_tail; t.max_total = max_iter;
         t.set_stride = B;
         if (spec_tail) {
           // the speculative tail delivers its problems to the caller's arrays itself (the
@@ -868,6 +906,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
           }
         }
       }
+      if (last_round && spec_tail) {  // everything has been delivered by the tail kernel
+        src_user = true;  // (nothing left to scatter)
+        break;
+      }
       // chunk lengths after the first: one chunk of 4 (the tail's second chance), then as many
       // iterations as are done (first chunk 10: compaction points at 10, 14, 28, 56 iterations).
       // Once the tail has run, every further round is three empty launches (14 us), so few of
@@ -881,7 +923,9 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       a.K = nullptr; a.k = nullptr;  // gains of work sets go to the scratch buffer (w.K == wsK)
       a.iters = w.iters; a.status = w.status;
       a.count = count; a.resume = 1; a.n_iters = len;
-      if (a.wsX) a.wsX = cv.set[cur ^ 1].X;  // (consumed by the compaction in front of this chunk)
+      // the chunk's exit packs its survivors into the OTHER work set (none behind the last chunk)
+      plan_exit(a, false, w.orig, done + len >= max_iter ? nullptr : &cv.set[cur ^ 1],
+                cv.count + round + 1);
       // a batch too large for the helper-wavefront form as a whole: its survivors may not be.
       // Both kernels are enqueued and the live count decides on the device which one runs (the
       // other is an empty launch, ~3 us): 21000 survivors of 65536 problems iterate at 46
@@ -908,7 +952,7 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
       round++;
     }
     // every remaining problem has a terminal status now: scatter them all
-    if (!src_user) {
+    if (!fused && !src_user) {
       LaneSet<T> none;
       std::memset(&none, 0, sizeof(none));
       hipLaunchKernelGGL((k_lane_compact<T, TILED>), dim3(cgrid), dim3(256), 0, s, n, m, N, src, 0,
@@ -1459,6 +1503,8 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->opt_merge = h->opt_ckpt = h->opt_spec = h->opt_stagger = h->opt_group_ws = -1;
   h->wave_tail = -1;
   h->opt_first_chunk = -1;
+  h->opt_fuse = -1;
+  h->opt_final_round = -1;
   h->opt_chunk_step = -1;
   h->opt_pair = -1;
   h->opt_two_x = -1;
@@ -1662,6 +1708,8 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "helper_wavefront")) h->opt_pair = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "state_buffers")) h->opt_two_x = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "chunk_step")) h->opt_chunk_step = v < 1 ? -1 : (v > 1024 ? 1024 : v);
+  else if (!strcmp(name, "fused_compaction")) h->opt_fuse = v < 0 ? -1 : (v != 0);
+  else if (!strcmp(name, "final_round")) h->opt_final_round = v < 0 ? -1 : (v > 20 ? 20 : v);
   else if (!strcmp(name, "speculate")) h->opt_spec = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "group_workspace")) h->opt_group_ws = v < 0 ? -1 : (v != 0);
   else if (!strcmp(name, "debug_self_test")) {

@@ -50,6 +50,27 @@ template <int Begin, int End, class F> __device__ __forceinline__ void static_fo
 #define I2LQR_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+template <class T> struct LaneSet {   // one set of per-problem arrays, batch-minor, row stride B
+  T* X; T* U; T* x_term; T* obs; T* lamb; T* cost; T* K; T* k;
+  int32_t* iters; int32_t* status; int32_t* orig;
+  int64_t B;
+};
+
+// Compaction folded into the EXIT of a chunk of the chunked solve (round 6; before: a kernel of its
+// own, k_lane_compact, between every two chunks).  A wavefront that has finished its chunk packs
+// its still-running problems into the next work set — ONE atomic add per wavefront claims their
+// slots — and scatters the problems that terminated to the caller's arrays, while the other
+// wavefronts of the launch are still iterating.
+template <class T> struct LaneCompact {
+  int on;             // 0: the kernel's exit is the plain one
+  int src_is_user;    // the chunk ran on the caller's arrays: terminated problems are in place
+  int user_tiled;     // the caller's arrays are batch-tiled (else batch-minor)
+  const int32_t* orig;  // [chunk's columns] index of each problem in the caller's arrays (work sets)
+  LaneSet<T> dst;     // work set that receives the survivors; X null: the last chunk, nothing survives
+  int32_t* count_out; // slot counter of dst (zeroed by the host before the first chunk)
+  LaneSet<T> usr;     // the caller's arrays (K / k / iters / status may be null)
+};
+
 template <class T> struct LaneArgs {
   int64_t B;                 // row stride (capacity) of every array; also the batch unless `count`
   int n_iters, early_exit;
@@ -75,7 +96,96 @@ template <class T> struct LaneArgs {
   int merge;      // deferred mode: accepted candidate inputs are merged into ONE input buffer
   int ckpt;       // only every kSeg-th state lives in HBM between the passes (see backward<.., CK>)
   int stagger;    // fused kernels: every second half-thousand of workgroups starts this many x ~8000 cycles late
+  LaneCompact<T> cp;  // chunked solve: compaction at the kernel's exit (cp.on)
 };
+
+// Exit of a chunk with the compaction folded in (LaneCompact).  Called by every lane that took part
+// in the chunk, with the arrays as the KERNEL sees them (re-based to the wavefront: element (row,
+// lane) at p[row * Bs + bl]) and the lane's final lamb / cost / iteration count / status.
+//   terminated (status != 0)  chunk on a work set: X, U, gains, lamb, cost, iters, status go to the
+//                             caller's arrays at orig[b]; chunk on the caller's arrays: in place.
+//   running (status == 0)     x_0, the inputs, x_term, obs, lamb, the iteration count and the
+//                             original index go to slot base + rank of the next work set, base from
+//                             ONE atomic add per wavefront (every chunk starts by rolling the states
+//                             out again, so a survivor carries its inputs and x_0 only).
+// The order of the slots is arbitrary (every problem is independent: results do not depend on it).
+template <class T>
+__device__ __forceinline__ void lane_exit_compact(const LaneCompact<T>& cp, const int n, const int m,
+                                                  const int N, const int64_t b, const int64_t Bs,
+                                                  const unsigned bl, const T* X, const T* U,
+                                                  const T* xt, const T* ob, const T* gK, const T* gk,
+                                                  const T lamb, const T cost, const int iters,
+                                                  const int status, unsigned long long* trap) {
+  (void)trap;
+  const int rx = n * (N + 1), ru = m * N, rK = m * n * N;
+  const LaneSet<T>& usr = cp.usr;
+  auto uaddr = [&](int rows, int row, int64_t p) -> int64_t {
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, row, rows);
+    I2LQR_DBG_CHECK(trap, TAG_COMPACT, p, usr.B);
+    if (cp.user_tiled) return ((p >> 6) * rows + row) * 64 + (p & 63);
+    return (int64_t)row * usr.B + p;
+  };
+  // rows are moved 32 at a time: 32 independent loads in flight, then 32 stores.  The exit runs
+  // with one or two wavefronts per SIMD and every wavefront of a chunk reaches it at about the
+  // same time, so what it costs is round trips to memory, not bytes (eight rows per round trip:
+  // +41 us on the first chunk of 65536 problems, as much as the k_lane_compact launch it replaced).
+  auto move_rows = [&](int rows, auto&& dst_at, auto&& src_at) __attribute__((always_inline)) {
+    constexpr int W = 32;
+    for (int r = 0; r < rows; r += W) {
+      T v[W];
+#pragma unroll
+      for (int q = 0; q < W; q++)
+        if (r + q < rows) v[q] = src_at(r + q);
+#pragma unroll
+      for (int q = 0; q < W; q++)
+        if (r + q < rows) dst_at(r + q, v[q]);
+    }
+  };
+  const bool run = status == 0;
+  const unsigned long long mask = __ballot(run);
+  if (!run) {
+    if (cp.src_is_user || (status & kStatusDelivered)) return;  // in place / the tail kernel's
+    const int64_t o = cp.orig[b];
+    move_rows(rx, [&](int r, T v) { usr.X[uaddr(rx, r, o)] = v; },
+              [&](int r) { return X[(int64_t)r * Bs + bl]; });
+    move_rows(ru, [&](int r, T v) { usr.U[uaddr(ru, r, o)] = v; },
+              [&](int r) { return U[(int64_t)r * Bs + bl]; });
+    if (usr.K) {
+      move_rows(rK, [&](int r, T v) { usr.K[uaddr(rK, r, o)] = v; },
+                [&](int r) { return gK[(int64_t)r * Bs + bl]; });
+      move_rows(ru, [&](int r, T v) { usr.k[uaddr(ru, r, o)] = v; },
+                [&](int r) { return gk[(int64_t)r * Bs + bl]; });
+    }
+    usr.lamb[o] = lamb;
+    usr.cost[o] = cost;
+    if (usr.iters) usr.iters[o] = iters;
+    if (usr.status) usr.status[o] = status;
+    return;
+  }
+  const LaneSet<T>& dst = cp.dst;
+  if (!dst.X) return;  // (cannot happen: the last chunk leaves no problem running)
+  // the running lanes of this wavefront claim consecutive slots with one atomic add
+  const unsigned lane = threadIdx.x & 63;
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  int base = 0;
+  if (rank == 0) base = atomicAdd(cp.count_out, __popcll(mask));
+  base = __builtin_amdgcn_readfirstlane(base);  // (the first active lane here IS the lane of rank 0)
+  const int64_t j = (int64_t)base + rank;
+  I2LQR_DBG_CHECK(trap, TAG_COMPACT, j, dst.B);
+  move_rows(n, [&](int r, T v) { dst.X[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return X[(int64_t)r * Bs + bl]; });
+  move_rows(ru, [&](int r, T v) { dst.U[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return U[(int64_t)r * Bs + bl]; });
+  move_rows(n, [&](int r, T v) { dst.x_term[(int64_t)r * dst.B + j] = v; },
+            [&](int r) { return xt[(int64_t)r * Bs + bl]; });
+  if (ob)
+    move_rows(6, [&](int r, T v) { dst.obs[(int64_t)r * dst.B + j] = v; },
+              [&](int r) { return ob[(int64_t)r * Bs + bl]; });
+  dst.lamb[j] = lamb;
+  dst.iters[j] = iters;
+  dst.status[j] = 0;  // RUNNING (a tail launch may finish it before the next chunk sees it)
+  dst.orig[j] = cp.src_is_user ? (int32_t)b : cp.orig[b];
+}
 
 // State checkpointing (fp64, large batches: the kernel sits on the HBM roof).  Between the passes of
 // an iteration only the states x_0, x_4, x_8, ... are kept in HBM; the backward pass re-rolls the
@@ -1669,9 +1779,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
   if (a.count && (live <= a.count_lo || live > a.count_hi)) return;  // the other kernel's chunk
-  if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
   const int N = c.N;
   const LaneView<TILED> v(a.B);
+  if (a.resume && a.status[b] != 0) {  // finished since the compaction (tail kernel)
+    // fused compaction: what a tail kernel finished without delivering it goes to the caller now
+    if (a.cp.on && true)
+      lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, v.rebase(a.X, n * (N + 1)),
+                        v.rebase(a.U, m * N), v.rebase(a.x_term, n), v.rebase(a.obs, 6),
+                        v.rebase(a.K ? a.K : a.wsK, m * n * N), v.rebase(a.K ? a.k : a.wsk, m * N),
+                        a.lamb[b], a.cost[b], a.iters[b], a.status[b], c.trap);
+    return;
+  }
   LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   extern __shared__ __align__(16) unsigned char lane_smem[];
   typedef __attribute__((address_space(3))) T lds_t;
@@ -1817,6 +1935,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? I2LQR_F32_WAVES : I2LQR_F64_W
   a.cost[b] = cost_ret;
   if (a.iters) a.iters[b] = it0 + it;
   if (a.status) a.status[b] = status;
+  if (a.cp.on)
+    lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, X, U0, gxt, gob, gK, gk, lamb, cost_ret, it0 + it,
+                      status, c.trap);
 }
 
 // k_lane_iterate with a HELPER wavefront (round 5; VERDICT r4 #4: 8 k - 32 k problems).  Up to 32768
@@ -1837,9 +1958,17 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
   if (a.count && (live <= a.count_lo || live > a.count_hi)) return;  // the other kernel's chunk
-  if (a.resume && a.status[b] != 0) return;  // finished since the compaction (wave-kernel tail)
   const int N = c.N;
   const LaneView<TILED> v(a.B);
+  if (a.resume && a.status[b] != 0) {  // finished since the compaction (tail kernel)
+    // fused compaction: what a tail kernel finished without delivering it goes to the caller now
+    if (a.cp.on && role == 0)
+      lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, v.rebase(a.X, n * (N + 1)),
+                        v.rebase(a.U, m * N), v.rebase(a.x_term, n), v.rebase(a.obs, 6),
+                        v.rebase(a.K ? a.K : a.wsK, m * n * N), v.rebase(a.K ? a.k : a.wsk, m * N),
+                        a.lamb[b], a.cost[b], a.iters[b], a.status[b], c.trap);
+    return;
+  }
   LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   extern __shared__ __align__(16) unsigned char lane_smem[];
   typedef __attribute__((address_space(3))) T lds_t;
@@ -2031,6 +2160,9 @@ __global__ __launch_bounds__(128, 1) void k_lane_iterate_pair(
   a.cost[b] = cost_ret;
   if (a.iters) a.iters[b] = it0 + it;
   if (a.status) a.status[b] = status;
+  if (a.cp.on)
+    lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, X0, U0, gxt, gob, gK, gk, lamb, cost_ret, it0 + it,
+                      status, c.trap);
 }
 
 // The fused kernel of the row-block plants (quad12): k_lane_iterate's deferred, merged form — the
@@ -2048,9 +2180,16 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t live = a.count ? (int64_t)*a.count : a.B;
   if (b >= live) return;
-  if (a.resume && a.status[b] != 0) return;
   const int N = c.N;
   const LaneView<TILED> v(a.B);
+  if (a.resume && a.status[b] != 0) {
+    if (a.cp.on)  // fused compaction (see k_lane_iterate)
+      lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, v.rebase(a.X, n * (N + 1)),
+                        v.rebase(a.U, m * N), v.rebase(a.x_term, n), v.rebase(a.obs, 6),
+                        v.rebase(a.K ? a.K : a.wsK, m * n * N), v.rebase(a.K ? a.k : a.wsk, m * N),
+                        a.lamb[b], a.cost[b], a.iters[b], a.status[b], c.trap);
+    return;
+  }
   LaneWorker<T, Sys, HASQR, TILED> w(c, v.Bs, v.bl);
   const T* gxt = v.rebase(a.x_term, n);
   const T* gob = v.rebase(a.obs, 6);
@@ -2142,6 +2281,9 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
   if (a.dbg && threadIdx.x == 0)
     for (int q = 0; q < 8; q++) a.dbg[blockIdx.x * 8 + q] = w.st_acc[q];
 #endif
+  if (a.cp.on)
+    lane_exit_compact(a.cp, n, m, N, b, v.Bs, v.bl, X, U0, gxt, gob, gK, gk, lamb, cost_ret, it0 + it,
+                      status, c.trap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2151,12 +2293,6 @@ __global__ __launch_bounds__(64, 1) void k_lane_iterate_rows(const DevCfg<T, Sys
 // wavefronts are full again.  Order inside the destination is arbitrary (atomic slot counter,
 // wave-aggregated by the compiler): every problem is independent, results do not depend on it.
 // ---------------------------------------------------------------------------------------------
-template <class T> struct LaneSet {   // one set of per-problem arrays, batch-minor, row stride B
-  T* X; T* U; T* x_term; T* obs; T* lamb; T* cost; T* K; T* k;
-  int32_t* iters; int32_t* status; int32_t* orig;
-  int64_t B;
-};
-
 template <class T, bool USER_TILED>
 __global__ __launch_bounds__(256) void k_lane_compact(int n, int m, int N, LaneSet<T> src,
                                                       int src_is_user, const int32_t* count_in,

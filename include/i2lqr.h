@@ -257,6 +257,19 @@ int i2lqr_set_compaction(i2lqr_handle* h, int64_t min_batch);
  *   "first_chunk", "chunk_step"  chunked solve only: length of the first chunk (automatic: 8) and
  *                     of the one behind it (automatic: 4) — hand-tuned schedules, there to measure
  *                     the automatic one against (tools/solve_bench.py).  Same results either way.
+ *   "fused_compaction"  chunked solve only (round 6).  1 (automatic): the compaction is folded into
+ *                     the EXIT of the chunk kernels — a wavefront that has finished its chunk packs
+ *                     its still-running problems into the next work set (one atomic add per
+ *                     wavefront claims their slots) and scatters the terminated ones to the
+ *                     caller's arrays while the other wavefronts still iterate; 0: a k_lane_compact
+ *                     launch between every two chunks and a scatter pass at the end (rounds 3-5).
+ *                     Same results (the order of a work set's slots differs; nothing depends on it).
+ *   "final_round"     chunked solve with the speculative tail only (round 6): the tail kernel of
+ *                     round r = value (1: at 8 iterations, 2: at 12, 3: at 24, ...) takes EVERY
+ *                     survivor, however many, and runs it to termination; nothing is enqueued behind
+ *                     it (the rounds behind the one whose tail ran were three to four empty launches
+ *                     each).  Automatic: 3.  0: never (the schedule runs to max_iter as in round 5).
+ *                     Same results either way.
  * Problem-major layout, i2lqr_iterate / i2lqr_solve:
  *   "group_lanes"     lanes of a wavefront that work on one problem: 64 (one problem per
  *                     wavefront, each lane one element of the Riccati step's products), 8 (eight

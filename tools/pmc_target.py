@@ -20,6 +20,8 @@ ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--options", default="", help="i2lqr_set_option settings: 'name=value name=value'")
 ap.add_argument("--solve", action="store_true", help="i2lqr_solve (to termination) instead of "
                 "a fixed iteration count")
+ap.add_argument("--sync-each", action="store_true", help="synchronise and pause 2 ms after every "
+                "launch (tools/solve_timeline.py separates the solves of a kernel trace by the gaps)")
 args = ap.parse_args()
 cfg = workloads.config_for(args.workload, args.dtype)
 cfg.layout = {"wave": 0, "lane": 1, "tiled": 2}[args.layout]
@@ -44,5 +46,9 @@ for buf in bufs:
         solver.solve(buf)
     else:
         solver.iterate(buf, args.iters)
+    if args.sync_each:
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.002)
 torch.cuda.synchronize()
 print("done", args)
