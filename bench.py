@@ -67,6 +67,12 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="all-gather of the costs: native = i2lqr_allgather_costs (RCCL through the "
                          "C-ABI), torch = torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--handoff", default="gather", choices=["gather", "broadcast"],
+                    help="--gpus N: how the winner reaches every rank in the TIMED step: gather = the "
+                         "local winners' packs ride in the grouped all-gather (one collective, no "
+                         "host round trip; the default), broadcast = all-gather of the costs, pick "
+                         "read back, ONE ncclBroadcast from the owner (two collectives: the form to "
+                         "fall back on should grouped collectives misbehave on a node)")
     ap.add_argument("--exchange-only", action="store_true",
                     help="CPU/gloo dry run of the multi-rank harness without the solve (see above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -432,7 +438,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
             torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    seconds = timed_loop()
+    seconds = timed_loop(args.handoff if exchange is not None else "gather")
     rank_seconds = [seconds]
     if grouped:
         t = torch.tensor([seconds], dtype=torch.float64,
@@ -472,8 +478,13 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         res["one_call_round"] = bool(one_call)
         # the pick is the same on every rank, is the first-index arg-min of the gathered vector, and
         # the pack every rank holds is the trajectory its owner solved
-        idx, owner = (int(v) for v in picks[-1].cpu())
-        first, best = dist_mod.select_best_flat(cost_alls[warmup + steps - 1])
+        if args.handoff == "gather":
+            idx, owner = (int(v) for v in picks[-1].cpu())
+            first, best = dist_mod.select_best_flat(cost_alls[warmup + steps - 1])
+        else:  # (two-collective form: the pick is a host integer, the costs are gathered again here)
+            idx = int(picks[-1])
+            owner = idx // B
+            first, best = dist_mod.select_best_flat(xch.allgather(cost_its[warmup + steps - 1]))
         assert idx == first, f"exchange / pick mismatch: {idx} vs {first}"
         assert owner == idx // B, (owner, idx, B)
         if owner == rank:
@@ -481,7 +492,10 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                 [idx - rank * B], dtype=torch.int64, device=solver.device))
             assert torch.equal(mine, winners[-1]), "the handed-over pack is not the owner's trajectory"
         assert bool(torch.isfinite(winners[-1]).all())
-        res["handoff"] = ("winner packs ride in the all-gather: ONE grouped collective "
+        res["handoff"] = ("--handoff broadcast: all-gather of the costs + i2lqr_argmin + 8-byte read-back "
+                          "+ i2lqr_pack_problem on the owner + ONE ncclBroadcast (i2lqr_broadcast_winner)"
+                          if args.handoff == "broadcast" else
+                          "winner packs ride in the all-gather: ONE grouped collective "
                           "(i2lqr_allgather_round) + pick + owner's pack (i2lqr_round_pick), no host "
                           "round trip; the whole round is one C-ABI call" if one_call else
                           "winner packs ride in the all-gather (i2lqr_allgather_round / torch) + "
@@ -500,7 +514,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         # arg-min, round winner; what round 5 timed) on fresh copies of the batch: the phase marks
         # of the exchange come from here, and its ms_per_step beside the one-call form's is what
         # the C entry point buys on this box.
-        if B <= 65536:
+        if B <= 65536 and args.handoff == "gather":
             fresh_sets()
             h_seconds = timed_loop("gather_host")
             res["exchange_ms"] = ms("start", "picked")
@@ -511,7 +525,7 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
         # The two-collective form for comparison (the pick read back, ONE ncclBroadcast from the
         # owner: i2lqr_broadcast_winner — what the controller's list-of-lists rounds use), on fresh
         # copies of the batch, same steps: its host round trip per step serialises the pipeline.
-        if B <= 65536:
+        if B <= 65536 and args.handoff == "gather":
             fresh_sets()
             b_seconds = timed_loop("broadcast")
             res["broadcast_variant"] = {

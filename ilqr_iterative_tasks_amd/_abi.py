@@ -177,6 +177,7 @@ EXPORTS = {
     "i2lqr_create": (C.c_int, [C.POINTER(I2lqrConfig), C.POINTER(_P)]),
     "i2lqr_destroy": (C.c_int, [_P]),
     "i2lqr_device_geometry": (C.c_int, [C.POINTER(C.c_int32), C.c_int32]),
+    "i2lqr_dry_run": (C.c_int64, [C.c_int32, _P, C.c_int64]),
     "i2lqr_recommended_layout": (C.c_int, [C.POINTER(I2lqrConfig), C.c_int64, C.c_int32]),
     "i2lqr_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
     "i2lqr_set_workspace": (C.c_int, [_P, _P, C.c_int64]),

@@ -25,6 +25,9 @@
 
 #include "i2lqr_lane12.h"
 
+#define I2LQR_DRY_RUN_LANE 1
+#include "i2lqr_dryrun.hpp"  // (empty unless -DI2LQR_DRY_RUN: the ASan build)
+
 using namespace i2lqr;
 
 namespace {
@@ -47,6 +50,89 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 }  // namespace
+
+#ifdef I2LQR_DRY_RUN
+#include <string>
+#include <vector>
+namespace i2lqr {
+namespace dry {
+namespace {
+struct State {
+  std::mutex mu;
+  std::vector<std::pair<uintptr_t, uintptr_t>> ranges;
+  std::string text;
+  int64_t launches = 0, violations = 0;
+};
+State& st() {
+  static State s;
+  return s;
+}
+}  // namespace
+bool on() {
+  static const bool v = [] {
+    const char* e = getenv("I2LQR_DRY_RUN");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+void allow(const void* base, size_t bytes) {
+  std::lock_guard<std::mutex> lock(st().mu);
+  st().ranges.emplace_back((uintptr_t)base, (uintptr_t)base + bytes);
+}
+void reset() {
+  std::lock_guard<std::mutex> lock(st().mu);
+  st().ranges.clear();
+  st().text.clear();
+  st().launches = st().violations = 0;
+}
+void record(const char* kernel, dim3 grid, dim3 block, size_t lds) {
+  std::lock_guard<std::mutex> lock(st().mu);
+  char line[384];
+  snprintf(line, sizeof(line), "launch %.200s grid %u block %u lds %zu\n", kernel, grid.x, block.x, lds);
+  if (st().text.size() < (1u << 15)) st().text += line;
+  st().launches++;
+  const DeviceGeometry& g = device_geometry();
+  if (grid.x == 0 || block.x == 0 || block.x > 1024 || lds > g.max_dyn_lds) {
+    st().violations++;
+    snprintf(line, sizeof(line), "VIOLATION %.200s: launch shape grid %u block %u lds %zu\n", kernel,
+             grid.x, block.x, lds);
+    st().text += line;
+  }
+}
+void ptr(const char* kernel, const char* field, const void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(st().mu);
+  const uintptr_t a = (uintptr_t)p;
+  for (const auto& r : st().ranges)
+    if (a >= r.first && a < r.second) return;
+  st().violations++;
+  char line[384];
+  snprintf(line, sizeof(line), "VIOLATION %.200s: %s = %p lies in no declared range\n", kernel, field, p);
+  st().text += line;
+}
+int64_t report(char* buf, int64_t n) {
+  std::lock_guard<std::mutex> lock(st().mu);
+  if (buf && n > 0) {
+    // violations first: the buffer may be shorter than the launch log
+    std::string out;
+    size_t pos = 0;
+    while ((pos = st().text.find("VIOLATION", pos)) != std::string::npos) {
+      const size_t end = st().text.find('\n', pos);
+      out += st().text.substr(pos, end == std::string::npos ? std::string::npos : end - pos + 1);
+      if (end == std::string::npos) break;
+      pos = end + 1;
+    }
+    out += st().text;
+    snprintf(buf, (size_t)n, "%s", out.c_str());
+  }
+  st().text.clear();
+  const int64_t v = st().violations;
+  st().violations = 0;
+  return v;
+}
+}  // namespace dry
+}  // namespace i2lqr
+#endif
 
 namespace i2lqr {
 // hipDeviceGetAttribute once per device; I2LQR_FAKE_CUS=<n> (a debug override, parity tests of the
@@ -1484,7 +1570,12 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
                       "symmetric R (use the problem-major layout otherwise)");
   }
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+#ifdef I2LQR_DRY_RUN
+  const bool dry_run = dry::on();  // (sanitizer build + I2LQR_DRY_RUN=1: launches are recorded, not run)
+#else
+  constexpr bool dry_run = false;
+#endif
+  if (!dry_run && (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0))
     return fail(I2LQR_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");
   i2lqr_handle* h = new (std::nothrow) i2lqr_handle;
   if (!h) return fail(I2LQR_ERR_LAUNCH, "out of host memory");
@@ -1513,7 +1604,14 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   h->ev_ready = h->ev_side_done = nullptr;
   h->side_pending = false;
   constexpr size_t kTicketBytes = i2lqr_handle::kTickets * sizeof(unsigned);
-  if (hipGetDevice(&h->device) != hipSuccess ||
+  if (dry_run) {
+#ifdef I2LQR_DRY_RUN
+    static unsigned fake_tickets[i2lqr_handle::kTickets];  // an address to declare, never written by a kernel
+    h->device = 0;
+    h->ticket = fake_tickets;
+    dry::allow(fake_tickets, sizeof(fake_tickets));
+#endif
+  } else if (hipGetDevice(&h->device) != hipSuccess ||
       hipMalloc((void**)&h->ticket, kTicketBytes) != hipSuccess ||
       hipMemset(h->ticket, 0, kTicketBytes) != hipSuccess) {
     if (h->ticket) (void)hipFree(h->ticket);
@@ -1534,6 +1632,23 @@ int i2lqr_create(const i2lqr_config* cfg, i2lqr_handle** out) {
   *out = h;
   g_err[0] = 0;
   return I2LQR_OK;
+}
+
+int64_t i2lqr_dry_run(int32_t op, void* p, int64_t n) {
+#ifdef I2LQR_DRY_RUN
+  switch (op) {
+    case 0: return dry::on() ? 1 : 0;
+    case 1: if (!dry::on()) break; dry::allow(p, (size_t)n); return 0;
+    case 2: if (!dry::on()) break; dry::reset(); return 0;
+    case 3: if (!dry::on()) break; return dry::report((char*)p, n);
+    default: return fail(I2LQR_ERR_INVALID, "i2lqr_dry_run: unknown operation %d", op);
+  }
+  return fail(I2LQR_ERR_UNSUPPORTED, "dry-run launches need I2LQR_DRY_RUN=1 in the environment");
+#else
+  (void)op; (void)p; (void)n;
+  return fail(I2LQR_ERR_UNSUPPORTED, "dry-run launches exist in the sanitizer build only (make -C "
+              "ilqr_iterative_tasks_amd/csrc asan -> libi2lqr_hip_asan.so, I2LQR_DRY_RUN=1)");
+#endif
 }
 
 int i2lqr_device_geometry(int32_t* out, int32_t count) {

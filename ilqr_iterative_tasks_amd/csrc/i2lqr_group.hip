@@ -4,6 +4,7 @@
 #include "i2lqr_devcfg.hpp"
 #include "i2lqr_geometry.hpp"
 #include "i2lqr_group.hpp"
+#include "i2lqr_dryrun.hpp"  // (empty unless -DI2LQR_DRY_RUN: the ASan build)
 
 namespace i2lqr {
 

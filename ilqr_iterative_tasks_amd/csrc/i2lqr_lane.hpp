@@ -231,6 +231,15 @@ template <bool TILED> struct LaneView {
   }
 };
 
+#ifndef I2LQR_ROWS_NT
+#define I2LQR_ROWS_NT 1
+#endif
+constexpr bool kRowsNT = I2LQR_ROWS_NT != 0;
+#ifndef I2LQR_ROWS_NT_ALL
+#define I2LQR_ROWS_NT_ALL 0
+#endif
+constexpr bool kRowsNTAll = I2LQR_ROWS_NT_ALL != 0;  // experiment: every row access of those kernels
+
 #ifndef I2LQR_DEEP_PREFETCH
 #define I2LQR_DEEP_PREFETCH 1
 #endif
@@ -322,7 +331,14 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
   // scalar base + immediate, and counted in BOTH vmcnt and lgkmcnt: every wait for an LDS read then
   // also waited for the 52 gain stores in flight to HBM.  f takes (index, const T&) to read the
   // word or (index, T&) to assign it.
-  template <int CNT, class P, class F>
+  // NT: the words are touched once per pass (the gains of the row-block plants: written by the
+  // backward pass, read by the forward pass, 4 GB apart at 65536 problems) — non-temporal accesses,
+  // so that they do not push the state and input rows the prefetches brought in out of the caches.
+  // Round 6, same-process A/B (profiles/r06_ab_quad12_nontemporal.json): quad12 65536 problems fp64
+  // 76.8 -> 78.9 M it/s, fp32 92.7 -> 99.8, 16384 problems 31.1 -> 32.1, stage weights 19.2 -> 20.0;
+  // on EVERY row access of the kernel (-DI2LQR_ROWS_NT_ALL=1): 79.6 / 97.7 / 31.1 / 20.2 — not
+  // ahead everywhere, so only the gains.  Same values either way (cache hints).
+  template <int CNT, bool NT = kRowsNTAll, class P, class F>
   __device__ __forceinline__ void for_rows(P* p, int row0, F&& f) const {
     I2LQR_DBG_CHECK(c.trap, TAG_LANE_ROW_K, row0 + CNT - 1, m * n * N + n);  // (largest array)
     using V = std::remove_const_t<P>;
@@ -335,13 +351,16 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
         using IC = std::integral_constant<int, 8 * g + r>;
         GP* word = q + (int64_t)r * stride() + lane;
         if constexpr (std::is_invocable_v<F&, IC, const V&>) {
-          const V v = *word;
+          V v;
+          if constexpr (NT) v = __builtin_nontemporal_load(word);
+          else v = *word;
           f(IC{}, v);
         } else {
           V v;
           f(IC{}, v);
           typedef __attribute__((address_space(1))) V GV;
-          *const_cast<GV*>(word) = v;  // (this branch is only taken with a non-const P)
+          if constexpr (NT) __builtin_nontemporal_store(v, const_cast<GV*>(word));
+          else *const_cast<GV*>(word) = v;  // (this branch is only taken with a non-const P)
         }
       });
     });
@@ -1494,9 +1513,9 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
           __builtin_amdgcn_s_waitcnt(0x0F70);
           I2LQR_PHASE_FENCE();
         }
-        for_rows<n>(gK, rK(a, 0, t), [&](auto j_, T& w) { w = g[decltype(j_)::value]; });
+        for_rows<n, kRowsNT>(gK, rK(a, 0, t), [&](auto j_, T& w) { w = g[decltype(j_)::value]; });
       });
-      for_rows<m>(gk, ru(0, t), [&](auto a_, T& w) {
+      for_rows<m, kRowsNT>(gk, ru(0, t), [&](auto a_, T& w) {
         w = kcs[(decltype(a_)::value * (n + 1) + n) * 64 + lrd];
       });
       STAMP_END(2);
@@ -1660,11 +1679,11 @@ template <class T, class Sys, bool HASQR, bool TILED> struct LaneWorker {
     for (int i = 0; i < n; i++) xo[i] = x[i];
     auto load_step = [&](const int t, Buf& b) __attribute__((always_inline)) {
       for_rows<m>(U, ru(0, t), [&](auto a_, const T& w) { b.ul[decltype(a_)::value] = w; });
-      for_rows<m * n>(gK, rK(0, 0, t), [&](auto e_, const T& w) {
+      for_rows<m * n, kRowsNT>(gK, rK(0, 0, t), [&](auto e_, const T& w) {
         constexpr int e = decltype(e_)::value;
         b.kl[e / n][e % n] = w;
       });
-      for_rows<m>(gk, ru(0, t), [&](auto a_, const T& w) { b.kl[decltype(a_)::value][n] = w; });
+      for_rows<m, kRowsNT>(gk, ru(0, t), [&](auto a_, const T& w) { b.kl[decltype(a_)::value][n] = w; });
     };
     // step 0: x_0 is common to the nominal and the candidate, K_0 multiplies zeros and is not read
     for_rows<m>(U, ru(0, 0), [&](auto a_, const T& w) { q[0].ul[decltype(a_)::value] = w; });

@@ -6,6 +6,7 @@
 
 #include "i2lqr_devcfg.hpp"
 #include "i2lqr_quad.hpp"
+#include "i2lqr_dryrun.hpp"  // (empty unless -DI2LQR_DRY_RUN: the ASan build)
 
 namespace i2lqr {
 

@@ -142,6 +142,21 @@ int i2lqr_destroy(i2lqr_handle* h);
 int i2lqr_device_geometry(int32_t* out, int32_t count);
 
 /*
+ * Sanitizer hook (round 6).  In the AddressSanitizer / UBSan build of the
+ * library (make asan -> libi2lqr_hip_asan.so) with I2LQR_DRY_RUN=1 in the environment,
+ * i2lqr_create needs no device and every kernel launch behind the handle becomes a RECORD (kernel,
+ * grid, workgroup size, dynamic LDS) whose pointer arguments — plain ones and every pointer field of
+ * the kernels' argument blocks — must lie in a range declared here: the host code behind a live
+ * handle (workspace carving, the chunked solve's scheduler, LDS budgeting, the sharded round) runs
+ * under the sanitizers on a box without a GPU (tools/dry_run_fuzz.py).
+ *   op 0: 1 if dry-run launches are active;  op 1: declare [p, p + n) (the workspace, a caller's
+ *   array);  op 2: forget ranges and records;  op 3: write the records and violations since the
+ *   last report into p[0..n) and return the number of violations.
+ * The product library answers I2LQR_ERR_UNSUPPORTED to every op.  No reference counterpart.
+ */
+int64_t i2lqr_dry_run(int32_t op, void* p, int64_t n);
+
+/*
  * Which cfg.layout to create the handle with for batches of B problems (host only, no GPU needed):
  * the layouts are different kernel FAMILIES — problem-major runs one problem per 64, 16 or 8 lanes
  * (latency kernels: up to ~10^4 problems), batch-minor / batch-tiled run one problem per lane (the

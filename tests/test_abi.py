@@ -152,7 +152,7 @@ def test_every_export_refuses_a_null_handle_or_null_buffers_on_the_host():
     lib = _abi.load_library()
     skip = {"i2lqr_version", "i2lqr_last_error", "i2lqr_argmin_workspace_bytes", "i2lqr_destroy",
             "i2lqr_comm_available", "i2lqr_comm_destroy", "i2lqr_comm_abort", "i2lqr_workspace_bytes",
-            "i2lqr_iterate_kernel", "i2lqr_solve_kernel"}
+            "i2lqr_iterate_kernel", "i2lqr_solve_kernel", "i2lqr_dry_run"}
     called = 0
     for name, (restype, argtypes) in _abi.EXPORTS.items():
         if name in skip:
@@ -227,3 +227,15 @@ def test_chip_geometry_lives_in_one_struct():
     if not queried:  # no device here: the MI355X figures
         assert (cus, lds, max_dyn, dflt, faked) == (256, 160 * 1024, 160 * 1024, 64 * 1024, 0)
     assert lib.i2lqr_device_geometry(None, 8) == -1
+
+
+def test_dry_run_hook_is_inert_in_the_product_library():
+    """i2lqr_dry_run (the sanitizer build's recorded launches, tools/dry_run_fuzz.py) answers
+    I2LQR_ERR_UNSUPPORTED in the shipped library, whatever the environment says: the product path
+    has no way to skip the device."""
+    if "asan" in str(_abi.LIB_PATH):
+        pytest.skip("the sanitizer build implements the hook")
+    lib = _abi.load_library()
+    for op in (0, 1, 2, 3):
+        assert lib.i2lqr_dry_run(op, None, 0) == -2
+    assert b"sanitizer build" in lib.i2lqr_last_error()

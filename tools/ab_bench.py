@@ -2,6 +2,7 @@
 """Interleaved A/B timing of the fused iterate kernel across layouts / dtypes / batches in ONE
 process (cdna guide §5.4 rule 24): variants x rounds, median and min per variant."""
 import argparse
+import json
 import sys
 from pathlib import Path
 
@@ -21,6 +22,8 @@ ap.add_argument("--cold", action="store_true", help="every timed launch runs on 
                 "leaves its inputs warm in the 256 MB Infinity Cache): what bench.py measures")
 ap.add_argument("--weights", action="store_true", help="stage weights Q, R != 0 (seeded random "
                 "positive semi-definite Q, positive definite R, a target off the origin)")
+ap.add_argument("--json", default=None, help="write the run as data (VERDICT r5 #10): per-round times "
+                "of every variant, medians, library hashes, device — the file a delta is quoted from")
 args = ap.parse_args()
 
 LAY = {"wave": 0, "lane": 1, "tiled": 2}
@@ -78,8 +81,25 @@ for r in range(args.rounds + 1):
         torch.cuda.synchronize()
         if r > 0:
             times.append(e0.elapsed_time(e1))
+doc = {"tool": "tools/ab_bench.py", "argv": sys.argv[1:], "workload": args.workload,
+       "iterations_per_launch": args.iters, "rounds": args.rounds, "cold": bool(args.cold),
+       "device": torch.cuda.get_device_name(0), "variants": []}
 for v, solver, buf, init, B, times in runs:
     t = np.array(times)
+    import hashlib
+    lib_file = getattr(solver.lib, "_name", None)
+    doc["variants"].append({
+        "variant": v, "batch": B, "ms_per_round": [float(x) for x in t], "ms_median": float(np.median(t)),
+        "ms_min": float(t.min()), "Mits_median": float(B * args.iters / np.median(t) / 1e3),
+        "kernel": solver.iterate_kernel(B), "library": lib_file,
+        "library_sha256": hashlib.sha256(Path(lib_file).read_bytes()).hexdigest()[:16] if lib_file else None})
     print(f"{v:56s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  -> "
           f"{B * args.iters / np.median(t) / 1e3:8.1f} M it/s (median)  "
           f"{B * args.iters / t.min() / 1e3:8.1f} (best)")
+if len(doc["variants"]) >= 2:
+    base = doc["variants"][0]["ms_median"]
+    for rec in doc["variants"][1:]:
+        rec["speedup_over_first"] = base / rec["ms_median"]
+if args.json:
+    Path(args.json).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.json).write_text(json.dumps(doc, indent=1))

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""The host code BEHIND a live handle under AddressSanitizer + UBSan:
+drives the dry-run form of the ASan build of the library (csrc/i2lqr_dryrun.hpp: I2LQR_DRY_RUN=1 —
+i2lqr_create skips the device, every kernel launch becomes a record whose pointer arguments must
+lie inside a declared range) through random configurations: plant x horizon x precision x layout x
+batch x scheduling options x entry point (rollout / backward / forward / iterate / solve /
+iterate_pick / sharded round).  The caller's arrays and the workspace are FAKE address ranges of
+exactly the sizes the layout prescribes; a carved or derived pointer that leaves them is a
+violation, an out-of-bounds host access or undefined behaviour is the sanitizers' report.
+
+    tools/run_host_sanitizers.sh            (builds the ASan library, preloads the runtime)
+    python tools/dry_run_fuzz.py --configs 1000"""
+import argparse
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ["I2LQR_DRY_RUN"] = "1"
+import numpy as np
+
+from ilqr_iterative_tasks_amd import _abi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--configs", type=int, default=1000)
+ap.add_argument("--seed", type=int, default=20260406)
+ap.add_argument("--verbose", action="store_true")
+args = ap.parse_args()
+
+lib = _abi.load_library()
+P = C.c_void_p
+assert lib.i2lqr_dry_run(0, None, 0) == 1, \
+    "this library has no dry-run form (needs the ASan build and I2LQR_DRY_RUN=1): " + \
+    lib.i2lqr_last_error().decode()
+
+rng = np.random.default_rng(args.seed)
+STREAM = P(0x1000)
+SIDE = P(0x2000)
+OPTIONS = {"defer_states": (0, 1), "reroll_nominal": (0, 1), "lds_gain_steps": (0, 1, 3, 7, 19, 40),
+           "merge_inputs": (0, 1), "checkpoint_states": (0, 1), "stagger": (0, 8, 45),
+           "per_step_jacobians": (0, 1), "wave_tail": (0, 512, 2048, 12288, 65536),
+           "first_chunk": (1, 4, 8, 12, 150), "helper_wavefront": (0, 1), "state_buffers": (0, 1),
+           "chunk_step": (1, 2, 4, 9), "speculate": (0, 1), "group_workspace": (0, 1),
+           "group_lanes": (8, 16, 64), "fused_compaction": (0, 1), "final_round": (0, 1, 2, 3, 5)}
+
+
+class Arena:
+    """Fake device addresses: every array gets its own range, declared to the library."""
+
+    def __init__(self):
+        self.next = 0x7000_0000_0000
+
+    def take(self, nbytes):
+        base = self.next
+        self.next += (int(nbytes) + 0xFFFF) // 0x10000 * 0x10000 + 0x10000  # a gap behind each
+        if nbytes > 0:
+            assert lib.i2lqr_dry_run(1, P(base), int(nbytes)) == 0
+        return P(base) if nbytes > 0 else P(None)
+
+
+def report():
+    buf = C.create_string_buffer(1 << 16)
+    bad = lib.i2lqr_dry_run(3, buf, len(buf))
+    return int(bad), buf.value.decode(errors="replace")
+
+
+# The checker must be live: a workspace DECLARED at half the size the library carves it to has to
+# come back as violations (the second work set of the chunked solve lies behind the declared half).
+cfg = _abi.default_config("bicycle6", 20, "f64", dt=0.25, layout=2)
+h = P()
+assert lib.i2lqr_create(C.byref(cfg), C.byref(h)) == 0, lib.i2lqr_last_error()
+B0 = 8192
+wsb = int(lib.i2lqr_workspace_bytes(h, B0))
+base = 0x6000_0000_0000
+assert lib.i2lqr_dry_run(1, P(base), wsb // 2) == 0
+assert lib.i2lqr_set_workspace(h, P(base), wsb) == 0
+arrs = []
+for nbytes in (B0 * 6 * 21 * 8, B0 * 2 * 20 * 8, B0 * 6 * 8, B0 * 8, B0 * 8):
+    a = 0x6800_0000_0000 + len(arrs) * 0x1000_0000
+    assert lib.i2lqr_dry_run(1, P(a), nbytes) == 0
+    arrs.append(P(a))
+assert lib.i2lqr_solve(h, B0, arrs[0], arrs[1], arrs[2], arrs[3], None, arrs[4], None, None, None, None,
+                       STREAM) == 0, lib.i2lqr_last_error()
+bad, text = report()
+assert bad > 0 and "VIOLATION" in text and "LaneArgs" in text, (bad, text[:400])
+assert lib.i2lqr_destroy(h) == 0
+print(f"self-check: a workspace declared at half its size is reported ({bad} violations, e.g. "
+      f"{text.splitlines()[0][:110]})")
+
+stats = {"configs": 0, "calls": 0, "ok": 0, "refused": 0, "launches": 0}
+for it in range(args.configs):
+    system = rng.choice(["bicycle4", "bicycle6", "quad12"], p=[0.35, 0.45, 0.2])
+    N = int(rng.choice([2, 3, 6, 10, 20, 31, 50, 64]))
+    dtype = rng.choice(["f64", "f32"])
+    layout = int(rng.choice([0, 1, 2]))
+    cfg = _abi.default_config(system, N, dtype, dt=0.25, layout=layout)
+    if rng.random() < 0.2:
+        cfg.set_matrix("R", np.eye(cfg.m) * 0.1)
+    if rng.random() < 0.1:
+        cfg.set_matrix("Q", np.eye(cfg.n) * 0.05)
+    cfg.max_iter = int(rng.choice([1, 4, 8, 17, 150]))
+    B = int(rng.choice([1, 3, 64, 200, 1024, 4096, 5000, 8192, 12288, 16384, 20000, 32768, 65536, 200000]))
+    if layout == 2:
+        B = max(64, B // 64 * 64)
+    assert lib.i2lqr_dry_run(2, None, 0) == 0  # reset ranges and records
+    h = P()
+    rc = lib.i2lqr_create(C.byref(cfg), C.byref(h))
+    stats["configs"] += 1
+    if rc != 0:
+        stats["refused"] += 1
+        continue
+    for name in rng.choice(list(OPTIONS), size=int(rng.integers(0, 5)), replace=False):
+        lib.i2lqr_set_option(h, name.encode(), int(rng.choice(OPTIONS[name])))
+    if rng.random() < 0.2:
+        lib.i2lqr_set_compaction(h, int(rng.choice([0, 64, 4096])))
+    item = 8 if dtype == "f64" else 4
+    n, m = cfg.n, cfg.m
+    arena = Arena()
+    X, U = arena.take(B * n * (N + 1) * item), arena.take(B * m * N * item)
+    xt, lamb, obs = arena.take(B * n * item), arena.take(B * item), arena.take(B * 6 * item)
+    cost, K, k = arena.take(B * item), arena.take(B * m * n * N * item), arena.take(B * m * N * item)
+    iters, status = arena.take(B * 4), arena.take(B * 4)
+    X2, U2, c2 = arena.take(B * n * (N + 1) * item), arena.take(B * m * N * item), arena.take(B * item)
+    qfun, cost_it = arena.take(B * 4), arena.take(B * item)
+    best_idx, best_cost = arena.take(8), arena.take(item)
+    pick_bytes = int(lib.i2lqr_argmin_workspace_bytes(B))
+    pick_ws = arena.take(pick_bytes)
+    want_gains = rng.random() < 0.5
+    Kp, kp = (K, k) if want_gains else (P(None), P(None))
+    obs_p = obs if rng.random() < 0.8 else P(None)
+    if rng.random() < 0.9:  # the workspace the handle asks for (sometimes none: calls must refuse)
+        wsb = int(lib.i2lqr_workspace_bytes(h, B))
+        if wsb > 0:
+            ws = arena.take(wsb)
+            assert lib.i2lqr_set_workspace(h, ws, wsb) == 0
+    calls = [
+        lambda: lib.i2lqr_rollout(h, B, X, U, xt, cost, STREAM),
+        lambda: lib.i2lqr_backward(h, B, X, U, xt, lamb, obs_p, K, k, STREAM),
+        lambda: lib.i2lqr_forward(h, B, X, U, xt, K, k, X2, U2, c2, STREAM),
+        lambda: lib.i2lqr_iterate(h, B, int(rng.integers(0, 12)), X, U, xt, lamb, obs_p, cost, Kp, kp,
+                                  iters, status, STREAM),
+        lambda: lib.i2lqr_solve(h, B, X, U, xt, lamb, obs_p, cost, Kp, kp, iters, status, STREAM),
+        lambda: lib.i2lqr_iterate_pick(h, B, int(rng.integers(0, 12)), X, U, xt, lamb, obs_p, cost, Kp,
+                                       kp, iters, status, qfun, 0, 55, cost_it, best_idx, best_cost,
+                                       pick_ws, pick_bytes, STREAM),
+        lambda: lib.i2lqr_relax_cost(h, B, X, xt, qfun, 0, 55, cost_it, STREAM),
+        lambda: lib.i2lqr_argmin(h, B, cost_it, best_idx, best_cost, pick_ws, pick_bytes, STREAM),
+        lambda: lib.i2lqr_pack_problem(h, B, X, U, best_idx, arena.take((m * N + n * (N + 1)) * item), STREAM),
+    ]
+
+    def sharded():
+        world = int(rng.choice([1, 2, 3, 8]))
+        rank = int(rng.integers(0, world))
+        base = int(rng.integers(0, 3))
+        total = B * world + (int(rng.integers(0, world)) if base == 0 else 0)
+        lo = rank * (total // world) + min(rank, total % world)
+        mine = total // world + (1 if rank < total % world else 0)
+        if mine != B:  # keep this rank's shard at B: choose a total that gives it exactly B
+            total = B * world
+        width = (total + world - 1) // world
+        PK = m * N + n * (N + 1)
+        r = _abi.I2lqrRound()
+        r.struct_size = C.sizeof(r)
+        r.n_iters = int(rng.choice([-1, 0, 3, 10]))
+        r.B, r.total, r.world, r.rank = B, total, world, rank
+        r.outer_iter, r.max_relax_iter, r.guard_previous = 0, 55, int(rng.integers(0, 2))
+        r.loopback = 1 if world > 1 else int(rng.integers(0, 2))
+        r.X, r.U, r.x_term, r.lamb, r.obs, r.cost = X.value, U.value, xt.value, lamb.value, obs_p.value, cost.value
+        r.K, r.k, r.iters, r.status, r.qfun = Kp.value, kp.value, iters.value, status.value, qfun.value
+        r.cost_it, r.local_best, r.local_best_cost = cost_it.value, best_idx.value, best_cost.value
+        r.pick_ws, r.pick_ws_bytes = pick_ws.value, pick_bytes
+        r.pack_local = arena.take(PK * item).value
+        r.cost_padded = arena.take(width * item).value
+        r.cost_all = arena.take(world * width * item).value
+        r.pack_all = arena.take(world * PK * item).value
+        sb = int(lib.i2lqr_argmin_workspace_bytes(world * width)) + 16
+        r.side_ws, r.side_ws_bytes = arena.take(sb).value, sb
+        r.best_cost, r.winner, r.best_global = arena.take(item).value, arena.take(PK * item).value, arena.take(16).value
+        return lib.i2lqr_sharded_round_flat(h, None, C.byref(r), SIDE if rng.random() < 0.5 else P(None), STREAM)
+
+    calls.append(sharded)
+    for ci in rng.choice(len(calls), size=4, replace=False):
+        rc = calls[ci]()
+        stats["calls"] += 1
+        stats["ok" if rc == 0 else "refused"] += 1
+        bad, text = report()
+        if bad:
+            print(f"VIOLATION in configuration {it}: {system} N={N} {dtype} layout={layout} B={B} "
+                  f"call {ci} rc={rc}\n{text}")
+            sys.exit(1)
+        stats["launches"] += text.count("\n")
+        if args.verbose:
+            print(it, system, N, dtype, layout, B, "call", ci, "rc", rc, lib.i2lqr_last_error().decode()[:80])
+    assert lib.i2lqr_iterate_kernel(h, B) is not None and lib.i2lqr_solve_kernel(h, B) is not None
+    assert lib.i2lqr_destroy(h) == 0
+print(f"dry-run fuzz: {stats['configs']} configurations, {stats['calls']} calls ({stats['ok']} enqueued, "
+      f"{stats['refused']} refused with an error code), {stats['launches']} recorded launches, "
+      "0 pointer-range violations")
