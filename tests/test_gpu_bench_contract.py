@@ -54,7 +54,7 @@ def test_bench_json_line_contract():
 
 
 CLAIMS = ("large_batch_B65536_f64_frac", "large_batch_B131072_f64_frac", "f32_B65536_frac",
-          "quad12_frac", "quad12_Mits", "sharded_step_ms", "unsharded_step_ms",
+          "quad12_frac", "quad12_Mits", "quad12_f32_frac", "sharded_step_ms", "unsharded_step_ms",
           "sharded_host_enqueue_ms", "sharded_over_unsharded", "sharded_over_unsharded_B131072",
           "control_step_ms", "control_step_ms_device_rounds", "solve_B65536_ms", "solve_B1024_ms",
           "solve_frac_of_fixed_count_rate", "mid_4096_Mits", "mid_8192_Mits", "mid_12288_Mits",

@@ -10,7 +10,7 @@
 #   bash tools/collect_profiles.sh [round tag, default r04]
 set -u
 ROOT=$(pwd)
-TAG=${1:-r04}
+TAG=${1:-r06}
 NEW=$ROOT/gpurun_out/profiles_new
 RAW=$ROOT/gpurun_out/prof_raw
 rm -rf "$NEW" "$RAW"; mkdir -p "$NEW" "$RAW"
@@ -28,6 +28,7 @@ config2_f32_B65536   config2 f32 65536   tiled 10 24
 config2_f64_B1048576 config2 f64 1048576 tiled 10 12
 config2_f32_B1048576 config2 f32 1048576 tiled 10 12
 config5_f64_B65536   config5 f64 65536   tiled 4  16
+config5_f32_B65536   config5 f32 65536   tiled 4  16
 "
 SQ_CYC="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES"
 SQ_INS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH"
@@ -66,7 +67,14 @@ done
 cd "$ROOT"
 python3 tools/summarise_profiles.py "$RAW" "$NEW" "$TAG" > "$NEW/summarise.log" 2>&1
 cp "$NEW/pmc_traffic.json" "$ROOT/profiles/pmc_traffic.json"   # bench.py reads it from profiles/
-python3 bench.py 2> "$NEW/bench.err" | tail -1 > "$NEW/${TAG}_bench.json"
+python3 bench.py 2> "$NEW/bench.err" | grep '^{"metric"' | tail -1 > "$NEW/${TAG}_bench.json"
+python3 tools/extract_bench_profiles.py "$NEW/${TAG}_bench.json" "$TAG" "$NEW"
+# one solve of 65536 problems as a timeline of dispatches (tools/solve_timeline.py)
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d "$RAW/solve_trace" -- python3 $ROOT/tools/pmc_target.py \
+  --workload config2 --dtype f64 --batch 65536 --layout tiled --launches 5 --solve --sync-each > /dev/null 2>&1
+cd "$ROOT"
+python3 tools/solve_timeline.py "$RAW/solve_trace" --json "$NEW/${TAG}_solve_timeline.json" > "$NEW/${TAG}_solve_timeline.txt" 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/bench_kstats" -- \
   python3 "$ROOT/bench.py" --no-cpu-baseline --no-extra > "$RAW/bench_kstats.log" 2>&1
