@@ -834,7 +834,7 @@ def run_solve(args, cfg, B, torch, reps=3, single_launch=False, want_gains=False
     executed = float(it.sum())
     kernel = solver.solve_kernel(B)
     if kernel.startswith("k_lane_iterate") and not single_launch:
-        kernel += " chunks + k_lane_compact + k_group_spec tail"
+        kernel += " chunks (compaction folded into their exit) + k_group_spec tail"
     solver.close()
     return {"executed_iterations_per_s": executed / (ms * 1e-3), "ms_per_solve": ms,
             "iterations_mean": executed / B, "iterations_max": int(it.max()), "kernel": kernel,

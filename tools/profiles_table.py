@@ -8,10 +8,11 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 d = json.loads(Path(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "pmc_traffic.json").read_text())
-ALG = {("config2", "f64"): 4968, ("config2", "f32"): 2484, ("config5", "f64"): 33912}
+ALG = {("config2", "f64"): 4968, ("config2", "f32"): 2484, ("config5", "f64"): 33912,
+       ("config5", "f32"): 16956}
 print("library", d["_meta"]["lib_sha256"][:16])
-print("| workload | kernel | kernel-trace avg (calls) | M it/s | frac of 8 TB/s (algorithmic) | PMC bytes ÷ algorithmic |")
-print("|---|---|---|---|---|---|")
+print("| workload | kernel | kernel-trace avg (calls) | M it/s | frac of 8 TB/s (algorithmic) | PMC bytes ÷ algorithmic | SQ: issuing / parked / stalled |")
+print("|---|---|---|---|---|---|---|")
 rows = []
 for key, r in d.items():
     if key.startswith(("_", "solve")):
@@ -20,10 +21,13 @@ for key, r in d.items():
     B, it = int(B[1:]), int(it[2:])
     t = r["kernel_avg_ms_kernel_trace"] * 1e-3
     alg = ALG[(wl, dt)]
+    sq = r.get("sq_shares_of_wave_cycles") or {}
     rows.append((wl, dt != "f64", B, f"| {wl} {dt} B={B} | `{r['kernel']}` | "
                  f"{r['kernel_avg_ms_kernel_trace'] * 1e3:.1f} µs ({r['kernel_calls_kernel_trace']}) | "
                  f"{B * it / t / 1e6:.0f} | {alg * B * it / t / 8e12:.3f} | "
-                 f"{r.get('hbm_bytes_per_problem_iteration', 0) / alg:.2f} |"))
+                 f"{r.get('hbm_bytes_per_problem_iteration', 0) / alg:.2f} | "
+                 f"{sq.get('issuing_any_instruction', 0):.2f} / {sq.get('parked_on_waitcnt_or_barrier', 0):.2f} / "
+                 f"{sq.get('issue_stalled', 0):.2f} |"))
 for row in sorted(rows):
     print(row[3])
 for key in ("solve:f64:B1024", "solve:f64:B65536"):
