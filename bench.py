@@ -340,7 +340,10 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                     exchange.close()
                 exchange = "torch"
                 native_error = native_error or "another rank could not create the communicator"
-    comm_stream = torch.cuda.Stream() if exchange is not None else None
+    # the exchange stream is PROBED (dist.exchange_stream): two HIP streams may share a hardware
+    # queue — every fourth stream a process creates lands on the launch stream's — and the exchange
+    # then runs BEHIND the next solve instead of beside it (+10 % at 8192 problems per rank)
+    comm_stream = dist_mod.exchange_stream(solver.device) if exchange is not None else None
     # The multi-rank step IS the product's sharded round (HipCandidateSolver.sharded_round — what
     # control.iLqr(sharded=...) calls): shard solve + relaxed costs + local pick (one launch on the
     # fused kernels), the local winner's pack, ONE grouped all-gather of costs and packs, the pick
@@ -647,7 +650,7 @@ class quiet_stdout:
         return False
 
 
-def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4):
+def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4, options=None):
     """Per-rank cost of the SHARDED step beside the unsharded one, in ONE process on ONE GPU
     (the only evidence for the >= 6x-at-8-GPUs target obtainable without the node —
     weak scaling needs the sharded pipeline to sustain the unsharded step's rate per rank).  A world
@@ -667,6 +670,8 @@ def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4):
     layout = pick_layout(args, B, cfg=cfg)
     cfg.layout = LAYOUT_ID[layout]
     solver = BatchedILQR(cfg, torch.device("cuda", torch.cuda.current_device()))
+    for key, val in (options or {}).items():  # (tools/sharded_overhead.py: A/B of a scheduling option)
+        solver.set_option(key, int(val))
     host = workloads.make_batch(cfg, B)
     sets = make_step_buffers(solver, host, steps, torch, want_gains=False)
     pristine = {k: sets[0][k].clone() for k in ("X", "U", "lamb")}
@@ -684,7 +689,7 @@ def measure_sharded_overhead(args, cfg, B, torch, dist_mod, steps=50, reps=4):
     plans = [solver.plan_round(sets[i], qfun, cost_its[i], B, 1, 0, args.iters, bufs=xbufs[i],
                                guard_previous=False) for i in range(steps)]
     rounds = HipCandidateSolver(solver.device)
-    side = torch.cuda.Stream()
+    side = dist_mod.exchange_stream(solver.device)  # (probed: not on the launch stream's hardware queue)
 
     def unsharded(i):
         solver.iterate_pick(sets[i], args.iters, qfun, 0, 55, cost_its[i], best=bests[i])

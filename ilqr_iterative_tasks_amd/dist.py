@@ -442,6 +442,49 @@ def native_comm(exchange):
     return None, False
 
 
+def exchange_stream(device=None, tries: int = 8):
+    """A stream for the exchange of a sharded round whose work really runs BESIDE the current
+    stream's (HipCandidateSolver.sharded_round(exchange_stream=...), i2lqr_sharded_round_flat's
+    side_stream).  Two HIP streams may share a hardware queue — on MI355X every fourth stream a
+    process creates lands on the launch stream's — and work on a shared queue runs BEHIND the launch
+    stream's kernels, not beside them: the exchange of round i then waits for the solve of round
+    i + 1 (measured: +10 % per step at 8192 problems per rank, +60 % with a high-priority stream
+    at 1024; profiles/r06_sharded_overhead_sweep.json).  So the candidates are PROBED: a spin kernel
+    of ~0.3 ms on the current stream, a tiny kernel on the candidate enqueued behind it — the first
+    candidate whose kernel finishes while the spin is still running is returned (the first
+    candidate if none does)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        probe = torch.zeros(64, device=dev)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        # what a spin of 200000 ticks lasts here (the tick of torch.cuda._sleep is the device's)
+        a, b = ev(), ev()
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize(dev)
+        a.record(main)
+        torch.cuda._sleep(200_000)
+        b.record(main)
+        torch.cuda.synchronize(dev)
+        ticks = int(200_000 * 0.3 / max(a.elapsed_time(b), 1e-3))  # ~0.3 ms
+        first = None
+        for _ in range(max(1, tries)):
+            s = torch.cuda.Stream(dev)
+            first = first or s
+            e0, e1, es = ev(), ev(), ev()
+            torch.cuda.synchronize(dev)
+            e0.record(main)
+            torch.cuda._sleep(ticks)
+            e1.record(main)
+            with torch.cuda.stream(s):
+                probe.add_(1.0)
+                es.record(s)
+            torch.cuda.synchronize(dev)
+            if e0.elapsed_time(es) < 0.5 * e0.elapsed_time(e1):
+                return s
+        return first
+
+
 def padded_width(total: int, world: int) -> int:
     """Largest shard of shard_range(total, ., world): what every rank pads its costs to."""
     return (total + world - 1) // world

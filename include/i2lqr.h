@@ -544,7 +544,11 @@ int i2lqr_round_winner(i2lqr_handle* h, int32_t world, int64_t width, int64_t to
  *
  * With side_stream != stream the launch stream carries the shard's solve only — the same single
  * launch per round as the unsharded i2lqr_iterate_pick — and the exchange of round i runs beside
- * the solve of round i + 1.  side_stream NULL (or == stream): everything on `stream`.
+ * the solve of round i + 1 — provided the two streams do not share a HARDWARE queue (two HIP
+ * streams may: the exchange then runs behind the next solve, +10 % per step measured; probe the
+ * candidate with a spin kernel as the Python host's dist.exchange_stream() does, and do not make
+ * it a high-priority stream: +60 % at 1024 problems).  side_stream NULL (or == stream): everything
+ * on `stream`.
  * comm NULL is a world of one without RCCL (the gathers become device copies), or any world with
  * round->loopback set (see there).
  * A rank with B == 0 (more ranks than candidates) takes part in the exchange with `width` costs of

@@ -234,3 +234,40 @@ def test_a_device_with_a_quarter_of_the_cus_still_passes_parity():
     for c in d["cases"]:
         assert c["same_branch"] > 0.97, c
         assert c["X_err"] < 1e-8 and c["U_err"] < 1e-7 and c["cost_err"] < 1e-7, c
+
+
+def test_exchange_stream_runs_beside_the_launch_stream(torch_mod):
+    """dist.exchange_stream(): two HIP streams may share a hardware queue (every fourth stream a
+    process creates lands on the launch stream's), and an exchange on a shared queue runs BEHIND
+    the next solve instead of beside it.  The probed stream's kernels finish while a spin kernel on
+    the current stream is still running — for several streams in a row, so at least one unlucky
+    candidate has been skipped on the way."""
+    torch = torch_mod
+    from ilqr_iterative_tasks_amd import dist as idist
+    main = torch.cuda.current_stream()
+    x = torch.zeros(64, device="cuda")
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    a, b = ev(), ev()
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    a.record()
+    torch.cuda._sleep(200_000)
+    b.record()
+    torch.cuda.synchronize()
+    ticks = int(200_000 * 0.5 / a.elapsed_time(b))  # a spin of ~0.5 ms
+    seen = set()
+    for _ in range(6):
+        s = idist.exchange_stream()
+        assert s != main
+        seen.add(s.cuda_stream)
+        e0, e1, es = ev(), ev(), ev()
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(ticks)
+        e1.record()
+        with torch.cuda.stream(s):
+            x.add_(1.0)
+            es.record(s)
+        torch.cuda.synchronize()
+        assert e0.elapsed_time(es) < 0.5 * e0.elapsed_time(e1), (e0.elapsed_time(es), e0.elapsed_time(e1))
+    assert len(seen) >= 2
