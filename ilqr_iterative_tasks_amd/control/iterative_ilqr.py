@@ -148,6 +148,10 @@ class HipCandidateSolver:
             raise ValueError("a sharded round needs at least one candidate over all ranks")
         on_phase = on_phase or (lambda name: None)
         empty_shard = plan is None and prepared is None and int(x_terms_local.shape[0]) == 0
+        if plan is None and prepared is None and exchange_stream is not None:
+            # this round's inputs are written into buffers cached per batch size: not before the
+            # previous round's exchange (which packs its winner out of them) has passed them
+            torch.cuda.current_stream(self.device).wait_stream(exchange_stream)
         if plan is not None:
             solver, buf, cost_it = plan["solver"], plan["keep"][0], plan["cost_local"]
             qfun = plan["keep"][1]

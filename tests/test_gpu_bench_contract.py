@@ -218,3 +218,31 @@ def test_graft_entry_smoke():
                          capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "smoke ok" in out.stdout
+
+
+@pytest.mark.parametrize("handoff", ["gather", "broadcast"])
+def test_two_gpus_native_rccl_round_hands_over_the_owners_trajectory(handoff):
+    """the grouped all-gather of costs and packs (and the two-collective form beside it)
+    over the library's own RCCL communicator with a world ABOVE one — gated on a second GPU (the
+    test boxes of this repository have one: skipped there; the driver's multi-GPU node runs it).
+    bench.py itself asserts, on every rank, that the pick is the first-index arg-min of the
+    gathered costs and, on the owner, that the handed-over pack is the trajectory it solved."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "5",
+                          "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--handoff", handoff],
+                         capture_output=True, text=True, timeout=1200, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048
+    assert d["exchange"]["path"] == "native" and d["exchange"]["nccl_world"] == 2
+    assert d["launcher"]["fallback"] is None
+    if handoff == "gather":
+        assert d["exchange"]["one_call_round"] is True
+        assert d["exchange"]["broadcast_variant"]["ms_per_step"] > 0
+    else:
+        assert "ncclBroadcast" in d["exchange"]["handoff"]
+    assert len(d["per_rank_iterations_per_s"]) == 2 and d["value"] > 1e6
