@@ -200,8 +200,12 @@ def test_schedule_options_of_the_chunked_solve_change_no_bit(torch_mod):
     assert int((plain["iters"] > 14).sum()) > 1000
     solver.set_compaction(4096)
     solver.set_option("wave_tail", 0)
-    for opts in ({}, {"first_chunk": 12}, {"first_chunk": 5, "chunk_step": 2}, {"chunk_step": 7}):
-        for key in ("first_chunk", "chunk_step"):
+    # (round 6: the compaction folded into the chunks' exit or as launches of its own, and the
+    # round that ends the schedule, are schedule choices like the others)
+    for opts in ({}, {"first_chunk": 12}, {"first_chunk": 5, "chunk_step": 2}, {"chunk_step": 7},
+                 {"fused_compaction": 0}, {"fused_compaction": 0, "chunk_step": 2},
+                 {"final_round": 0}, {"final_round": 2, "first_chunk": 6}):
+        for key in ("first_chunk", "chunk_step", "fused_compaction", "final_round"):
             solver.set_option(key, opts.get(key, -1))
         got = solver.solve(dev_batch(solver, host, want_gains=False))
         for key in ("X", "U", "lamb", "cost", "iters", "status"):
