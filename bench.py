@@ -465,7 +465,10 @@ def run_gpu(args, cfg, B, rank, world, torch, dist_mod, steps, warmup, with_tail
                # launches of ONE step: the fused round is one launch only on a single GPU; a sharded
                # step adds the winner's pack, the grouped all-gather, the pick on the gathered
                # vector and i2lqr_round_winner
-               launches_per_step=((1 if fused else 3) + (3 if exchange is not None else 0))
+               # (... the one-call round: local winner's pack, grouped gather, pick + hand-off; driven
+               # from Python: pack, gather, arg-min, round winner)
+               launches_per_step=((1 if fused else 3) +
+                                  ((3 if one_call else 4) if exchange is not None else 0))
                if with_tail else 1,
                # share of the fixed-count iterations that were accepted steps (a rejected step of
                # the one-problem-per-lane kernels stores no states: "defer_states")
