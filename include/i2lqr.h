@@ -348,7 +348,7 @@ int i2lqr_set_option(i2lqr_handle* h, const char* name, int64_t value);
  * Host only; "" for a NULL handle. */
 const char* i2lqr_iterate_kernel(const i2lqr_handle* h, int64_t B);
 /* The same for i2lqr_solve / early-exit calls (the dominant kernel; the chunked solves of the lane
- * layouts also launch k_lane_compact and a tail kernel). */
+ * layouts also launch a tail kernel, and k_lane_compact with "fused_compaction" 0). */
 const char* i2lqr_solve_kernel(const i2lqr_handle* h, int64_t B);
 
 /*
