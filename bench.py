@@ -790,8 +790,10 @@ def closed_loop_config1(torch):
                     "control_step_ms_median": float(np.median(t) * 1e3),
                     "control_step_ms_p95": float(np.percentile(t, 95) * 1e3),
                     "control_step_ms_max": float(t.max() * 1e3)}
-    out["modes"] = {"chained": "lamb chained across candidates (the reference's exact semantics): 48 "
-                               "dependent solves per control step",
+    out["modes"] = {"chained": "lamb chained across the candidates of a lap (the reference's exact "
+                               "semantics): 8 dependent chain steps per round over the two laps, the "
+                               "chain carried on the device (HipCandidateSolver.solve_chained: one "
+                               "upload, 8 launches replayed as a hipGraph, one read-back per round)",
                     "independent": "independent lamb per candidate, one batched solve per round, host "
                                    "rounds",
                     "device_rounds": "independent lamb, the three rounds chained on the GPU and "

@@ -166,6 +166,15 @@ class iLqr(ControlBase):
                 for c in range(len(idx)):
                     U[a][c], X[a][c] = out["U"][pos], out["X"][pos]
                     pos += 1
+        elif hasattr(solver, "solve_chained") and N > 1:
+            # the chain on the device (round 6): every candidate of the round goes up at once, step c
+            # of every lap's chain is one launch whose lamb comes from step c - 1 on the device;
+            # one read-back per round instead of one per step
+            res = solver.solve_chained(cfg, x0, [np.stack([self.ss[lap][:, j] for j in idx], axis=0)
+                                                 for lap, idx in candidates], float(p.lamb), obs)
+            for a, (_, idx) in enumerate(candidates):
+                for c in range(len(idx)):
+                    U[a][c], X[a][c] = res[a]["U"][c], res[a]["X"][c]
         else:
             lamb = np.full(n_laps, float(p.lamb))  # reset per lap: utils/base.py:393
             for c in range(width):

@@ -318,6 +318,126 @@ class HipCandidateSolver:
         return dict(U=f(U), X=f(X), lamb=f(h["lamb"]), cost=f(h["cost"]),
                     iters=np.array(pk["hi"]["iters"]), status=np.array(pk["hi"]["status"]))
 
+    def solve_chained(self, cfg, x0, x_terms_by_chain, lamb0, obs_rec):
+        """The reference's chained regularisation on the DEVICE (round 6): inside one lap's
+        candidate list the final lamb of candidate c seeds candidate c + 1 (utils/base.py:393,
+        :414-426 — `lamb` is reset per lap and carried through the `for j` loop), the laps are
+        independent.  x_terms_by_chain: one array [k_a, n] per lap (their lengths may differ).
+        All candidates go up in ONE host-to-device copy; step c of every chain is one launch
+        (i2lqr_solve over the chains that still have a candidate c), its lamb input gathered on the
+        device from step c - 1's output; ONE copy back and ONE synchronisation per round — against
+        a host round trip per step (the controller's loop before: 24 per control step on BASELINE
+        configs[0]).  Same kernels on the same inputs: bit-identical to the step-by-step form.
+        Returns one dict(U, X, lamb, cost, iters, status) per chain (host arrays, leading axis k_a)."""
+        import torch
+        chains = [np.atleast_2d(np.asarray(xt, float)) for xt in x_terms_by_chain]
+        widths = [len(c) for c in chains]
+        width = max(widths)
+        rows = [[a for a, w in enumerate(widths) if c < w] for c in range(width)]
+        counts = [len(r) for r in rows]
+        B = sum(counts)
+        solver = self._solver(cfg, max(counts), early_exit=True)
+        if solver.batch_minor or solver.batch_tiled or B > 4096:
+            raise ValueError("solve_chained is the controller's path: problem-major batches")
+        n, m, N = cfg.n, cfg.m, cfg.N
+        has_obs = obs_rec is not None
+        key = ("chain", id(solver), tuple(widths), has_obs)
+        if not hasattr(self, "_packs"):
+            self._packs = {}
+        pk = self._packs.get(key)
+        if pk is None:
+            if len(self._packs) > 16:
+                self._packs.clear()
+            item = 8 if solver.dtype == torch.float64 else 4
+            sizes = [("X", B * n * (N + 1)), ("U", B * m * N), ("x_term", B * n), ("lamb", B),
+                     ("obs", B * 6), ("cost", B)]
+            off, o = {}, 0
+            for name, cnt in sizes:
+                off[name] = (o, cnt)
+                o += (cnt * item + 15) // 16 * 16
+            ioff = o
+            istep = (B * 4 + 15) // 16 * 16
+            o += 2 * istep
+            host = torch.empty(o, dtype=torch.uint8).pin_memory()
+            dev = torch.empty(o, dtype=torch.uint8, device=solver.device)
+            hv = {k: host[a:a + c * item].view(solver.dtype).numpy() for k, (a, c) in off.items()}
+            dv = {k: dev[a:a + c * item].view(solver.dtype) for k, (a, c) in off.items()}
+            hi = {"iters": host[ioff:ioff + B * 4].view(torch.int32).numpy(),
+                  "status": host[ioff + istep:ioff + istep + B * 4].view(torch.int32).numpy()}
+            di = {"iters": dev[ioff:ioff + B * 4].view(torch.int32),
+                  "status": dev[ioff + istep:ioff + istep + B * 4].view(torch.int32)}
+            # one buffer dict per step: contiguous views of the step's problems (step-major order)
+            starts = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+            steps = []
+            for c in range(width):
+                lo, hi_ = int(starts[c]), int(starts[c + 1])
+                steps.append(dict(
+                    X=dv["X"].view(B, n, N + 1)[lo:hi_], U=dv["U"].view(B, m, N)[lo:hi_],
+                    x_term=dv["x_term"].view(B, n)[lo:hi_], lamb=dv["lamb"][lo:hi_],
+                    cost=dv["cost"][lo:hi_], obs=dv["obs"].view(B, 6)[lo:hi_] if has_obs else None,
+                    iters=di["iters"][lo:hi_], status=di["status"][lo:hi_], K=None, k=None))
+            # where step c's chains sat in step c - 1 (chains only ever drop out: ordered subsets)
+            gather = [None]
+            for c in range(1, width):
+                pos = [rows[c - 1].index(a) for a in rows[c]]
+                gather.append(None if pos == list(range(len(rows[c - 1]))) else
+                              torch.tensor(pos, dtype=torch.int64, device=solver.device))
+            pk = self._packs[key] = dict(host=host, dev=dev, h=hv, hi=hi, steps=steps,
+                                         gather=gather, in_bytes=off["cost"][0], starts=starts)
+        h = pk["h"]
+        X = h["X"].reshape(B, n, N + 1)
+        X[:] = 0
+        X[:, :, 0] = np.asarray(x0, float)
+        h["U"][:] = 0
+        xt = h["x_term"].reshape(B, n)
+        starts = pk["starts"]
+        for c in range(width):
+            for r, a in enumerate(rows[c]):
+                xt[starts[c] + r] = chains[a][c]
+        h["lamb"][:] = float(lamb0)  # (steps behind the first get theirs on the device)
+        if has_obs:
+            h["obs"].reshape(B, 6)[:] = np.asarray(obs_rec, float)
+        nb = pk["in_bytes"]
+
+        def launches():  # the device side of the round: a launch per chain step, lamb carried over
+            for c, buf in enumerate(pk["steps"]):
+                if c > 0:
+                    prev = pk["steps"][c - 1]["lamb"]
+                    if pk["gather"][c] is None:
+                        buf["lamb"].copy_(prev)
+                    else:
+                        torch.index_select(prev, 0, pk["gather"][c], out=buf["lamb"])
+                solver.solve(buf)
+
+        pk["dev"][:nb].copy_(pk["host"][:nb], non_blocking=True)
+        if pk.get("graph") is not None:
+            pk["graph"].replay()  # (the same launches, captured once: ~2 instead of ~10 us per node)
+        else:
+            launches()
+        pk["host"].copy_(pk["dev"], non_blocking=True)
+        torch.cuda.current_stream(solver.device).synchronize()
+        if "graph" not in pk:  # first round on this buffer set: capture its launches for the next
+            pk["graph"], pk["graph_error"] = None, None
+            if getattr(self, "use_graph", True):
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        launches()
+                    pk["graph"] = g
+                except RuntimeError as e:  # refused: the rounds stay eager, and say so
+                    pk["graph_error"] = f"{type(e).__name__}: {e}"
+                    torch.cuda.synchronize(solver.device)
+            self.chain_info = {"graph": pk["graph"] is not None, "graph_error": pk["graph_error"]}
+        U = h["U"].reshape(B, m, N)
+        out = []
+        for a, w in enumerate(widths):
+            sel = [int(starts[c]) + rows[c].index(a) for c in range(w)]
+            f = lambda arr: np.array(arr[sel], dtype=np.float64)
+            out.append(dict(U=f(U), X=f(X), lamb=f(h["lamb"]), cost=f(h["cost"]),
+                            iters=np.array(pk["hi"]["iters"][sel]),
+                            status=np.array(pk["hi"]["status"][sel])))
+        return out
+
     def _solve_generic(self, solver, cfg, B, x0, x_terms, lamb0, obs_rec, U0):
         import torch
         buf = solver.alloc(B, want_gains=False)

@@ -271,3 +271,31 @@ def test_exchange_stream_runs_beside_the_launch_stream(torch_mod):
         torch.cuda.synchronize()
         assert e0.elapsed_time(es) < 0.5 * e0.elapsed_time(e1), (e0.elapsed_time(es), e0.elapsed_time(e1))
     assert len(seen) >= 2
+
+
+def test_chain_on_the_device_equals_the_step_by_step_chain(torch_mod):
+    """HipCandidateSolver.solve_chained (round 6): the reference's chained lamb — candidate c + 1 of
+    a lap starts from candidate c's final lamb, utils/base.py:393, :414-426 — with the whole round
+    on the device: one upload, one launch per chain step whose lamb is gathered on the device from
+    the step before, one read-back.  Bit-identical to the step-by-step form (a host round trip per
+    step), for laps of equal and of different lengths, with and without the obstacle."""
+    from ilqr_iterative_tasks_amd import default_config
+    from ilqr_iterative_tasks_amd.control.iterative_ilqr import HipCandidateSolver
+    cfg = default_config("bicycle4", 6)
+    rng = np.random.default_rng(5)
+    x0 = np.array([0.0, 0.0, 1.0, 0.0])
+    hs = HipCandidateSolver()
+    for widths, obs in (((8, 8), (31.0, -3.0, 8.0, 6.0, 0.0, 0.0)), ((8, 5, 3), None), ((1,), None),
+                        ((4, 8), (12.0, 1.0, 6.0, 4.0, 0.0, 0.0))):
+        chains = [np.column_stack([rng.uniform(5, 40, w), rng.uniform(-4, 4, w),
+                                   rng.uniform(0.5, 3, w), rng.uniform(-0.3, 0.3, w)]) for w in widths]
+        got = hs.solve_chained(cfg, x0, chains, 1.0, obs)
+        lamb = np.full(len(widths), 1.0)
+        for c in range(max(widths)):
+            rows = [a for a, w in enumerate(widths) if c < w]
+            ref = hs.solve(cfg, x0, np.stack([chains[a][c] for a in rows]), lamb[rows], obs)
+            for r, a in enumerate(rows):
+                for key in ("U", "X", "lamb", "cost", "iters", "status"):
+                    assert np.array_equal(got[a][key][c], ref[key][r]), (widths, a, c, key)
+                lamb[a] = ref["lamb"][r]
+        assert all(len(g["lamb"]) == w for g, w in zip(got, widths))
