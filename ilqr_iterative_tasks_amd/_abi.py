@@ -191,6 +191,8 @@ EXPORTS = {
     "i2lqr_iterate": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P]),
     "i2lqr_solve": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "i2lqr_solve_chained": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _P, _P]),
     "i2lqr_relax_cost": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "i2lqr_argmin_workspace_bytes": (C.c_int64, [C.c_int64]),
     "i2lqr_argmin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_int64, _P]),

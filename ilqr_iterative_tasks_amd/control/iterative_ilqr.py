@@ -323,11 +323,15 @@ class HipCandidateSolver:
         candidate list the final lamb of candidate c seeds candidate c + 1 (utils/base.py:393,
         :414-426 — `lamb` is reset per lap and carried through the `for j` loop), the laps are
         independent.  x_terms_by_chain: one array [k_a, n] per lap (their lengths may differ).
-        All candidates go up in ONE host-to-device copy; step c of every chain is one launch
-        (i2lqr_solve over the chains that still have a candidate c), its lamb input gathered on the
-        device from step c - 1's output; ONE copy back and ONE synchronisation per round — against
-        a host round trip per step (the controller's loop before: 24 per control step on BASELINE
-        configs[0]).  Same kernels on the same inputs: bit-identical to the step-by-step form.
+        All candidates go up in ONE host-to-device copy and come back in ONE.  Laps of equal
+        length (the rule): ONE launch, i2lqr_solve_chained — a workgroup of the speculative kernel
+        solves its chains' candidates one after the other, lamb carried in a register.  Otherwise
+        (ragged laps; configurations the chain kernel is not built for): step c of every chain is
+        one launch (i2lqr_solve over the chains that still have a candidate c), its lamb input
+        gathered on the device from step c - 1's output, the launches replayed as a hipGraph.
+        Either way ONE synchronisation per round — against a host round trip per step (the
+        controller's loop before: 24 per control step on BASELINE configs[0]).  Same kernel code on
+        the same inputs: bit-identical to the step-by-step form.
         Returns one dict(U, X, lamb, cost, iters, status) per chain (host arrays, leading axis k_a)."""
         import torch
         chains = [np.atleast_2d(np.asarray(xt, float)) for xt in x_terms_by_chain]
@@ -398,6 +402,43 @@ class HipCandidateSolver:
         if has_obs:
             h["obs"].reshape(B, 6)[:] = np.asarray(obs_rec, float)
         nb = pk["in_bytes"]
+        if pk.get("one_launch") is None:
+            pk["one_launch"] = len(set(widths)) == 1 and getattr(self, "use_chain_kernel", True)
+            if pk["one_launch"]:  # the steps' views are consecutive slices of ONE block: the whole of it
+                first = pk["steps"][0]
+                whole = {name: torch.as_strided(first[name], (B,) + tuple(first[name].shape[1:]),
+                                                first[name].stride(), first[name].storage_offset())
+                         for name in ("X", "U", "x_term", "lamb", "cost", "iters", "status")}
+                whole["obs"] = (torch.as_strided(first["obs"], (B, 6), first["obs"].stride(),
+                                                 first["obs"].storage_offset()) if has_obs else None)
+                whole["K"] = whole["k"] = None
+                pk["whole"] = whole
+        if pk["one_launch"]:
+            from ..solver import I2lqrError
+            L, k = len(widths), widths[0]
+            for a in range(L):  # chain-major order: candidate c of lap a at a * k + c
+                xt[a * k:(a + 1) * k] = chains[a]
+            pk["dev"][:nb].copy_(pk["host"][:nb], non_blocking=True)
+            try:
+                solver.solve_chained(pk["whole"], L, k)
+            except I2lqrError:  # not built for this configuration: a launch per chain step below
+                pk["one_launch"] = False
+                for c in range(width):
+                    for r, a in enumerate(rows[c]):
+                        xt[starts[c] + r] = chains[a][c]
+            else:
+                pk["host"].copy_(pk["dev"], non_blocking=True)
+                torch.cuda.current_stream(solver.device).synchronize()
+                U = h["U"].reshape(B, m, N)
+                out = []
+                for a in range(L):
+                    sel = slice(a * k, (a + 1) * k)
+                    f = lambda arr: np.array(arr[sel], dtype=np.float64)
+                    out.append(dict(U=f(U), X=f(X), lamb=f(h["lamb"]), cost=f(h["cost"]),
+                                    iters=np.array(pk["hi"]["iters"][sel]),
+                                    status=np.array(pk["hi"]["status"][sel])))
+                self.chain_info = {"one_launch": True, "graph": False, "graph_error": None}
+                return out
 
         def launches():  # the device side of the round: a launch per chain step, lamb carried over
             for c, buf in enumerate(pk["steps"]):
@@ -427,7 +468,8 @@ class HipCandidateSolver:
                 except RuntimeError as e:  # refused: the rounds stay eager, and say so
                     pk["graph_error"] = f"{type(e).__name__}: {e}"
                     torch.cuda.synchronize(solver.device)
-            self.chain_info = {"graph": pk["graph"] is not None, "graph_error": pk["graph_error"]}
+            self.chain_info = {"one_launch": False, "graph": pk["graph"] is not None,
+                               "graph_error": pk["graph_error"]}
         U = h["U"].reshape(B, m, N)
         out = []
         for a, w in enumerate(widths):

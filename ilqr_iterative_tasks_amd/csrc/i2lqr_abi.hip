@@ -541,6 +541,29 @@ template <class T, class Sys> struct Launch {
     return I2LQR_OK;
   }
   static int names_pair(i2lqr_handle*, int64_t, int) { return 0; }
+  // L chains of k problems each in ONE launch (k_group_spec<.., CHAIN>)
+  static int solve_chained(i2lqr_handle* h, int64_t L, int k, void* X, void* U, const void* x_term,
+                           void* lamb, const void* obs, void* cost, void* K, void* kk, int32_t* iters,
+                           int32_t* status, hipStream_t s) {
+    if constexpr (m == 2 && n + m <= 8) {
+      if (h->opt_spec == 0 || h->opt_group == 8 || h->opt_group == 64 ||
+          !group_spec_chain_supported(h->cfg, L))
+        return fail(I2LQR_ERR_UNSUPPORTED, "chains run on the sixteen-lane speculative kernel: a "
+                    "bicycle plant with Q = R = 0, at most %lld chains, a horizon whose three-wavefront "
+                    "buffers fit a CU's LDS (solve the chain steps one after the other instead)",
+                    (long long)h->geo.scaled(512));
+      IterArgs<T> a;
+      a.B = L; a.n_iters = h->cfg.max_iter; a.early_exit = 1;
+      a.X = (T*)X; a.U = (T*)U; a.x_term = (const T*)x_term; a.lamb = (T*)lamb;
+      a.obs = (const T*)obs; a.cost = (T*)cost; a.K = (T*)K; a.k = (T*)kk;
+      a.iters = iters; a.status = status; a.dbg = nullptr;
+      a.count = nullptr; a.count_max = 0; a.max_total = 0; a.set_stride = 0;
+      a.chain_len = k;
+      HIP_TRY(group_spec_chain<T>(h->cfg, a, s));
+      return I2LQR_OK;
+    }
+    return fail(I2LQR_ERR_UNSUPPORTED, "chains are built for the m = 2 plants");
+  }
   static int rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      hipStream_t s) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
@@ -1080,6 +1103,10 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
   // kernel: the SAME carve + option + use_pair sequence the launchers above run, on scratch
   // arguments (no launch, no device access) — i2lqr_iterate_kernel / i2lqr_solve_kernel (ADVICE r5:
   // a hand-written mirror of these conditions had drifted).
+  static int solve_chained(i2lqr_handle*, int64_t, int, void*, void*, const void*, void*, const void*,
+                           void*, void*, void*, int32_t*, int32_t*, hipStream_t) {
+    return fail(I2LQR_ERR_UNSUPPORTED, "chains are problem-major batches (the controller's path)");
+  }
   static int names_pair(i2lqr_handle* h, int64_t B, int early_exit) {
     const Cfg c = make_dev_cfg<T, n, m>(h->cfg);
     LaneArgs<T> a;
@@ -1213,6 +1240,12 @@ template <class T, class Sys, bool TILED> struct LaneLaunch {
 int prepare_dispatch(i2lqr_handle* h) { I2LQR_DISPATCH(h, prepare(h)); }
 int names_pair_dispatch(i2lqr_handle* h, int64_t B, int early_exit) {
   I2LQR_DISPATCH(h, names_pair(h, B, early_exit));
+}
+int dispatch_solve_chained(i2lqr_handle* h, int64_t L, int k, void* X, void* U, const void* x_term,
+                           void* lamb, const void* obs, void* cost, void* K, void* kk, int32_t* iters,
+                           int32_t* status, void* stream) {
+  I2LQR_DISPATCH(h, solve_chained(h, L, k, X, U, x_term, lamb, obs, cost, K, kk, iters, status,
+                                  (hipStream_t)stream));
 }
 int dispatch_rollout(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term, void* cost,
                      void* stream) {
@@ -1935,6 +1968,21 @@ int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term
     return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
   return debug_check(dispatch_iterate(h, B, h->cfg.max_iter, 1, X, U, x_term, lamb, obs, cost, K, k,
                                       iters, status, stream), stream);
+}
+
+int i2lqr_solve_chained(i2lqr_handle* h, int64_t chains, int32_t chain_len, void* X, void* U,
+                        const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                        int32_t* iters, int32_t* status, void* stream) {
+  if (int rc = check_common(h, chains)) return rc;
+  if (chain_len < 1) return fail(I2LQR_ERR_INVALID, "chain_len must be >= 1");
+  if (chains * (int64_t)chain_len > (int64_t)0x7fffffff)
+    return fail(I2LQR_ERR_INVALID, "%lld chains of %d problems", (long long)chains, chain_len);
+  if (chains == 0) return I2LQR_OK;
+  if (!X || !U || !x_term || !lamb || !cost) return fail(I2LQR_ERR_INVALID, "null buffer");
+  if ((K == nullptr) != (k == nullptr))
+    return fail(I2LQR_ERR_INVALID, "K and k must both be given or both be NULL");
+  return debug_check(dispatch_solve_chained(h, chains, chain_len, X, U, x_term, lamb, obs, cost, K, k,
+                                            iters, status, stream), stream);
 }
 
 int i2lqr_relax_cost(i2lqr_handle* h, int64_t B, const void* X, const void* x_term,

@@ -53,6 +53,14 @@ template <class T> hipError_t group_iterate_ws(const i2lqr_config& cfg, const It
 bool group_spec_supported(const i2lqr_config& cfg, int lanes);
 template <class T> hipError_t group_spec_iterate(const i2lqr_config& cfg, const IterArgs<T>& a,
                                                  hipStream_t stream, int lanes);
+// Chains (k_group_spec<.., CHAIN>): a.B chains of a.chain_len problems each, stored chain after chain,
+// solved in ONE launch — the final lamb of a chain's problem c is the initial lamb of its problem
+// c + 1 (utils/base.py:393, :414-426: the controller's chained regularisation).  Supported for the
+// plants of the speculative kernel with Q = R = 0 in the problem-major layout, up to the batch of
+// its three-wavefront form (512 chains on 256 CUs).
+bool group_spec_chain_supported(const i2lqr_config& cfg, int64_t chains);
+template <class T> hipError_t group_spec_chain(const i2lqr_config& cfg, const IterArgs<T>& a,
+                                               hipStream_t stream);
 // The same kernel on the first *a.count (<= a.count_max) columns of a batch-minor work set: the tail
 // of the chunked solves of the one-problem-per-lane layouts (IterArgs::count / set_stride /
 // max_total).  Supported for the plants of the eight-lane kernel with Q = R = 0, whatever the

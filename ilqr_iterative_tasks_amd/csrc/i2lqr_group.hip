@@ -158,6 +158,39 @@ int group_spec_tail_lanes(const i2lqr_config& cfg) {
 }
 bool group_spec_tail_supported(const i2lqr_config& cfg) { return group_spec_tail_lanes(cfg) != 0; }
 
+// chains (k_group_spec<.., 3, false, 16, true>): the sixteen-lane form with three wavefronts
+template <class T, class Sys>
+hipError_t launch_spec_chain(const i2lqr_config& cfg, const IterArgs<T>& a, hipStream_t s) {
+  const auto c = make_dev_cfg<T, Sys::n, Sys::m>(cfg);
+  const size_t lds = spec_lds_bytes<T, Sys, 3, 16>(cfg.N);
+  if (hipError_t e = raise_lds_limit<k_group_spec<T, Sys, 3, false, 16, true>>(lds); e != hipSuccess)
+    return e;
+  const unsigned grid = (unsigned)((a.B + 3) / 4);
+  hipLaunchKernelGGL((k_group_spec<T, Sys, 3, false, 16, true>), dim3(grid), dim3(64 * 3), lds, s, c, a);
+  return hipGetLastError();
+}
+bool group_spec_chain_supported(const i2lqr_config& cfg, int64_t chains) {
+  if (!spec_plant_ok(cfg) || cfg.layout != I2LQR_LAYOUT_PROBLEM_MAJOR) return false;
+  const DeviceGeometry& geo = device_geometry();
+  if (chains > geo.scaled(kSpecWideBatch)) return false;  // three wavefronts per workgroup
+  const size_t lds = cfg.dtype == I2LQR_F64
+      ? (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<double, Bicycle4<double>, 3, 16>(cfg.N)
+                                             : spec_lds_bytes<double, Bicycle6<double>, 3, 16>(cfg.N))
+      : (cfg.system_id == I2LQR_SYS_BICYCLE4 ? spec_lds_bytes<float, Bicycle4<float>, 3, 16>(cfg.N)
+                                             : spec_lds_bytes<float, Bicycle6<float>, 3, 16>(cfg.N));
+  return lds <= geo.max_dyn_lds;
+}
+template <> hipError_t group_spec_chain<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
+                                                hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec_chain<double, Bicycle4<double>>(cfg, a, s);
+  return launch_spec_chain<double, Bicycle6<double>>(cfg, a, s);
+}
+template <> hipError_t group_spec_chain<float>(const i2lqr_config& cfg, const IterArgs<float>& a,
+                                               hipStream_t s) {
+  if (cfg.system_id == I2LQR_SYS_BICYCLE4) return launch_spec_chain<float, Bicycle4<float>>(cfg, a, s);
+  return launch_spec_chain<float, Bicycle6<float>>(cfg, a, s);
+}
+
 template <> hipError_t group_spec_iterate<double>(const i2lqr_config& cfg, const IterArgs<double>& a,
                                                   hipStream_t s, int lanes) {
   return launch_spec_any<double, false>(cfg, a, s, lanes);

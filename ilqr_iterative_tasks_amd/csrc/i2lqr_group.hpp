@@ -1291,9 +1291,15 @@ template <class Sys, int V, int G = kGroup> struct GSpecLayout {
 // tail of the chunked solve of the one-problem-per-lane layouts, see IterArgs and k_iterate): the
 // launch does nothing unless *count <= count_max, the iteration counters continue from iters[] and
 // stop at max_total.
-template <class T, class Sys, int V, bool SETIO = false, int G = kGroup>
+// CHAIN (round 6; the controller's chained regularisation, utils/base.py:393, :414-426): a.B CHAINS
+// of a.chain_len problems each, stored chain after chain; a workgroup solves the problems of its
+// chains one after the other, the final lamb of problem c being the initial lamb of problem c + 1
+// (lamb[] is read for the first problem of a chain only and written for all of them) — the 8
+// dependent solves of a lap's candidate list in ONE launch instead of eight.
+template <class T, class Sys, int V, bool SETIO = false, int G = kGroup, bool CHAIN = false>
 __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, Sys::m> c,
                                                        const IterArgs<T> a) {
+  static_assert(!(CHAIN && SETIO), "chains are problem-major batches");
   constexpr int n = Sys::n, m = Sys::m, W = n + m;
   using GL = GLayout<Sys, G>;
   using SL = GSpecLayout<Sys, V, G>;
@@ -1302,7 +1308,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   T* smem = reinterpret_cast<T*>(gsmem_raw);
   const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = lane / G, g = lane % G;
-  const int64_t prob0 = (int64_t)blockIdx.x * PW + p;
+  const int64_t prob0 = (int64_t)blockIdx.x * PW + p;  // (CHAIN: the chain's index)
   int64_t live = a.B;
   if constexpr (SETIO) {
     live = *a.count;
@@ -1310,7 +1316,10 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
   }
   const int64_t Bs = SETIO ? a.set_stride : 0;
   const bool real = prob0 < live;
-  const int64_t prob = real ? prob0 : live - 1;
+  const int clen = CHAIN ? a.chain_len : 1;
+  T lamb_carry = T(0);
+ for (int cstep = 0; cstep < clen; cstep++) {  // (one pass unless CHAIN)
+  const int64_t prob = CHAIN ? (real ? prob0 : live - 1) * clen + cstep : (real ? prob0 : live - 1);
   const SL SLay(c.N);
   const int N = c.N;
   T* const S = smem + p * SLay.total;
@@ -1346,7 +1355,7 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
 #pragma unroll
   for (int q = 0; q < 6; q++)
     ob[q] = a.obs ? (SETIO ? a.obs[q * Bs + prob] : a.obs[prob * 6 + q]) : T(q == 5 ? -1 : 1);
-  T lamb = a.lamb[prob];
+  T lamb = (CHAIN && cstep > 0) ? lamb_carry : a.lamb[prob];
   const int it0 = SETIO ? a.iters[prob] : 0;              // iterations of the earlier chunks
   const int it_cap = SETIO ? a.max_total - it0 : a.n_iters;
   const T ob_pa = T(1) / (ob[2] * ob[2]), ob_pb = T(1) / (ob[3] * ob[3]);
@@ -1499,6 +1508,8 @@ __global__ __launch_bounds__(64 * V) void k_group_spec(const DevCfg<T, Sys::n, S
       if (a.status) a.status[prob] = status;
     }
   }
+  lamb_carry = lamb;  // CHAIN: the next problem of the chain starts from it
+ }
 }
 
 }  // namespace i2lqr

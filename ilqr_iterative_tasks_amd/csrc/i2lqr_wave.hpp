@@ -112,6 +112,8 @@ template <class T> struct IterArgs {
   unsigned* pick_ticket = nullptr;     // the handle's ticket word (wraps to 0 by itself)
   int64_t* best_idx = nullptr;         // [1] out
   T* best_cost = nullptr;              // [1] out
+  // k_group_spec<.., CHAIN>: B chains of chain_len problems each, stored chain after chain
+  int chain_len = 1;
 };
 
 // relaxed terminal cost of one candidate, utils/base.py:427-437: ss = ||x_N - x_term||_2^2 summed in

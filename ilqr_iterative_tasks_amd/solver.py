@@ -306,6 +306,20 @@ class BatchedILQR:
                                              self._stream()))
         return buf
 
+    def solve_chained(self, buf: dict, chains: int, chain_len: int) -> dict:
+        """i2lqr_solve_chained: `chains` chains of `chain_len` problems each (problem-major buffers of
+        chains * chain_len problems, chain after chain) solved in ONE launch, the final lamb of a
+        chain's problem c seeding its problem c + 1 (utils/base.py:393, :414-426).  Raises I2lqrError
+        (I2LQR_ERR_UNSUPPORTED) where the chain kernel is not built."""
+        B = int(chains) * int(chain_len)
+        if self.batch_of(buf["X"]) != B:
+            raise ValueError(f"buffers hold {self.batch_of(buf['X'])} problems, {chains} chains of "
+                             f"{chain_len} need {B}")
+        with torch.cuda.device(self.device):
+            self._check(self.lib.i2lqr_solve_chained(self._handle, int(chains), int(chain_len),
+                                                     *self._iter_args(buf, B), self._stream()))
+        return buf
+
     def relax_cost(self, X, x_term, qfun, outer_iter: int, max_relax_iter: int = 55,
                    cost_it=None):
         """utils/base.py:427-437 for every candidate."""

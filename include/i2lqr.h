@@ -401,6 +401,24 @@ int i2lqr_solve(i2lqr_handle* h, int64_t B, void* X, void* U, const void* x_term
                 void* stream);
 
 /*
+ * The chained regularisation of the reference's candidate loops, ONE launch (round 6): inside one
+ * lap's candidate list `lamb` is carried from candidate to candidate — it is reset per lap
+ * (utils/base.py:393) and ilqr() returns the value the next call starts from (:414-426) —, the laps
+ * are independent.  `chains` chains of `chain_len` problems each, problem-major arrays of
+ * chains * chain_len problems stored chain after chain (problem c of chain a at index a * chain_len
+ * + c); lamb[] is READ for the first problem of every chain only and WRITTEN for all of them (what
+ * each ilqr() call returned); everything else as i2lqr_solve.  A workgroup of the sixteen-lane
+ * speculative kernel solves its chains' problems one after the other: bit-identical to chain_len
+ * calls of i2lqr_solve with lamb copied across, without their launches (~20 us each at N = 6).
+ * I2LQR_ERR_UNSUPPORTED where that kernel is not built (stage weights, quad12, lane layouts, more
+ * than 512 chains, a horizon whose three-wavefront buffers do not fit the LDS): solve the chain
+ * steps one after the other instead (the Python host's HipCandidateSolver.solve_chained does).
+ */
+int i2lqr_solve_chained(i2lqr_handle* h, int64_t chains, int32_t chain_len, void* X, void* U,
+                        const void* x_term, void* lamb, const void* obs, void* cost, void* K, void* k,
+                        int32_t* iters, int32_t* status, void* stream);
+
+/*
  * Relaxed terminal cost of each candidate — replaces utils/base.py:427-437:
  * smallest i in [1, max_relax_iter] with ||x_N - x_term||_2 <= 80 i / 10^outer_iter gives
  * cost_it = qfun + N + 100 i; a norm above 80 max_relax_iter / 10^outer_iter (or NaN) gives +inf.

@@ -285,11 +285,21 @@ def test_chain_on_the_device_equals_the_step_by_step_chain(torch_mod):
     rng = np.random.default_rng(5)
     x0 = np.array([0.0, 0.0, 1.0, 0.0])
     hs = HipCandidateSolver()
+    hs_steps = HipCandidateSolver()
+    hs_steps.use_chain_kernel = False  # a launch per chain step (hipGraph replay) for equal laps too
     for widths, obs in (((8, 8), (31.0, -3.0, 8.0, 6.0, 0.0, 0.0)), ((8, 5, 3), None), ((1,), None),
-                        ((4, 8), (12.0, 1.0, 6.0, 4.0, 0.0, 0.0))):
+                        ((4, 8), (12.0, 1.0, 6.0, 4.0, 0.0, 0.0)), ((6, 6, 6, 6, 6), None)):
         chains = [np.column_stack([rng.uniform(5, 40, w), rng.uniform(-4, 4, w),
                                    rng.uniform(0.5, 3, w), rng.uniform(-0.3, 0.3, w)]) for w in widths]
         got = hs.solve_chained(cfg, x0, chains, 1.0, obs)
+        # laps of equal length: ONE launch (i2lqr_solve_chained: k_group_spec<.., CHAIN>)
+        assert hs.chain_info["one_launch"] == (len(set(widths)) == 1)
+        for rep in range(2):  # (second call: the captured graph is replayed)
+            again = hs_steps.solve_chained(cfg, x0, chains, 1.0, obs)
+            assert hs_steps.chain_info["one_launch"] is False
+            for a in range(len(widths)):
+                for key in ("U", "X", "lamb", "cost", "iters", "status"):
+                    assert np.array_equal(again[a][key], got[a][key]), (widths, a, key, rep)
         lamb = np.full(len(widths), 1.0)
         for c in range(max(widths)):
             rows = [a for a, w in enumerate(widths) if c < w]

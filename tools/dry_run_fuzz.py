@@ -148,6 +148,11 @@ for it in range(args.configs):
         lambda: lib.i2lqr_argmin(h, B, cost_it, best_idx, best_cost, pick_ws, pick_bytes, STREAM),
         lambda: lib.i2lqr_pack_problem(h, B, X, U, best_idx, arena.take((m * N + n * (N + 1)) * item), STREAM),
     ]
+    for k_chain in (1, 2, 4, 8):  # chains: B problems as B / k chains of k (where k divides B)
+        if B % k_chain == 0 and B // k_chain <= 4096:
+            calls.append(lambda k_chain=k_chain: lib.i2lqr_solve_chained(
+                h, B // k_chain, k_chain, X, U, xt, lamb, obs_p, cost, Kp, kp, iters, status, STREAM))
+            break
 
     def sharded():
         world = int(rng.choice([1, 2, 3, 8]))
